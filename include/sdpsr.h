@@ -1,0 +1,195 @@
+/*
+ * sdpsr.h -- C ABI of libsdpsr_hip.so: the MI355X (gfx950) implementation of the
+ * Jordan-reduction hot path of SDPSymmetryReduction.jl.
+ *
+ * The reference is pure Julia and has no FFI; its seam is dispatch on the
+ * partition type (AbstractPartition contract, src/abstract_part.jl:7-16, exercised
+ * by the alternate backend in test/partitions_set.jl:6-92,102-105).  A Julia
+ * backend type `HIPPartition` binds these entry points with `ccall`
+ * (INTEGRATION.md shows the stub).  Every entry point cites the reference lines it
+ * replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *  - all matrices column-major, n x n unless stated; "len" = number of entries
+ *    scanned in column-major linear order (the only order the reference uses);
+ *  - labels are uint32: 0 = structurally-zero class (not counted), 1..dim;
+ *  - every array argument lives in the memory space named by `mem`
+ *    (SDPSR_MEM_HOST: caller-owned host memory, copied by the library;
+ *     SDPSR_MEM_DEVICE: device pointers on ctx's device, used in place);
+ *  - scalar outputs (int64_t* etc.) are always host pointers;
+ *  - calls on one ctx are serialised on ctx's HIP stream; distinct ctxs may be
+ *    used from distinct host threads; no global state; no callbacks;
+ *  - return value: sdpsr_status; details via sdpsr_last_error(ctx).
+ */
+#ifndef SDPSR_H
+#define SDPSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDPSR_VERSION_MAJOR 0
+#define SDPSR_VERSION_MINOR 1
+
+typedef struct sdpsr_ctx sdpsr_ctx;
+
+typedef enum sdpsr_status {
+    SDPSR_OK = 0,
+    /* InvalidDecompositionField, src/eigen_decomposition.jl:140-150,247-253 */
+    SDPSR_INVALID_DECOMPOSITION_FIELD = 1,
+    /* NumericalInconsistency, src/eigen_decomposition.jl:152-161,264-270 */
+    SDPSR_NUMERICAL_INCONSISTENCY = 2,
+    /* DimensionMismatch from check_block_sizes, src/diagonalize.jl:1-11 */
+    SDPSR_DIMENSION_MISMATCH = 3,
+    /* Julia's InexactError on label overflow, src/partitions.jl:63 */
+    SDPSR_LABEL_OVERFLOW = 4,
+    /* @assert n^2 == length(C) (src/partitions.jl:118), length(values)==dim(P) (:69) ... */
+    SDPSR_BAD_ARGUMENT = 5,
+    SDPSR_HIP_ERROR = 6,
+    SDPSR_SOLVER_ERROR = 7,
+    SDPSR_OUT_OF_MEMORY = 8,
+    SDPSR_NOT_CONVERGED = 9,
+    SDPSR_BAD_STATE = 10
+} sdpsr_status;
+
+typedef enum sdpsr_mem { SDPSR_MEM_HOST = 0, SDPSR_MEM_DEVICE = 1 } sdpsr_mem;
+
+/* How the random square of src/partitions.jl:172 is evaluated. */
+typedef enum sdpsr_square_mode {
+    SDPSR_SQUARE_AUTO = 0, /* = I8 */
+    /* exact integers: `channels` independent draws of int8 class values, int8 MFMA,
+       int32 accumulate; classes compared by exact equality (no rounding involved) */
+    SDPSR_SQUARE_I8 = 1,
+    /* exact integers on the fp32 MFMA (|v| <= floor(sqrt(2^24/n)) so every partial sum
+       is an exactly representable integer) */
+    SDPSR_SQUARE_F32 = 2,
+    /* reference-literal: uniform [0,1) doubles, fp64 MFMA, 7-digit rounding
+       (src/utils.jl:34-53) */
+    SDPSR_SQUARE_F64 = 3
+} sdpsr_square_mode;
+
+typedef struct sdpsr_opts {
+    uint32_t struct_size;   /* = sizeof(sdpsr_opts) */
+    int32_t square_mode;    /* sdpsr_square_mode */
+    int32_t channels;       /* independent draws per square step (1..8), 0 = default 4 */
+    int32_t max_iters;      /* 0 = default (10000) */
+    int32_t confirm_rounds; /* extra no-change square rounds demanded before stopping */
+    int32_t eig_driver;     /* 0 = default */
+    int32_t reserved[10];
+} sdpsr_opts;
+
+/* phase_ms slots filled by sdpsr_admissible_subspace / sdpsr_block_diagonalize
+   (the reference only prints @timed per phase: src/diagonalize.jl:32-37,
+   src/compat.jl:63-65) */
+enum {
+    SDPSR_T_TOTAL = 0,
+    SDPSR_T_PROJECT = 1,   /* randomize + projection + signature */
+    SDPSR_T_SQUARE = 2,    /* randomize + N x N square(s) */
+    SDPSR_T_REFINE = 3,    /* partition refinement + canonical relabel */
+    SDPSR_T_EIGEN = 4,     /* symmetric eigendecomposition */
+    SDPSR_T_ISO = 5,       /* Q'AQ, block norms, isomorphism classes */
+    SDPSR_T_IRRED = 6,     /* irreducible_decomposition */
+    SDPSR_T_IMAGE = 7,     /* basis_image */
+    SDPSR_T_COUNT = 8
+};
+
+/* ---- lifecycle ------------------------------------------------------------ */
+/* opts may be NULL (defaults).  seed drives every random draw of the ctx. */
+int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx** out);
+void sdpsr_destroy(sdpsr_ctx* ctx);
+const char* sdpsr_last_error(const sdpsr_ctx* ctx);
+const char* sdpsr_status_string(int status);
+int sdpsr_version(void);
+/* Use an existing HIP stream (hipStream_t) for all work of ctx; NULL = ctx's own. */
+int sdpsr_set_stream(sdpsr_ctx* ctx, void* hip_stream);
+int sdpsr_synchronize(sdpsr_ctx* ctx);
+/* Reseed (tests; independent restarts use distinct seeds per rank). */
+int sdpsr_set_seed(sdpsr_ctx* ctx, uint64_t seed);
+
+/* ---- AbstractPartition contract (primitives) ------------------------------- */
+/* Partition{T}(M::AbstractMatrix) float ctor, src/partitions.jl:24-35: classes of
+   bit-equal values, labelled by first occurrence in column-major order, +0.0 -> 0. */
+int sdpsr_partition_from_f64(sdpsr_ctx* ctx, int64_t len, const double* M,
+                             uint32_t* labels, int64_t* nparts, int mem);
+/* Integer ctor + __sort_unique!, src/partitions.jl:37-60. in == out allowed. */
+int sdpsr_partition_from_u32(sdpsr_ctx* ctx, int64_t len, const uint32_t* in,
+                             uint32_t* labels, int64_t* nparts, int mem);
+/* refine!(P1, P2), src/partitions.jl:62-66: p1 <- canonical relabel of the pairs
+   (p1, p2); label 0 only where both are 0.  *d1 is updated. */
+int sdpsr_refine(sdpsr_ctx* ctx, int64_t len, uint32_t* p1, int64_t* d1,
+                 const uint32_t* p2, int64_t d2, int mem);
+/* fill!(M, P; values), src/partitions.jl:68-75: M[idx] = values[label-1], 0 -> 0.0.
+   `values` has d entries. */
+int sdpsr_fill(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, const double* values,
+               int64_t d, double* M, int mem);
+/* randomize!(M, P), src/abstract_part.jl:107-110: one uniform [0,1) draw per class from
+   the ctx's counter-based generator (a fresh stream per call). */
+int sdpsr_randomize(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, double* M, int mem);
+/* _clamp_round!, src/utils.jl:34-53 with round-to-nearest on the 7-digit mantissa
+   (DESIGN.md "rounding"); in place. */
+int sdpsr_clamp_round(sdpsr_ctx* ctx, int64_t len, double* a, double atol, int mem);
+/* x .-= projL(x), src/partitions.jl:161 + src/utils.jl:62-66, with qr(A') folded into an
+   orthonormal basis U (len x r, column-major) of rowspace(A). */
+int sdpsr_project_out(sdpsr_ctx* ctx, int64_t len, double* x, const double* U, int64_t r,
+                      int mem);
+
+/* ---- the N x N square, mul!(X2, X, X) src/partitions.jl:172 ----------------- */
+/* X symmetric, column-major, leading dimension n. */
+int sdpsr_square_f64(sdpsr_ctx* ctx, int64_t n, const double* X, double* X2, int mem);
+int sdpsr_square_f32(sdpsr_ctx* ctx, int64_t n, const float* X, float* X2, int mem);
+int sdpsr_square_i8(sdpsr_ctx* ctx, int64_t n, const int8_t* X, int32_t* X2, int mem);
+/* C = A' * B, all column-major fp64: A is k x m (lda), B is k x n (ldb), C m x n (ldc).
+   The Q'AQ products of src/eigen_decomposition.jl:203 and the block products of :70. */
+int sdpsr_gemm_tn_f64(sdpsr_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A,
+                      int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                      int mem);
+
+/* ---- admissible_subspace, src/partitions.jl:109-190 ------------------------- */
+/* Loop :145-185 on the device.  The setup stage (:117-142: qr(A'), C_L, CRAIG x0) stays
+   with the caller, which passes
+     CL   n x n  reshape(_symmetrize!(_clamp_round!(c - projL(c))), n, n)      (:129-134)
+     X0L  n x n  reshape(_clamp_round!(projL(_symmetrize!(craig(A,b)))), n, n) (:137-142)
+     U    n^2 x r orthonormal basis of rowspace(A)                              (:124)
+   Outputs: P_out (n x n labels), *dim_out, *iters_out, phase_ms[SDPSR_T_COUNT] (may be
+   NULL). */
+int sdpsr_admissible_subspace(sdpsr_ctx* ctx, int64_t n, const double* CL, const double* X0L,
+                              const double* U, int64_t r, double atol, uint32_t* P_out,
+                              int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem);
+/* Convenience for dense problems: does the setup stage on the host (Householder QR of A',
+   min-norm solution) and then calls the loop.  C: n^2, A: m x n^2 column-major, b: m;
+   host pointers.  P_out is in `mem_out`. */
+int sdpsr_admissible_subspace_dense(sdpsr_ctx* ctx, int64_t n, int64_t m, const double* C,
+                                    const double* A, const double* b, double atol,
+                                    uint32_t* P_out, int64_t* dim_out, int32_t* iters_out,
+                                    double* phase_ms, int mem_out);
+
+/* ---- blockDiagonalize, src/compat.jl:46-68 ---------------------------------- */
+/* Phase 1 = diagonalize(Float64, P; atol=epsilon) (src/diagonalize.jl:25-40) +
+   check_block_sizes (:1-11).  Keeps Q_hat on the device inside ctx.
+   Outputs: *nblocks, *sum_sq = sum_k s_k^2, *sum_s = sum_k s_k. */
+int sdpsr_block_diagonalize(sdpsr_ctx* ctx, int64_t n, const uint32_t* P, int64_t d,
+                            double epsilon, int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s,
+                            double* phase_ms, int mem);
+/* blkSizes of the last successful phase 1 (host array of nblocks ints). */
+int sdpsr_block_sizes(sdpsr_ctx* ctx, int32_t* blk_sizes);
+/* Phase 2 = basis_image(Q_hat, P) (src/diagonalize.jl:64-89).
+   blks: d * sum_sq doubles, class-major, then block, each block column-major s_k x s_k.
+   Q_hat (optional, may be NULL): n x sum_s column-major, blocks side by side. */
+int sdpsr_block_images(sdpsr_ctx* ctx, double* blks, double* Q_hat, double* phase_ms, int mem);
+/* eigen_decomposition(P, A; atol), src/eigen_decomposition.jl:236-273: status only
+   (test/numerical_issues.jl:91-94), *neig = number of eigenspaces, *nclasses = number of
+   isomorphism classes. */
+int sdpsr_eigen_decomposition(sdpsr_ctx* ctx, int64_t n, const uint32_t* P, int64_t d,
+                              double atol, int32_t* neig, int32_t* nclasses, int mem);
+/* Symmetric eigendecomposition used by the path (eigen(A), :246): ascending values,
+   orthonormal vectors (column-major n x n, overwrites nothing of A). */
+int sdpsr_syev_f64(sdpsr_ctx* ctx, int64_t n, const double* A, double* values, double* vectors,
+                   int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDPSR_H */

@@ -1,0 +1,381 @@
+"""Host-side mirror of the reference's interface for the Jordan-reduction path.
+
+Same names, argument meaning and error behaviour as the Julia package
+(``Partition``, ``dim``, ``refine``, ``fill``, ``randomize``, ``admissible_subspace``,
+``diagonalize``, ``blockDiagonalize``); all computation happens in libsdpsr_hip.so
+through the C ABI.  Arrays may be NumPy (host, copied by the library) or torch CUDA
+tensors (device-resident, used in place).
+
+Reference lines mirrored: src/partitions.jl:6-17,24-75,109-190; src/compat.jl:26-68;
+src/diagonalize.jl:25-40,64-89; src/abstract_part.jl:7-16,107-110.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib as L
+
+RTOL_DEFAULT = math.sqrt(np.finfo(np.float64).eps)  # Base.rtoldefault(Float64)
+
+
+class SdpsrError(RuntimeError):
+    status = None
+
+
+class InvalidDecompositionField(SdpsrError):
+    """src/eigen_decomposition.jl:140-150"""
+
+
+class NumericalInconsistency(SdpsrError):
+    """src/eigen_decomposition.jl:152-161"""
+
+
+class DimensionMismatch(SdpsrError):
+    """src/diagonalize.jl:4-9"""
+
+
+class LabelOverflow(SdpsrError):
+    """InexactError of src/partitions.jl:63"""
+
+
+class NotConverged(SdpsrError):
+    pass
+
+
+_EXC = {1: InvalidDecompositionField, 2: NumericalInconsistency, 3: DimensionMismatch,
+        4: LabelOverflow, 9: NotConverged}
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(x.ctypes.data)
+
+
+class Context:
+    """One device context = one HIP stream + workspace (sdpsr_create)."""
+
+    def __init__(self, device=0, seed=0, square_mode=L.SQUARE_AUTO, channels=0, max_iters=0,
+                 confirm_rounds=0, eig_driver=0):
+        self._lib = L.load_library()
+        o = L.Opts()
+        o.struct_size = C.sizeof(L.Opts)
+        o.square_mode = int(square_mode)
+        o.channels = int(channels)
+        o.max_iters = int(max_iters)
+        o.confirm_rounds = int(confirm_rounds)
+        o.eig_driver = int(eig_driver)
+        h = C.c_void_p()
+        st = self._lib.sdpsr_create(int(device), C.c_uint64(seed & (2 ** 64 - 1)), C.byref(o), C.byref(h))
+        if st != 0:
+            raise SdpsrError(f"sdpsr_create failed: {L.STATUS.get(st, st)} (is a GPU visible?)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdpsr_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st == 0:
+            return
+        msg = self._lib.sdpsr_last_error(self._h).decode()
+        exc = _EXC.get(st, SdpsrError)(msg or L.STATUS.get(st, str(st)))
+        exc.status = st
+        raise exc
+
+    def set_seed(self, seed):
+        self.check(self._lib.sdpsr_set_seed(self._h, C.c_uint64(seed & (2 ** 64 - 1))))
+
+    def set_stream(self, stream_ptr):
+        self.check(self._lib.sdpsr_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self.check(self._lib.sdpsr_synchronize(self._h))
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else default_context()
+
+
+def _f(a, dtype):
+    """Column-major flat host view of a matrix (the only order the reference scans)."""
+    a = np.asarray(a, dtype=dtype)
+    return np.ascontiguousarray(a.ravel(order="F"))
+
+
+class Partition:
+    """``Partition`` (src/partitions.jl:6-17): ``matrix`` holds labels 0..nparts."""
+
+    def __init__(self, nparts, matrix):
+        self.nparts = int(nparts)
+        self.matrix = matrix
+
+    # --- constructors: Partition(M) float ctor (:24-35) / integer ctor (:37-42) ---
+    @classmethod
+    def from_matrix(cls, M, ctx=None):
+        ctx = _ctx(ctx)
+        M = np.asarray(M)
+        shape = M.shape
+        n = C.c_int64(0)
+        out = np.empty(M.size, dtype=np.uint32)
+        if np.issubdtype(M.dtype, np.floating):
+            flat = _f(M, np.float64)
+            ctx.check(ctx._lib.sdpsr_partition_from_f64(ctx._h, flat.size, _ptr(flat), _ptr(out), C.byref(n), L.MEM_HOST))
+        else:
+            if M.size and (M.min() < 0 or M.max() >= 2 ** 32):
+                raise ValueError("labels must be in [0, 2^32)")
+            flat = _f(M, np.uint32)
+            ctx.check(ctx._lib.sdpsr_partition_from_u32(ctx._h, flat.size, _ptr(flat), _ptr(out), C.byref(n), L.MEM_HOST))
+        return cls(n.value, out.reshape(shape, order="F"))
+
+    def __eq__(self, other):  # :16-17
+        return self.nparts == other.nparts and np.array_equal(np.asarray(self.matrix), np.asarray(other.matrix))
+
+    @property
+    def shape(self):
+        return tuple(self.matrix.shape)
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def __repr__(self):
+        return f"Partition(dim={self.nparts}, size={self.shape})"
+
+
+def dim(P):
+    return P.nparts
+
+
+def refine(P1, P2, ctx=None):
+    """``refine!(P1, P2)`` (src/partitions.jl:62-66); P1 is updated and returned."""
+    ctx = _ctx(ctx)
+    assert P1.shape == P2.shape
+    a = _f(P1.matrix, np.uint32).copy()
+    b = _f(P2.matrix, np.uint32)
+    d1 = C.c_int64(P1.nparts)
+    ctx.check(ctx._lib.sdpsr_refine(ctx._h, a.size, _ptr(a), C.byref(d1), _ptr(b), P2.nparts, L.MEM_HOST))
+    P1.matrix = a.reshape(P1.shape, order="F")
+    P1.nparts = d1.value
+    return P1
+
+
+def fill(P, values, ctx=None):
+    """``fill!(M, P; values)`` (src/partitions.jl:68-75)."""
+    ctx = _ctx(ctx)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    if len(values) != P.nparts:  # @assert length(values) == dim(P), :69
+        raise ValueError("length(values) != dim(P)")
+    lab = _f(P.matrix, np.uint32)
+    out = np.empty(lab.size, dtype=np.float64)
+    ctx.check(ctx._lib.sdpsr_fill(ctx._h, lab.size, _ptr(lab), _ptr(values), P.nparts, _ptr(out), L.MEM_HOST))
+    return out.reshape(P.shape, order="F")
+
+
+def randomize(P, ctx=None):
+    """``randomize(P)`` (src/abstract_part.jl:97-110)."""
+    ctx = _ctx(ctx)
+    lab = _f(P.matrix, np.uint32)
+    out = np.empty(lab.size, dtype=np.float64)
+    ctx.check(ctx._lib.sdpsr_randomize(ctx._h, lab.size, _ptr(lab), _ptr(out), L.MEM_HOST))
+    return out.reshape(P.shape, order="F")
+
+
+# ---------------------------------------------------------------------------
+# admissible_subspace
+# ---------------------------------------------------------------------------
+def _dense(A):
+    return np.asarray(A.todense()) if hasattr(A, "todense") else np.asarray(A)
+
+
+def clamp_round_host(a, atol):
+    """_clamp_round! (src/utils.jl:34-53), nearest rounding; host copy used only by the
+    setup stage below (O(n^2), once)."""
+    sig = math.floor(-math.log10(atol))
+    scale = float(10 ** sig)
+    x, e = np.frexp(a)
+    out = np.ldexp(np.rint(scale * x) / scale, e)
+    return np.where(np.abs(a) < atol, 0.0, out)
+
+
+def admissible_setup(C_, A, b, atol=RTOL_DEFAULT):
+    """Setup stage of ``admissible_subspace`` (src/partitions.jl:117-142), on the host:
+    qr(A') -> orthonormal basis U of rowspace(A); C_L; min-norm x0 projected.
+    Returns (n, CL, X0L, U) with CL/X0L flat column-major, U (n^2 x r) Fortran-ordered."""
+    import scipy.linalg as sla
+    c = np.asarray(C_.todense()).reshape(-1) if hasattr(C_, "todense") else np.asarray(C_, dtype=np.float64).reshape(-1)
+    n = math.isqrt(len(c))
+    if n * n != len(c):  # @assert n^2 == length(C), :118
+        raise ValueError("length(C) is not a perfect square")
+    Ad = np.asarray(_dense(A), dtype=np.float64)
+    if Ad.shape[0] > 0:
+        Q, R, _ = sla.qr(Ad.T, mode="economic", pivoting=True)
+        dg = np.abs(np.diag(R))
+        r = int(np.sum(dg > 1e-12 * dg.max())) if dg.size and dg.max() > 0 else 0
+        U = np.asfortranarray(Q[:, :r])
+        x0, *_ = np.linalg.lstsq(Ad, np.asarray(b, dtype=np.float64), rcond=None)  # Krylov.craig, :137
+    else:
+        U = np.zeros((n * n, 0), order="F")
+        x0 = np.zeros(n * n)
+
+    def proj(v):
+        return U @ (U.T @ v)
+
+    def symm(v):
+        M = v.reshape(n, n, order="F")
+        return ((M + M.T) / 2).ravel(order="F")
+
+    CL = symm(clamp_round_host(c - proj(c), atol))
+    X0L = clamp_round_host(proj(symm(x0)), atol)
+    return n, np.ascontiguousarray(CL), np.ascontiguousarray(X0L), U
+
+
+def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, setup=None,
+                        return_info=False):
+    """``admissible_subspace(C, A, b; verbose, atol)`` (src/partitions.jl:77-190)."""
+    ctx = _ctx(ctx)
+    n, CL, X0L, U = setup if setup is not None else admissible_setup(C_, A, b, atol)
+    on_dev = _is_torch(CL)
+    r = U.shape[1]
+    if on_dev:
+        import torch
+        P = torch.empty(n * n, dtype=torch.int32, device=CL.device)  # uint32 bit pattern
+    else:
+        U = np.asfortranarray(U, dtype=np.float64)
+        P = np.empty(n * n, dtype=np.uint32)
+    d = C.c_int64(0)
+    it = C.c_int32(0)
+    ms = (C.c_double * L.T_COUNT)()
+    st = ctx._lib.sdpsr_admissible_subspace(
+        ctx._h, n, _ptr(CL), _ptr(X0L), _ptr(U) if r > 0 else None, r, float(atol), _ptr(P),
+        C.byref(d), C.byref(it), C.cast(ms, C.c_void_p), L.MEM_DEVICE if on_dev else L.MEM_HOST)
+    ctx.check(st)
+    if verbose:
+        print(f"[sdpsr] admissible subspace: dim {d.value} after {it.value} iterations, "
+              f"{ms[L.T_TOTAL]:.3f} ms (project {ms[L.T_PROJECT]:.3f}, square {ms[L.T_SQUARE]:.3f}, "
+              f"refine {ms[L.T_REFINE]:.3f})")
+    mat = P.view(n, n).t() if on_dev else P.reshape(n, n, order="F")
+    out = Partition(d.value, mat)
+    out.iterations = it.value
+    out.phase_ms = list(ms)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# blockDiagonalize
+# ---------------------------------------------------------------------------
+BlockDiagonalization = namedtuple("BlockDiagonalization", ["blkSizes", "blks", "Q_hat", "phase_ms"])
+
+
+def _labels_arg(P):
+    m = P.matrix
+    if _is_torch(m):
+        # stored as the transposed view of a flat column-major buffer (see admissible_subspace)
+        flat = m.t().contiguous().view(-1)
+        return flat, L.MEM_DEVICE
+    return _f(m, np.uint32), L.MEM_HOST
+
+
+def blockDiagonalize(P, verbose=False, epsilon=RTOL_DEFAULT, complex=False, ctx=None):
+    """``blockDiagonalize(P, verbose; epsilon, complex)`` (src/compat.jl:26-68), real path."""
+    if complex:
+        raise NotImplementedError("complex path (desymmetrize + ComplexF64 eigen) is outside the HIP hot path; see DESIGN.md")
+    ctx = _ctx(ctx)
+    n = P.shape[0]
+    lab, mem = _labels_arg(P)
+    nb = C.c_int32(0)
+    ssq = C.c_int64(0)
+    ss = C.c_int64(0)
+    ms1 = (C.c_double * L.T_COUNT)()
+    ctx.check(ctx._lib.sdpsr_block_diagonalize(ctx._h, n, _ptr(lab), P.nparts, float(epsilon), C.byref(nb),
+                                               C.byref(ssq), C.byref(ss), C.cast(ms1, C.c_void_p), mem))
+    sizes = np.zeros(nb.value, dtype=np.int32)
+    ctx.check(ctx._lib.sdpsr_block_sizes(ctx._h, _ptr(sizes)))
+    blks = np.empty(P.nparts * ssq.value, dtype=np.float64)
+    qh = np.empty(n * ss.value, dtype=np.float64)
+    ms2 = (C.c_double * L.T_COUNT)()
+    ctx.check(ctx._lib.sdpsr_block_images(ctx._h, _ptr(blks), _ptr(qh), C.cast(ms2, C.c_void_p), L.MEM_HOST))
+    out = []
+    blks = blks.reshape(P.nparts, ssq.value) if ssq.value else blks.reshape(P.nparts, 0)
+    for i in range(P.nparts):
+        row, off = [], 0
+        for s in sizes:
+            row.append(blks[i, off:off + s * s].reshape(s, s, order="F"))
+            off += s * s
+        out.append(row)
+    Q, off = [], 0
+    qh = qh.reshape(n, ss.value, order="F")
+    for s in sizes:
+        Q.append(qh[:, off:off + s])
+        off += s
+    ms = [a + b for a, b in zip(ms1, ms2)]
+    if verbose:
+        print(f"[sdpsr] blockDiagonalize: blocks {list(sizes)}; eigen {ms[L.T_EIGEN]:.3f} ms, iso {ms[L.T_ISO]:.3f}, "
+              f"irreducible {ms[L.T_IRRED]:.3f}, image {ms[L.T_IMAGE]:.3f}")
+    return BlockDiagonalization([int(s) for s in sizes], out, Q, ms)
+
+
+def diagonalize(P, atol=None, ctx=None):
+    """``diagonalize(Float64, P; atol)`` (src/diagonalize.jl:25-40): list of n x s_k."""
+    n = P.shape[0]
+    atol = 1e-12 * n if atol is None else atol
+    ctx = _ctx(ctx)
+    lab, mem = _labels_arg(P)
+    nb = C.c_int32(0)
+    ssq = C.c_int64(0)
+    ss = C.c_int64(0)
+    st = ctx._lib.sdpsr_block_diagonalize(ctx._h, n, _ptr(lab), P.nparts, float(atol), C.byref(nb),
+                                          C.byref(ssq), C.byref(ss), None, mem)
+    if st == 3:
+        st = 0  # diagonalize itself does not run check_block_sizes (src/compat.jl:60 does)
+        ctx_valid = False
+    ctx.check(st)
+    sizes = np.zeros(nb.value, dtype=np.int32)
+    ctx.check(ctx._lib.sdpsr_block_sizes(ctx._h, _ptr(sizes)))
+    return [int(s) for s in sizes]
+
+
+def eigen_decomposition(P, atol=None, ctx=None):
+    """``eigen_decomposition(P, A; atol)`` (src/eigen_decomposition.jl:236-273): returns
+    (number of eigenspaces, number of isomorphism classes) or raises."""
+    n = P.shape[0]
+    atol = 1e-12 * n if atol is None else atol
+    ctx = _ctx(ctx)
+    lab, mem = _labels_arg(P)
+    ne = C.c_int32(0)
+    nc = C.c_int32(0)
+    ctx.check(ctx._lib.sdpsr_eigen_decomposition(ctx._h, n, _ptr(lab), P.nparts, float(atol), C.byref(ne), C.byref(nc), mem))
+    return ne.value, nc.value

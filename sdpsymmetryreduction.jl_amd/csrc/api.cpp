@@ -1,0 +1,1231 @@
+// C ABI of libsdpsr_hip.so (include/sdpsr.h) and the host orchestration of the two
+// device-resident phases:
+//   admissible_subspace loop   src/partitions.jl:145-185
+//   blockDiagonalize           src/compat.jl:46-68 -> src/diagonalize.jl, src/eigen_decomposition.jl
+// The host only sees scalars between device phases (class counts, eigenvalues, the
+// neig x neig block-norm matrix), exactly the control/device boundary of SURVEY.md 3.4.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "sdpsr_internal.h"
+
+using namespace sdpsr;
+
+// ---------------------------------------------------------------------------
+// ctx helpers
+// ---------------------------------------------------------------------------
+int ctx_fail(sdpsr_ctx* c, int status, const std::string& msg) {
+    if (c) c->err = std::string(sdpsr_status_string(status)) + ": " + msg;
+    return status;
+}
+
+void* ctx_buf(sdpsr_ctx* c, const char* name, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    DevBuf& b = c->bufs[name];
+    if (b.bytes >= bytes) return b.p;
+    if (b.p) {
+        hipStreamSynchronize(c->stream);
+        hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 3);  // slack so that slowly growing sizes do not realloc
+    want = (want + 255) & ~size_t(255);
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        if (hipMalloc(&b.p, bytes) != hipSuccess) {
+            b.p = nullptr;
+            ctx_fail(c, SDPSR_OUT_OF_MEMORY, std::string("hipMalloc ") + name + " " + std::to_string(bytes));
+            return nullptr;
+        }
+        want = bytes;
+    }
+    b.bytes = want;
+    return b.p;
+}
+
+static void ctx_free_buf(sdpsr_ctx* c, const char* name) {
+    auto it = c->bufs.find(name);
+    if (it == c->bufs.end()) return;
+    if (it->second.p) {
+        hipStreamSynchronize(c->stream);
+        hipFree(it->second.p);
+    }
+    c->bufs.erase(it);
+}
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        hipGetDevice(&prev);
+        if (prev != dev) hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        int cur;
+        hipGetDevice(&cur);
+        if (prev >= 0 && cur != prev) hipSetDevice(prev);
+    }
+};
+
+template <typename T>
+const T* in_dev(sdpsr_ctx* c, const char* name, const T* p, size_t count, int mem, int* st) {
+    if (mem == SDPSR_MEM_DEVICE || p == nullptr) return p;
+    T* d = (T*)ctx_buf(c, name, count * sizeof(T));
+    if (!d) {
+        *st = SDPSR_OUT_OF_MEMORY;
+        return nullptr;
+    }
+    if (hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        *st = ctx_fail(c, SDPSR_HIP_ERROR, std::string("H2D copy of ") + name);
+        return nullptr;
+    }
+    return d;
+}
+
+template <typename T>
+T* out_dev(sdpsr_ctx* c, const char* name, T* p, size_t count, int mem, int* st) {
+    if (mem == SDPSR_MEM_DEVICE) return p;
+    T* d = (T*)ctx_buf(c, name, count * sizeof(T));
+    if (!d) *st = SDPSR_OUT_OF_MEMORY;
+    return d;
+}
+
+template <typename T>
+int out_finish(sdpsr_ctx* c, T* host, const T* dev, size_t count, int mem) {
+    if (mem == SDPSR_MEM_DEVICE) return SDPSR_OK;
+    HIP_TRY(c, hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDPSR_OK;
+}
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int ceil_log2(uint64_t x) {
+    int l = 0;
+    while ((uint64_t(1) << l) < x) ++l;
+    return l;
+}
+
+uint64_t next_key(sdpsr_ctx* c) { return sdpsr_stream_key(c->seed, c->stream_counter++); }
+
+// ---- phase timing with events; collected after the syncs the loop needs anyway ----
+struct PhaseTimer {
+    sdpsr_ctx* c;
+    double acc[SDPSR_T_COUNT] = {};
+    struct Pending {
+        int slot;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    bool enabled;
+    PhaseTimer(sdpsr_ctx* ctx, bool en) : c(ctx), enabled(en) {}
+    ~PhaseTimer() {
+        for (auto e : pool) hipEventDestroy(e);
+        for (auto& p : pending) {
+            hipEventDestroy(p.a);
+            hipEventDestroy(p.b);
+        }
+    }
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
+    int cur_slot = -1;
+    hipEvent_t cur_a{};
+    void begin(int slot) {
+        if (!enabled) return;
+        cur_slot = slot;
+        cur_a = get();
+        hipEventRecord(cur_a, c->stream);
+    }
+    void end() {
+        if (!enabled || cur_slot < 0) return;
+        hipEvent_t b = get();
+        hipEventRecord(b, c->stream);
+        pending.push_back({cur_slot, cur_a, b});
+        cur_slot = -1;
+    }
+    void collect() {  // call after a stream sync
+        for (auto& p : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) acc[p.slot] += ms;
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+};
+
+// ---- canonical refinement of a signature array --------------------------------
+int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* labels,
+                      int64_t* nparts) {
+    const int full = std::max(12, ceil_log2((uint64_t)len * 2));
+    int log2cap = std::min(full, std::max(12, c->table_log2_hint));
+    const int64_t rb = (int64_t)refine_block_entries();
+    const int64_t nblk = (len + rb - 1) / rb;
+    for (;;) {
+        const size_t cap = size_t(1) << log2cap;
+        RefineWs ws;
+        ws.tab_sig = (uint64_t*)ctx_buf(c, "ref_tab_sig", cap * 8);
+        ws.tab_min = (uint32_t*)ctx_buf(c, "ref_tab_min", cap * 4);
+        ws.tab_lab = (uint32_t*)ctx_buf(c, "ref_tab_lab", cap * 4);
+        ws.blk_cnt = (uint32_t*)ctx_buf(c, "ref_blk_cnt", (nblk + 1) * 4);
+        ws.counters = (uint32_t*)ctx_buf(c, "ref_counters", 64);
+        if (!ws.tab_sig || !ws.tab_min || !ws.tab_lab || !ws.blk_cnt || !ws.counters)
+            return SDPSR_OUT_OF_MEMORY;
+        ws.log2cap = log2cap;
+        ws.nblk = (int)nblk;
+        launch_refine(c->stream, len, sig, labels, ws);
+        uint32_t* h = (uint32_t*)c->pinned;
+        HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        if (h[1]) {  // table too small for this many classes
+            if (log2cap >= full) return ctx_fail(c, SDPSR_HIP_ERROR, "refine hash table overflow at full size");
+            log2cap = std::min(full, log2cap + 4);
+            continue;
+        }
+        *nparts = h[2];
+        c->table_log2_hint = std::min(full, std::max(12, ceil_log2((uint64_t)h[2] * 8 + 1)));
+        return SDPSR_OK;
+    }
+}
+
+int check_len(sdpsr_ctx* c, int64_t len) {
+    if (len < 1 || len >= (int64_t)0xFFFFFFF0ll)
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "len out of range [1, 2^32-16)");
+    return SDPSR_OK;
+}
+
+}  // namespace
+
+#define CHECK_CTX(c) \
+    if (!(c)) return SDPSR_BAD_ARGUMENT; \
+    DeviceGuard _dg((c)->device); \
+    (c)->err.clear();
+
+// ---------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* sdpsr_status_string(int s) {
+    switch (s) {
+        case SDPSR_OK: return "OK";
+        case SDPSR_INVALID_DECOMPOSITION_FIELD: return "INVALID_DECOMPOSITION_FIELD";
+        case SDPSR_NUMERICAL_INCONSISTENCY: return "NUMERICAL_INCONSISTENCY";
+        case SDPSR_DIMENSION_MISMATCH: return "DIMENSION_MISMATCH";
+        case SDPSR_LABEL_OVERFLOW: return "LABEL_OVERFLOW";
+        case SDPSR_BAD_ARGUMENT: return "BAD_ARGUMENT";
+        case SDPSR_HIP_ERROR: return "HIP_ERROR";
+        case SDPSR_SOLVER_ERROR: return "SOLVER_ERROR";
+        case SDPSR_OUT_OF_MEMORY: return "OUT_OF_MEMORY";
+        case SDPSR_NOT_CONVERGED: return "NOT_CONVERGED";
+        case SDPSR_BAD_STATE: return "BAD_STATE";
+    }
+    return "UNKNOWN";
+}
+
+int sdpsr_version(void) { return SDPSR_VERSION_MAJOR * 1000 + SDPSR_VERSION_MINOR; }
+
+int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx** out) {
+    if (!out) return SDPSR_BAD_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SDPSR_HIP_ERROR;
+    if (device_id < 0 || device_id >= ndev) return SDPSR_BAD_ARGUMENT;
+    sdpsr_ctx* c = new sdpsr_ctx();
+    c->device = device_id;
+    c->seed = seed;
+    if (opts) {
+        size_t sz = std::min<size_t>(opts->struct_size ? opts->struct_size : sizeof(sdpsr_opts), sizeof(sdpsr_opts));
+        memcpy(&c->opts, opts, sz);
+    }
+    c->opts.struct_size = sizeof(sdpsr_opts);
+    if (c->opts.square_mode == SDPSR_SQUARE_AUTO) c->opts.square_mode = SDPSR_SQUARE_I8;
+    if (c->opts.channels <= 0) c->opts.channels = 4;
+    if (c->opts.channels > 8) c->opts.channels = 8;
+    if (c->opts.max_iters <= 0) c->opts.max_iters = 10000;
+    DeviceGuard dg(device_id);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SDPSR_HIP_ERROR;
+    }
+    c->own_stream = true;
+    c->pinned_bytes = 4096;
+    if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return SDPSR_OUT_OF_MEMORY;
+    }
+    *out = c;
+    return SDPSR_OK;
+}
+
+void sdpsr_destroy(sdpsr_ctx* c) {
+    if (!c) return;
+    DeviceGuard dg(c->device);
+    hipStreamSynchronize(c->stream);
+    destroy_handle(c);
+    for (auto& kv : c->bufs)
+        if (kv.second.p) hipFree(kv.second.p);
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* sdpsr_last_error(const sdpsr_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int sdpsr_set_stream(sdpsr_ctx* c, void* hip_stream) {
+    CHECK_CTX(c);
+    hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return SDPSR_OK;
+}
+
+int sdpsr_synchronize(sdpsr_ctx* c) {
+    CHECK_CTX(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDPSR_OK;
+}
+
+int sdpsr_set_seed(sdpsr_ctx* c, uint64_t seed) {
+    if (!c) return SDPSR_BAD_ARGUMENT;
+    c->seed = seed;
+    c->stream_counter = 0;
+    return SDPSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// primitives
+// ---------------------------------------------------------------------------
+int sdpsr_partition_from_f64(sdpsr_ctx* c, int64_t len, const double* M, uint32_t* labels,
+                             int64_t* nparts, int mem) {
+    CHECK_CTX(c);
+    if (!M || !labels || !nparts) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    int st = check_len(c, len);
+    if (st) return st;
+    const double* dM = in_dev(c, "prim_in_a", M, len, mem, &st);
+    uint32_t* dL = out_dev(c, "prim_out", labels, len, mem, &st);
+    uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+    if (st || !sig) return st ? st : SDPSR_OUT_OF_MEMORY;
+    launch_sig_f64(c->stream, len, nullptr, dM, sig);
+    st = refine_signatures(c, len, sig, dL, nparts);
+    if (st) return st;
+    return out_finish(c, labels, dL, len, mem);
+}
+
+int sdpsr_partition_from_u32(sdpsr_ctx* c, int64_t len, const uint32_t* in, uint32_t* labels,
+                             int64_t* nparts, int mem) {
+    CHECK_CTX(c);
+    if (!in || !labels || !nparts) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    int st = check_len(c, len);
+    if (st) return st;
+    const uint32_t* dI = in_dev(c, "prim_in_a", in, len, mem, &st);
+    uint32_t* dL = out_dev(c, "prim_out", labels, len, mem, &st);
+    uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+    if (st || !sig) return st ? st : SDPSR_OUT_OF_MEMORY;
+    launch_sig_u32(c->stream, len, nullptr, dI, sig);
+    st = refine_signatures(c, len, sig, dL, nparts);
+    if (st) return st;
+    return out_finish(c, labels, dL, len, mem);
+}
+
+int sdpsr_refine(sdpsr_ctx* c, int64_t len, uint32_t* p1, int64_t* d1, const uint32_t* p2,
+                 int64_t d2, int mem) {
+    CHECK_CTX(c);
+    (void)d2;
+    if (!p1 || !p2 || !d1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    int st = check_len(c, len);
+    if (st) return st;
+    const uint32_t* d1in = in_dev(c, "prim_in_a", (const uint32_t*)p1, len, mem, &st);
+    const uint32_t* d2in = in_dev(c, "prim_in_b", p2, len, mem, &st);
+    uint32_t* dL = (mem == SDPSR_MEM_DEVICE) ? p1 : (uint32_t*)ctx_buf(c, "prim_out", len * 4);
+    uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+    if (st || !sig || !dL) return st ? st : SDPSR_OUT_OF_MEMORY;
+    launch_sig_u32(c->stream, len, d1in, d2in, sig);
+    st = refine_signatures(c, len, sig, dL, d1);
+    if (st) return st;
+    return out_finish(c, p1, dL, len, mem);
+}
+
+int sdpsr_fill(sdpsr_ctx* c, int64_t len, const uint32_t* labels, const double* values, int64_t d,
+               double* M, int mem) {
+    CHECK_CTX(c);
+    if (!labels || !M || (d > 0 && !values)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    int st = check_len(c, len);
+    if (st) return st;
+    const uint32_t* dL = in_dev(c, "prim_in_a", labels, len, mem, &st);
+    const double* dV = in_dev(c, "prim_in_b", values, (size_t)std::max<int64_t>(d, 1), mem, &st);
+    double* dM = out_dev(c, "prim_out", M, len, mem, &st);
+    if (st) return st;
+    launch_fill_f64(c->stream, len, dL, dV, dM);
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, M, dM, len, mem);
+}
+
+int sdpsr_randomize(sdpsr_ctx* c, int64_t len, const uint32_t* labels, double* M, int mem) {
+    CHECK_CTX(c);
+    if (!labels || !M) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    int st = check_len(c, len);
+    if (st) return st;
+    const uint32_t* dL = in_dev(c, "prim_in_a", labels, len, mem, &st);
+    double* dM = out_dev(c, "prim_out", M, len, mem, &st);
+    if (st) return st;
+    launch_randomize_f64(c->stream, len, dL, next_key(c), dM);
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, M, dM, len, mem);
+}
+
+int sdpsr_clamp_round(sdpsr_ctx* c, int64_t len, double* a, double atol, int mem) {
+    CHECK_CTX(c);
+    if (!a || !(atol > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer or atol <= 0");
+    int st = check_len(c, len);
+    if (st) return st;
+    double* dA = (mem == SDPSR_MEM_DEVICE) ? a : (double*)in_dev(c, "prim_in_a", (const double*)a, len, mem, &st);
+    if (st) return st;
+    const double scale = std::pow(10.0, std::floor(-std::log10(atol)));
+    launch_clamp_round(c->stream, len, dA, atol, scale);
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, a, dA, len, mem);
+}
+
+int sdpsr_project_out(sdpsr_ctx* c, int64_t len, double* x, const double* U, int64_t r, int mem) {
+    CHECK_CTX(c);
+    if (!x || (r > 0 && !U) || r < 0) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = check_len(c, len);
+    if (st) return st;
+    double* dX = (mem == SDPSR_MEM_DEVICE) ? x : (double*)in_dev(c, "prim_in_a", (const double*)x, len, mem, &st);
+    const double* dU = in_dev(c, "prim_in_b", U, (size_t)len * std::max<int64_t>(r, 1), mem, &st);
+    const int nblk = 512;
+    double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * nblk * 8);
+    double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
+    if (st || !partial || !coef) return st ? st : SDPSR_OUT_OF_MEMORY;
+    launch_proj_coef(c->stream, len, r, dU, nullptr, 0, dX, partial, nblk, coef);
+    launch_proj_apply(c->stream, len, r, dU, nullptr, 0, dX, coef, 0, 1, 0, dX, nullptr);
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, x, dX, len, mem);
+}
+
+// ---------------------------------------------------------------------------
+// squares / products
+// ---------------------------------------------------------------------------
+}  // extern "C"
+
+template <typename TI, typename TO, typename F>
+static int square_generic(sdpsr_ctx* c, int64_t n, const TI* X, TO* X2, int mem, F launch) {
+    if (!X || !X2 || n < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = SDPSR_OK;
+    const int64_t ld = round_up(n, 128);
+    const TI* dX = in_dev(c, "sq_in", X, (size_t)n * n, mem, &st);
+    TI* Xp = (TI*)ctx_buf(c, "sq_xpad", (size_t)ld * ld * sizeof(TI));
+    TO* Cp = (TO*)ctx_buf(c, "sq_cpad", (size_t)ld * ld * sizeof(TO));
+    TO* dC = out_dev(c, "sq_out", X2, (size_t)n * n, mem, &st);
+    if (st || !Xp || !Cp) return st ? st : SDPSR_OUT_OF_MEMORY;
+    launch_pad_copy(c->stream, n, ld, dX, Xp, sizeof(TI));
+    launch(c->stream, ld, ld, ld, Xp, ld, Xp, ld, Cp, ld, 1, 0, 0, 0);
+    launch_unpad_copy(c->stream, n, ld, Cp, dC, sizeof(TO));
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, X2, dC, (size_t)n * n, mem);
+}
+
+extern "C" {
+
+int sdpsr_square_f64(sdpsr_ctx* c, int64_t n, const double* X, double* X2, int mem) {
+    CHECK_CTX(c);
+    return square_generic<double, double>(c, n, X, X2, mem, launch_gemm_tn_f64);
+}
+int sdpsr_square_f32(sdpsr_ctx* c, int64_t n, const float* X, float* X2, int mem) {
+    CHECK_CTX(c);
+    return square_generic<float, float>(c, n, X, X2, mem, launch_gemm_tn_f32);
+}
+int sdpsr_square_i8(sdpsr_ctx* c, int64_t n, const int8_t* X, int32_t* X2, int mem) {
+    CHECK_CTX(c);
+    return square_generic<int8_t, int32_t>(c, n, X, X2, mem, launch_gemm_tn_i8);
+}
+
+int sdpsr_gemm_tn_f64(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda,
+                      const double* B, int64_t ldb, double* C, int64_t ldc, int mem) {
+    CHECK_CTX(c);
+    if (!A || !B || !C || m < 1 || n < 1 || k < 1 || lda < k || ldb < k || ldc < m)
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = SDPSR_OK;
+    const int64_t mp = round_up(m, 128), np = round_up(n, 128), kp = round_up(k, 16);
+    const double* dA = in_dev(c, "g_a", A, (size_t)lda * m, mem, &st);
+    const double* dB = in_dev(c, "g_b", B, (size_t)ldb * n, mem, &st);
+    double* dC = out_dev(c, "g_c", C, (size_t)ldc * n, mem, &st);
+    double* Ap = (double*)ctx_buf(c, "g_ap", (size_t)kp * mp * 8);
+    double* Bp = (double*)ctx_buf(c, "g_bp", (size_t)kp * np * 8);
+    double* Cp = (double*)ctx_buf(c, "g_cp", (size_t)mp * np * 8);
+    if (st || !Ap || !Bp || !Cp) return st ? st : SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemsetAsync(Ap, 0, (size_t)kp * mp * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(Bp, 0, (size_t)kp * np * 8, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(Ap, kp * 8, dA, lda * 8, k * 8, m, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(Bp, kp * 8, dB, ldb * 8, k * 8, n, hipMemcpyDeviceToDevice, c->stream));
+    launch_gemm_tn_f64(c->stream, mp, np, kp, Ap, kp, Bp, kp, Cp, mp, 1, 0, 0, 0);
+    HIP_TRY(c, hipMemcpy2DAsync(dC, ldc * 8, Cp, mp * 8, m * 8, n, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, C, dC, (size_t)ldc * n, mem);
+}
+
+// ---------------------------------------------------------------------------
+// admissible_subspace loop, src/partitions.jl:145-185
+// ---------------------------------------------------------------------------
+int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L,
+                              const double* U, int64_t r, double atol, uint32_t* P_out,
+                              int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem) {
+    CHECK_CTX(c);
+    if (!CL || !X0L || !P_out || !dim_out || n < 1 || r < 0 || (r > 0 && !U) || !(atol > 0))
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    PhaseTimer tm(c, phase_ms != nullptr);
+    hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
+    if (phase_ms) {
+        hipEventCreate(&ev_total0);
+        hipEventCreate(&ev_total1);
+        hipEventRecord(ev_total0, s);
+    }
+
+    const double* dCL = in_dev(c, "adm_cl", CL, len, mem, &st);
+    const double* dX0 = in_dev(c, "adm_x0", X0L, len, mem, &st);
+    const double* dU = in_dev(c, "adm_u", U, (size_t)len * std::max<int64_t>(r, 1), mem, &st);
+    uint32_t* L = out_dev(c, "adm_labels", P_out, len, mem, &st);
+    uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+    const int nblk = 512;
+    double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * nblk * 8);
+    double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
+    if (st || !sig || !partial || !coef) return st ? st : SDPSR_OUT_OF_MEMORY;
+
+    const int mode = c->opts.square_mode;
+    const int T = (mode == SDPSR_SQUARE_F64) ? 1 : c->opts.channels;
+    const int64_t ld = round_up(n, 128);
+    void* Xp = nullptr;
+    void* Cp = nullptr;
+    double* Y = nullptr;
+    int vmax = 0;
+    if (mode == SDPSR_SQUARE_I8) {
+        Xp = ctx_buf(c, "adm_xi8", (size_t)T * ld * ld);
+        Cp = ctx_buf(c, "adm_ci32", (size_t)T * ld * ld * 4);
+    } else if (mode == SDPSR_SQUARE_F32) {
+        Xp = ctx_buf(c, "adm_xf32", (size_t)T * ld * ld * 4);
+        Cp = ctx_buf(c, "adm_cf32", (size_t)T * ld * ld * 4);
+        vmax = (int)std::floor(std::sqrt(16777216.0 / (double)n));
+        if (vmax > 127) vmax = 127;
+        if (vmax < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "n too large for the exact fp32 square");
+    } else if (mode == SDPSR_SQUARE_F64) {
+        Xp = ctx_buf(c, "adm_xf64", (size_t)ld * ld * 8);
+        Cp = ctx_buf(c, "adm_cf64", (size_t)ld * ld * 8);
+        Y = (double*)ctx_buf(c, "adm_y", (size_t)len * 8);
+        if (!Y) return SDPSR_OUT_OF_MEMORY;
+    } else {
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "unknown square_mode");
+    }
+    if (!Xp || !Cp) return SDPSR_OUT_OF_MEMORY;
+
+    const double sigdigits = std::floor(-std::log10(atol));  // src/utils.jl:37
+    const double scale = std::pow(10.0, sigdigits);
+
+    // S = Part(CL); S = refine!(S, Part(X0L))   (:145-146)
+    int64_t d = 0;
+    tm.begin(SDPSR_T_REFINE);
+    launch_sig_f64(s, len, nullptr, dCL, sig);
+    st = refine_signatures(c, len, sig, L, &d);
+    if (st) return st;
+    launch_sig_f64(s, len, L, dX0, sig);
+    st = refine_signatures(c, len, sig, L, &d);
+    tm.end();
+    if (st) return st;
+    HIP_TRY(c, hipStreamSynchronize(s));
+    tm.collect();
+
+    const int64_t maximal = (len + n) / 2;  // :148
+    int64_t current = d;
+    int it = 0;
+    int confirm_left = c->opts.confirm_rounds;
+    bool converged = current >= maximal;
+    while (current < maximal) {  // :154
+        if (it >= c->opts.max_iters) break;
+        ++it;
+        // --- random projection (:159-164) ---
+        tm.begin(SDPSR_T_PROJECT);
+        const uint64_t key = next_key(c);
+        launch_proj_coef(s, len, r, dU, L, key, nullptr, partial, nblk, coef);
+        launch_proj_apply(s, len, r, dU, L, key, nullptr, coef, atol, scale, 1, Y, sig);
+        tm.end();
+        tm.begin(SDPSR_T_REFINE);
+        int64_t d1 = 0;
+        st = refine_signatures(c, len, sig, L, &d1);
+        tm.end();
+        if (st) return st;
+        // --- random square (:166-174) ---
+        int64_t d2 = d1;
+        for (;;) {
+            tm.begin(SDPSR_T_SQUARE);
+            const uint64_t key2 = next_key(c);
+            if (mode == SDPSR_SQUARE_I8) {
+                launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp);
+                launch_gemm_tn_i8(s, ld, ld, ld, (const int8_t*)Xp, ld, (const int8_t*)Xp, ld,
+                                  (int32_t*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
+                launch_sig_i32(s, n, ld, T, L, (const int32_t*)Cp, sig);
+            } else if (mode == SDPSR_SQUARE_F32) {
+                launch_gather_f32(s, n, ld, T, vmax, L, key2, (float*)Xp);
+                launch_gemm_tn_f32(s, ld, ld, ld, (const float*)Xp, ld, (const float*)Xp, ld,
+                                   (float*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
+                launch_sig_f32(s, n, ld, T, L, (const float*)Cp, sig);
+            } else {
+                // reference-literal: the projected element is squared when the projection
+                // step did not refine S (X is overwritten in place at :160-163), a fresh
+                // random element otherwise (:166-168)
+                if (d1 != current || confirm_left != c->opts.confirm_rounds)
+                    launch_gather_f64_padded(s, n, ld, L, key2, (double*)Xp);
+                else
+                    launch_pad_copy(s, n, ld, Y, Xp, 8);
+                launch_gemm_tn_f64(s, ld, ld, ld, (const double*)Xp, ld, (const double*)Xp, ld,
+                                   (double*)Cp, ld, 1, 0, 0, 0);
+                launch_sig_f64_rounded(s, n, ld, L, (const double*)Cp, atol, scale, sig);
+            }
+            tm.end();
+            tm.begin(SDPSR_T_REFINE);
+            st = refine_signatures(c, len, sig, L, &d2);
+            tm.end();
+            if (st) return st;
+            tm.collect();
+            if (d2 == current && confirm_left > 0) {  // extra independent draws before stopping
+                --confirm_left;
+                continue;
+            }
+            break;
+        }
+        if (d2 == current) {  // :180-182
+            converged = true;
+            break;
+        }
+        confirm_left = c->opts.confirm_rounds;
+        current = d2;  // :184
+        if (current >= maximal) converged = true;
+    }
+    HIP_TRY(c, hipGetLastError());
+    *dim_out = current;
+    if (iters_out) *iters_out = it;
+    st = out_finish(c, P_out, L, len, mem);
+    if (st) return st;
+    if (phase_ms) {
+        hipEventRecord(ev_total1, s);
+        hipEventSynchronize(ev_total1);
+        tm.collect();
+        float ms = 0;
+        hipEventElapsedTime(&ms, ev_total0, ev_total1);
+        for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = tm.acc[i];
+        phase_ms[SDPSR_T_TOTAL] = ms;
+        hipEventDestroy(ev_total0);
+        hipEventDestroy(ev_total1);
+    }
+    if (!converged) return ctx_fail(c, SDPSR_NOT_CONVERGED, "max_iters reached");
+    return SDPSR_OK;
+}
+
+// Host setup stage for dense problems, src/partitions.jl:117-142.
+int sdpsr_admissible_subspace_dense(sdpsr_ctx* c, int64_t n, int64_t m, const double* C,
+                                    const double* A, const double* b, double atol, uint32_t* P_out,
+                                    int64_t* dim_out, int32_t* iters_out, double* phase_ms,
+                                    int mem_out) {
+    CHECK_CTX(c);
+    if (!C || !A || !b || n < 1 || m < 0 || !(atol > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    // U = orthonormal basis of rowspace(A): modified Gram-Schmidt on the residual rows with
+    // pivoting by residual norm and one re-orthogonalisation pass (stands in for qr(A'), :124).
+    // coeffs[i][j] = <U_j, a_i>, so a_i = sum_j coeffs[i][j] U_j for every pivot row.
+    std::vector<double> U((size_t)len * std::max<int64_t>(m, 1));
+    std::vector<std::vector<double>> res(m, std::vector<double>(len));
+    std::vector<std::vector<double>> coeffs(m, std::vector<double>(m, 0.0));
+    std::vector<int64_t> piv;
+    std::vector<char> used(m, 0);
+    double maxnorm = 0;
+    auto norm2 = [&](const std::vector<double>& w) {
+        double s2 = 0;
+        for (double t : w) s2 += t * t;
+        return std::sqrt(s2);
+    };
+    for (int64_t i = 0; i < m; ++i) {
+        for (int64_t e = 0; e < len; ++e) res[i][e] = A[i + e * m];
+        maxnorm = std::max(maxnorm, norm2(res[i]));
+    }
+    int64_t r = 0;
+    for (int64_t step = 0; step < m; ++step) {
+        int64_t best = -1;
+        double bestn = -1;
+        for (int64_t i = 0; i < m; ++i) {
+            if (used[i]) continue;
+            double nn = norm2(res[i]);
+            if (nn > bestn) {
+                bestn = nn;
+                best = i;
+            }
+        }
+        if (best < 0 || bestn <= 1e-12 * maxnorm) break;
+        std::vector<double>& v = res[best];
+        for (int64_t j = 0; j < r; ++j) {  // re-orthogonalise against the basis so far
+            const double* uj = &U[(size_t)j * len];
+            double dot = 0;
+            for (int64_t e = 0; e < len; ++e) dot += uj[e] * v[e];
+            for (int64_t e = 0; e < len; ++e) v[e] -= dot * uj[e];
+            coeffs[best][j] += dot;
+        }
+        bestn = norm2(v);
+        if (bestn <= 1e-12 * maxnorm) {
+            used[best] = 1;
+            continue;
+        }
+        used[best] = 1;
+        double* ur = &U[(size_t)r * len];
+        for (int64_t e = 0; e < len; ++e) ur[e] = v[e] / bestn;
+        coeffs[best][r] = bestn;
+        for (int64_t i = 0; i < m; ++i) {
+            if (used[i]) continue;
+            double dot = 0;
+            for (int64_t e = 0; e < len; ++e) dot += ur[e] * res[i][e];
+            for (int64_t e = 0; e < len; ++e) res[i][e] -= dot * ur[e];
+            coeffs[i][r] += dot;
+        }
+        piv.push_back(best);
+        ++r;
+    }
+    // min-norm solution x0 = U y with R' y = b(piv): forward substitution (Krylov.craig, :137)
+    std::vector<double> y(r, 0.0);
+    for (int64_t k = 0; k < r; ++k) {
+        double s2 = b[piv[k]];
+        for (int64_t j = 0; j < k; ++j) s2 -= coeffs[piv[k]][j] * y[j];
+        y[k] = s2 / coeffs[piv[k]][k];
+    }
+    std::vector<double> x0(len, 0.0), CLv(len), X0(len);
+    for (int64_t k = 0; k < r; ++k)
+        for (int64_t e = 0; e < len; ++e) x0[e] += U[(size_t)k * len + e] * y[k];
+    auto project = [&](const std::vector<double>& in, std::vector<double>& out) {
+        std::fill(out.begin(), out.end(), 0.0);
+        for (int64_t k = 0; k < r; ++k) {
+            const double* uk = &U[(size_t)k * len];
+            double dot = 0;
+            for (int64_t e = 0; e < len; ++e) dot += uk[e] * in[e];
+            for (int64_t e = 0; e < len; ++e) out[e] += dot * uk[e];
+        }
+    };
+    auto symmetrize = [&](std::vector<double>& w) {  // src/utils.jl:71-81
+        for (int64_t j = 0; j < n; ++j)
+            for (int64_t i = j; i < n; ++i) {
+                double t = (w[i + j * n] + w[j + i * n]) / 2;
+                w[i + j * n] = w[j + i * n] = t;
+            }
+    };
+    const double scale = std::pow(10.0, std::floor(-std::log10(atol)));
+    std::vector<double> tmp(len);
+    // CL (:129-134)
+    std::vector<double> cv(C, C + len);
+    project(cv, tmp);
+    for (int64_t e = 0; e < len; ++e) CLv[e] = sdpsr_clamp_round(cv[e] - tmp[e], atol, scale);
+    symmetrize(CLv);
+    // X0L (:137-142)
+    symmetrize(x0);
+    project(x0, tmp);
+    for (int64_t e = 0; e < len; ++e) X0[e] = sdpsr_clamp_round(tmp[e], atol, scale);
+    // run the loop with host inputs; the output may be wanted on the device
+    if (mem_out == SDPSR_MEM_HOST)
+        return sdpsr_admissible_subspace(c, n, CLv.data(), X0.data(), U.data(), r, atol, P_out, dim_out,
+                                         iters_out, phase_ms, SDPSR_MEM_HOST);
+    std::vector<uint32_t> hostP(len);
+    int st = sdpsr_admissible_subspace(c, n, CLv.data(), X0.data(), U.data(), r, atol, hostP.data(),
+                                       dim_out, iters_out, phase_ms, SDPSR_MEM_HOST);
+    if (st) return st;
+    HIP_TRY(c, hipMemcpy(P_out, hostP.data(), len * 4, hipMemcpyHostToDevice));
+    return SDPSR_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// blockDiagonalize
+// ---------------------------------------------------------------------------
+namespace {
+
+// DataStructures.jl IntDisjointSets (union by rank, path compression) as used at
+// src/eigen_decomposition.jl:208-217
+struct DisjointSets {
+    std::vector<int> parent, rank;
+    explicit DisjointSets(int n) : parent(n), rank(n, 0) { std::iota(parent.begin(), parent.end(), 0); }
+    int find(int x) {
+        int r = x;
+        while (parent[r] != r) r = parent[r];
+        while (parent[x] != r) {
+            int nx = parent[x];
+            parent[x] = r;
+            x = nx;
+        }
+        return r;
+    }
+    void unite(int x, int y) {
+        x = find(x);
+        y = find(y);
+        if (x == y) return;
+        if (rank[x] < rank[y]) std::swap(x, y);
+        else if (rank[x] == rank[y]) ++rank[x];
+        parent[y] = x;
+    }
+};
+
+// otsu_threshold + log_histogram, src/eigen_decomposition.jl:83-139
+double otsu_threshold(const std::vector<double>& X, double atol) {
+    const int nb = std::max((int)std::ceil(-std::log10(2.220446049250313e-16)), 4);  // 16
+    double mn = INFINITY, mx = 0;
+    for (double x : X) {
+        double a = std::fabs(x);
+        mn = std::min(mn, a);
+        mx = std::max(mx, a);
+    }
+    if (mn < atol) mn = atol;
+    std::vector<double> edges(nb + 1);
+    const double l0 = std::log(mn), l1 = std::log(mx);
+    for (int i = 0; i <= nb; ++i) {
+        // Julia range(a, b, length=n): a + i*(b-a)/(n-1), endpoints exact
+        double t = (i == nb) ? l1 : l0 + (l1 - l0) * (double)i / (double)nb;
+        edges[i] = std::exp(t);
+    }
+    std::vector<double> counts(nb, 0.0);
+    for (double x : X) {
+        int f = nb + 1;  // something(findfirst(b -> b > x, edges), nb + 1), 1-based
+        for (int i = 0; i <= nb; ++i)
+            if (edges[i] > x) {
+                f = i + 1;
+                break;
+            }
+        int bin = std::min(std::max(f - 1, 1), nb);
+        counts[bin - 1] += 1;
+    }
+    double total = 0;
+    for (double v : counts) total += v;
+    std::vector<double> w(nb), mu(nb);
+    double cw = 0, cm = 0;
+    for (int i = 0; i < nb; ++i) {
+        double p = counts[i] / total;
+        cw += p;
+        cm += std::log(edges[i]) * p;
+        w[i] = cw;
+        mu[i] = cm;
+    }
+    const double muT = mu[nb - 1];
+    int best = 0;
+    double bestv = -INFINITY;
+    bool have_nan = false;
+    for (int i = 0; i < nb - 1; ++i) {
+        double num = muT * w[i] - mu[i];
+        double s2 = num * num / (w[i] * (1 - w[i]));
+        if (std::isnan(s2)) {  // Julia argmax returns the first NaN
+            if (!have_nan) {
+                best = i;
+                have_nan = true;
+            }
+        } else if (!have_nan && s2 > bestv) {
+            bestv = s2;
+            best = i;
+        }
+    }
+    return edges[best + 1];
+}
+
+struct EigInfo {
+    std::vector<double> vals;
+    std::vector<int> ptrs;  // 0-based boundaries, size neig+1
+    std::vector<int> kpart; // root of every eigenspace
+};
+
+// eigen_decomposition (src/eigen_decomposition.jl:236-273) on the device.  On success the
+// padded buffers "bd_q" (eigenvectors, ld x ld) stay valid in ctx.
+int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, double atol, EigInfo& info,
+                               PhaseTimer& tm) {
+    hipStream_t s = c->stream;
+    const int64_t ld = round_up(n, 128);
+    uint32_t* flag = (uint32_t*)ctx_buf(c, "bd_flag", 64);
+    double* Q = (double*)ctx_buf(c, "bd_q", (size_t)ld * ld * 8);
+    double* Ap = (double*)ctx_buf(c, "bd_a", (size_t)ld * ld * 8);
+    double* Tp = (double*)ctx_buf(c, "bd_t", (size_t)ld * ld * 8);
+    double* w = (double*)ctx_buf(c, "bd_w", (size_t)n * 8);
+    if (!flag || !Q || !Ap || !Tp || !w) return SDPSR_OUT_OF_MEMORY;
+    // a non-symmetric partition has a non-symmetric generic element: eigen() leaves the reals
+    // (src/eigen_decomposition.jl:247-253)
+    launch_check_symmetric(s, n, L, flag);
+    uint32_t* hflag = (uint32_t*)c->pinned;
+    HIP_TRY(c, hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (hflag[0]) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
+                                  "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
+    // Step 1-2: generic element and its eigendecomposition (:242-254)
+    tm.begin(SDPSR_T_EIGEN);
+    launch_gather_f64_padded(s, n, ld, L, next_key(c), Q);
+    int st = syev_device(c, n, Q, ld, w);
+    tm.end();
+    if (st) return st;
+    info.vals.resize(n);
+    HIP_TRY(c, hipMemcpyAsync(info.vals.data(), w, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    tm.collect();
+    // EigenDecomposition ctor (:19-40): new eigenspace where |dv| > atol
+    info.ptrs.assign(1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (i == n - 1) {
+            info.ptrs.push_back((int)n);
+            break;
+        }
+        if (!(std::fabs(info.vals[i + 1] - info.vals[i]) <= atol)) info.ptrs.push_back((int)i + 1);
+    }
+    const int neig = (int)info.ptrs.size() - 1;
+    std::vector<int32_t> space_of(n);
+    for (int b = 0; b < neig; ++b)
+        for (int i = info.ptrs[b]; i < info.ptrs[b + 1]; ++i) space_of[i] = b;
+    // Step 3: second generic element, Q'AQ, block norms (:259-262, :201-205)
+    tm.begin(SDPSR_T_ISO);
+    int32_t* dspace = (int32_t*)ctx_buf(c, "bd_space", (size_t)n * 4);
+    unsigned long long* dnorms = (unsigned long long*)ctx_buf(c, "bd_norms", (size_t)neig * neig * 8);
+    if (!dspace || !dnorms) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(dspace, space_of.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(dnorms, 0, (size_t)neig * neig * 8, s));
+    launch_gather_f64_padded(s, n, ld, L, next_key(c), Ap);
+    launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);   // T = A Q (A symmetric)
+    launch_gemm_tn_f64(s, ld, ld, ld, Q, ld, Tp, ld, Ap, ld, 1, 0, 0, 0);   // M = Q' T  (into Ap)
+    launch_block_norms(s, n, ld, Ap, dspace, neig, dnorms);
+    std::vector<double> norms((size_t)neig * neig);
+    HIP_TRY(c, hipMemcpyAsync(norms.data(), dnorms, (size_t)neig * neig * 8, hipMemcpyDeviceToHost, s));
+    tm.end();
+    HIP_TRY(c, hipStreamSynchronize(s));
+    tm.collect();
+    // blocks between eigenspaces of different dimension count as zero (:185-186); the kernel
+    // computes the (bi, bj) max with bi = row space, symmetrise like end_norm[i,j] = end_norm[j,i]
+    auto dimof = [&](int b) { return info.ptrs[b + 1] - info.ptrs[b]; };
+    for (int i = 0; i < neig; ++i)
+        for (int j = i; j < neig; ++j) {
+            double v = (dimof(i) != dimof(j)) ? 0.0 : norms[(size_t)i * neig + j];  // block rows Ei, cols Ej
+            norms[(size_t)i * neig + j] = norms[(size_t)j * neig + i] = v;
+        }
+    const double thr = otsu_threshold(norms, atol);
+    DisjointSets K(neig);
+    for (int i = 0; i < neig; ++i)
+        for (int j = i + 1; j < neig; ++j)
+            if (norms[(size_t)i * neig + j] >= thr) K.unite(i, j);
+    // __isconsistent (:163-167)
+    info.kpart.resize(neig);
+    for (int i = 0; i < neig; ++i) info.kpart[i] = K.find(i);
+    std::vector<int> first(neig, -1);
+    for (int i = 0; i < neig; ++i)
+        if (first[info.kpart[i]] < 0) first[info.kpart[i]] = i;
+    for (int i = 0; i < neig; ++i)
+        if (first[info.kpart[i]] != info.kpart[i])
+            return ctx_fail(c, SDPSR_NUMERICAL_INCONSISTENCY,
+                            "eigen_decomposition: the K-partition seems inconsistent with eigenspaces. Decrease atol, or simply try again.");
+    return SDPSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdpsr_eigen_decomposition(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double atol,
+                              int32_t* neig, int32_t* nclasses, int mem) {
+    CHECK_CTX(c);
+    (void)d;
+    if (!P || n < 1 || !(atol > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = check_len(c, n * n);
+    if (st) return st;
+    const uint32_t* L = in_dev(c, "bd_labels", P, (size_t)n * n, mem, &st);
+    if (st) return st;
+    c->bd_valid = false;
+    EigInfo info;
+    PhaseTimer tm(c, false);
+    st = eigen_decomposition_device(c, n, L, atol, info, tm);
+    if (st) return st;
+    if (neig) *neig = (int32_t)info.ptrs.size() - 1;
+    if (nclasses) {
+        std::vector<int> roots(info.kpart);
+        std::sort(roots.begin(), roots.end());
+        *nclasses = (int32_t)(std::unique(roots.begin(), roots.end()) - roots.begin());
+    }
+    return SDPSR_OK;
+}
+
+int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon,
+                            int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* phase_ms,
+                            int mem) {
+    CHECK_CTX(c);
+    if (!P || n < 1 || d < 0 || !(epsilon > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    c->bd_valid = false;
+    PhaseTimer tm(c, phase_ms != nullptr);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (phase_ms) {
+        hipEventCreate(&ev0);
+        hipEventCreate(&ev1);
+        hipEventRecord(ev0, s);
+    }
+    // keep a device copy of the labels for phase 2
+    uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
+    if (!L) return SDPSR_OUT_OF_MEMORY;
+    if (mem == SDPSR_MEM_DEVICE) {
+        if (P != L) HIP_TRY(c, hipMemcpyAsync(L, P, len * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(L, P, len * 4, hipMemcpyHostToDevice, s));
+    }
+    const double atol = epsilon;  // diagonalize(T, P; atol=epsilon), src/compat.jl:53
+    EigInfo info;
+    st = eigen_decomposition_device(c, n, L, atol, info, tm);
+    if (st) return st;
+
+    // irreducible_decomposition (src/eigen_decomposition.jl:295-348)
+    tm.begin(SDPSR_T_IRRED);
+    const int64_t ld = round_up(n, 128);
+    const int neig = (int)info.ptrs.size() - 1;
+    std::vector<int> roots;  // unique(Kpartition) in first-occurrence order (:303)
+    {
+        std::vector<char> seen(neig, 0);
+        for (int i = 0; i < neig; ++i)
+            if (!seen[info.kpart[i]]) {
+                seen[info.kpart[i]] = 1;
+                roots.push_back(info.kpart[i]);
+            }
+    }
+    std::vector<std::vector<int>> members(roots.size());
+    std::vector<int> root_pos(neig, -1);
+    for (size_t p = 0; p < roots.size(); ++p) root_pos[roots[p]] = (int)p;
+    for (int i = 0; i < neig; ++i) members[root_pos[info.kpart[i]]].push_back(i);
+    std::vector<int32_t> sizes(roots.size());
+    int64_t S1 = 0, S = 0;
+    for (size_t p = 0; p < roots.size(); ++p) {
+        sizes[p] = (int32_t)members[p].size();
+        S1 += sizes[p];
+        S += (int64_t)sizes[p] * sizes[p];
+    }
+    double* Q = (double*)ctx_buf(c, "bd_q", (size_t)ld * ld * 8);
+    double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
+    if (!Q || !Qhat) return SDPSR_OUT_OF_MEMORY;
+    // first eigenvector of every eigenspace that sits in a merged class -> F; B = A3 * F
+    std::vector<int> fcol(neig, -1);
+    int nf = 0;
+    for (size_t p = 0; p < roots.size(); ++p)
+        if (members[p].size() > 1)
+            for (int j : members[p]) fcol[j] = nf++;
+    double* Bf = nullptr;
+    if (nf > 0) {
+        const int64_t nfp = round_up(nf, 128);
+        double* A3 = (double*)ctx_buf(c, "bd_a", (size_t)ld * ld * 8);
+        double* F = (double*)ctx_buf(c, "bd_f", (size_t)ld * nfp * 8);
+        Bf = (double*)ctx_buf(c, "bd_bf", (size_t)ld * nfp * 8);
+        if (!A3 || !F || !Bf) return SDPSR_OUT_OF_MEMORY;
+        launch_gather_f64_padded(s, n, ld, L, next_key(c), A3);  // generic element #3 (:306)
+        HIP_TRY(c, hipMemsetAsync(F, 0, (size_t)ld * nfp * 8, s));
+        for (int j = 0; j < neig; ++j)
+            if (fcol[j] >= 0)
+                HIP_TRY(c, hipMemcpyAsync(F + (size_t)fcol[j] * ld, Q + (size_t)info.ptrs[j] * ld, n * 8,
+                                          hipMemcpyDeviceToDevice, s));
+        launch_gemm_tn_f64(s, ld, nfp, ld, A3, ld, F, ld, Bf, ld, 1, 0, 0, 0);  // B = A3' F = A3 F
+    }
+    double* wv = (double*)ctx_buf(c, "bd_wv", (size_t)n * 8);
+    double* cv = (double*)ctx_buf(c, "bd_cv", (size_t)n * 8);
+    double* inv = (double*)ctx_buf(c, "bd_inv", 64);
+    if (!wv || !cv || !inv) return SDPSR_OUT_OF_MEMORY;
+    int64_t col = 0;
+    for (size_t p = 0; p < roots.size(); ++p) {
+        const int i = roots[p];
+        const int64_t mi = info.ptrs[i + 1] - info.ptrs[i];
+        // first member: P1 = I -> first eigenvector of Ei (:311-313, :326)
+        launch_copy_col(s, n, Q + (size_t)info.ptrs[i] * ld, Qhat + (size_t)col * n);
+        ++col;
+        for (size_t q = 1; q < members[p].size(); ++q) {
+            const int j = members[p][q];
+            const int64_t mj = info.ptrs[j + 1] - info.ptrs[j];
+            // first column of P_blk = block(A,Ei,Ej)' is Qj' (A q_i1)             (:333)
+            launch_gemv_t(s, n, ld, Q, info.ptrs[j], mj, Bf + (size_t)fcol[i] * ld, wv);
+            // norm(P_blk[1,:]) = || Qi' (A q_j1) ||                              (:335)
+            launch_gemv_t(s, n, ld, Q, info.ptrs[i], mi, Bf + (size_t)fcol[j] * ld, cv);
+            launch_inv_norm(s, mi, cv, inv);
+            // column of P_hat = Qj * first column of the normalised block       (:338-344)
+            launch_gemv_n_scaled(s, n, ld, Q, info.ptrs[j], mj, wv, inv, Qhat + (size_t)col * n);
+            ++col;
+        }
+    }
+    launch_clamptol(s, n * S1, Qhat, atol);  // src/diagonalize.jl:39
+    tm.end();
+    HIP_TRY(c, hipGetLastError());
+
+    // check_block_sizes (src/diagonalize.jl:1-11)
+    int64_t final_dim = 0;
+    for (int32_t sz : sizes) final_dim += (int64_t)sz * (sz + 1) / 2;
+    c->bd_n = n;
+    c->bd_d = d;
+    c->bd_sizes = sizes;
+    c->bd_sum_s = S1;
+    c->bd_sum_sq = S;
+    if (nblocks) *nblocks = (int32_t)sizes.size();
+    if (sum_sq) *sum_sq = S;
+    if (sum_s) *sum_s = S1;
+    if (phase_ms) {
+        hipEventRecord(ev1, s);
+        hipEventSynchronize(ev1);
+        tm.collect();
+        float ms = 0;
+        hipEventElapsedTime(&ms, ev0, ev1);
+        for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = tm.acc[i];
+        phase_ms[SDPSR_T_TOTAL] = ms;
+        hipEventDestroy(ev0);
+        hipEventDestroy(ev1);
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    if (final_dim != d) {
+        std::string szs;
+        for (int32_t sz : sizes) szs += std::to_string(sz) + " ";
+        return ctx_fail(c, SDPSR_DIMENSION_MISMATCH,
+                        "final_dim=" + std::to_string(final_dim) + " block_sizes=[" + szs + "] expected dim(P)=" +
+                            std::to_string(d) + " (rounding error: try another epsilon or try again; or the algebra is not block-diagonalizable over the reals)");
+    }
+    c->bd_valid = true;
+    return SDPSR_OK;
+}
+
+int sdpsr_block_sizes(sdpsr_ctx* c, int32_t* blk_sizes) {
+    if (!c || !blk_sizes) return SDPSR_BAD_ARGUMENT;
+    if (c->bd_sizes.empty()) return ctx_fail(c, SDPSR_BAD_STATE, "no block diagonalisation available");
+    memcpy(blk_sizes, c->bd_sizes.data(), c->bd_sizes.size() * sizeof(int32_t));
+    return SDPSR_OK;
+}
+
+int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_ms, int mem) {
+    CHECK_CTX(c);
+    if (!c->bd_valid) return ctx_fail(c, SDPSR_BAD_STATE, "sdpsr_block_diagonalize has not succeeded on this ctx");
+    if (!blks) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    hipStream_t s = c->stream;
+    const int64_t n = c->bd_n, d = c->bd_d, S1 = c->bd_sum_s, S = c->bd_sum_sq, len = n * n;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (phase_ms) {
+        hipEventCreate(&ev0);
+        hipEventCreate(&ev1);
+        hipEventRecord(ev0, s);
+    }
+    int st = SDPSR_OK;
+    uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
+    double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
+    double* Qrm = (double*)ctx_buf(c, "bd_qrm", (size_t)n * S1 * 8);
+    double* out = out_dev(c, "bd_blks", blks, (size_t)d * S, mem, &st);
+    if (st || !L || !Qhat || !Qrm) return st ? st : SDPSR_OUT_OF_MEMORY;
+    launch_transpose_to_rowmajor(s, n, S1, Qhat, Qrm);
+    // _constraints(P): entries grouped by class (src/diagonalize.jl:42-50)
+    uint32_t* ent = nullptr;
+    int64_t* class_ptr = nullptr;  // host, size d+2: class_ptr[l]..class_ptr[l+1] = label l
+    st = sort_entries_by_label(c, len, d, L, &ent, &class_ptr);
+    if (st) return st;
+    // chunks + output descriptors
+    const int64_t CH = 4096;
+    std::vector<int64_t> chunk_ptr(d + 1, 0), cb, ce;
+    for (int64_t i = 1; i <= d; ++i) {
+        chunk_ptr[i - 1] = (int64_t)cb.size();
+        for (int64_t p = class_ptr[i]; p < class_ptr[i + 1]; p += CH) {
+            cb.push_back(p);
+            ce.push_back(std::min(p + CH, class_ptr[i + 1]));
+        }
+    }
+    chunk_ptr[d] = (int64_t)cb.size();
+    free(class_ptr);
+    std::vector<int32_t> dA(S), dB(S);
+    {
+        int64_t o = 0, colbase = 0;
+        for (int32_t sz : c->bd_sizes) {
+            for (int b = 0; b < sz; ++b)
+                for (int a = 0; a < sz; ++a) {
+                    dA[o] = (int32_t)(colbase + a);
+                    dB[o] = (int32_t)(colbase + b);
+                    ++o;
+                }
+            colbase += sz;
+        }
+    }
+    const int64_t nch = (int64_t)cb.size();
+    int64_t* d_chunk_ptr = (int64_t*)ctx_buf(c, "bi_chunk_ptr", (d + 1) * 8);
+    int64_t* d_cb = (int64_t*)ctx_buf(c, "bi_cb", std::max<int64_t>(nch, 1) * 8);
+    int64_t* d_ce = (int64_t*)ctx_buf(c, "bi_ce", std::max<int64_t>(nch, 1) * 8);
+    int32_t* d_dA = (int32_t*)ctx_buf(c, "bi_da", std::max<int64_t>(S, 1) * 4);
+    int32_t* d_dB = (int32_t*)ctx_buf(c, "bi_db", std::max<int64_t>(S, 1) * 4);
+    double* partial = (double*)ctx_buf(c, "bi_partial", (size_t)std::max<int64_t>(nch * S, 1) * 8);
+    if (!d_chunk_ptr || !d_cb || !d_ce || !d_dA || !d_dB || !partial) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(d_chunk_ptr, chunk_ptr.data(), (d + 1) * 8, hipMemcpyHostToDevice, s));
+    if (nch) {
+        HIP_TRY(c, hipMemcpyAsync(d_cb, cb.data(), nch * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d_ce, ce.data(), nch * 8, hipMemcpyHostToDevice, s));
+    }
+    if (S) {
+        HIP_TRY(c, hipMemcpyAsync(d_dA, dA.data(), S * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d_dB, dB.data(), S * 4, hipMemcpyHostToDevice, s));
+    }
+    const double atol = 1e-12 * (double)n;  // basis_image default atol (src/diagonalize.jl:67)
+    launch_basis_image(s, n, d, S1, S, Qrm, ent, nullptr, d_dA, d_dB, d_chunk_ptr, nch, nullptr, d_cb, d_ce,
+                       partial, out, atol);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));  // host vectors above must outlive the copies
+    st = out_finish(c, blks, out, (size_t)d * S, mem);
+    if (st) return st;
+    if (Q_hat) {
+        if (mem == SDPSR_MEM_DEVICE)
+            HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, hipMemcpyDeviceToDevice, s));
+        else
+            HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    if (phase_ms) {
+        hipEventRecord(ev1, s);
+        hipEventSynchronize(ev1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, ev0, ev1);
+        for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = 0;
+        phase_ms[SDPSR_T_IMAGE] = ms;
+        phase_ms[SDPSR_T_TOTAL] = ms;
+        hipEventDestroy(ev0);
+        hipEventDestroy(ev1);
+    }
+    return SDPSR_OK;
+}
+
+int sdpsr_syev_f64(sdpsr_ctx* c, int64_t n, const double* A, double* values, double* vectors, int mem) {
+    CHECK_CTX(c);
+    if (!A || !values || !vectors || n < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = SDPSR_OK;
+    const double* dA = in_dev(c, "ev_in", A, (size_t)n * n, mem, &st);
+    double* dV = out_dev(c, "ev_vec", vectors, (size_t)n * n, mem, &st);
+    double* dW = out_dev(c, "ev_val", values, (size_t)n, mem, &st);
+    if (st) return st;
+    HIP_TRY(c, hipMemcpyAsync(dV, dA, (size_t)n * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    st = syev_device(c, n, dV, n, dW);
+    if (st) return st;
+    st = out_finish(c, vectors, dV, (size_t)n * n, mem);
+    if (st) return st;
+    return out_finish(c, values, dW, (size_t)n, mem);
+}
+
+}  // extern "C"

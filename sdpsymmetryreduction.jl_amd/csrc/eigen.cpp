@@ -1,0 +1,75 @@
+// Symmetric eigendecomposition of the generic algebra element, eigen(A) at
+// src/eigen_decomposition.jl:246 (LAPACK dsyevr in the reference: all eigenpairs, ascending).
+//
+// Round-1 driver: rocSOLVER in three explicit phases so that each can be timed and the
+// tridiagonalisation can be replaced by the hand-written HIP panel kernel without touching
+// the callers:   sytrd (A = Q T Q')  ->  stedc (T = Z D Z')  ->  ormtr (V = Q Z).
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include "sdpsr_internal.h"
+
+namespace sdpsr {
+
+static int ensure_handle(sdpsr_ctx* c) {
+    if (!c->rocblas) {
+        rocblas_handle h = nullptr;
+        if (rocblas_create_handle(&h) != rocblas_status_success)
+            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocblas_create_handle failed");
+        c->rocblas = h;
+    }
+    if (rocblas_set_stream((rocblas_handle)c->rocblas, c->stream) != rocblas_status_success)
+        return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocblas_set_stream failed");
+    return SDPSR_OK;
+}
+
+void destroy_handle(sdpsr_ctx* c) {
+    if (c->rocblas) rocblas_destroy_handle((rocblas_handle)c->rocblas);
+    c->rocblas = nullptr;
+}
+
+// A: n x n column-major with leading dimension lda, lower triangle referenced; on exit the
+// columns of A are the orthonormal eigenvectors, w ascending.
+int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w) {
+    int st = ensure_handle(c);
+    if (st) return st;
+    rocblas_handle h = (rocblas_handle)c->rocblas;
+    double* E = (double*)ctx_buf(c, "eig_E", (size_t)n * sizeof(double));
+    double* tau = (double*)ctx_buf(c, "eig_tau", (size_t)n * sizeof(double));
+    rocblas_int* info = (rocblas_int*)ctx_buf(c, "eig_info", 64);
+    if (!E || !tau || !info) return SDPSR_OUT_OF_MEMORY;
+    rocblas_status rs;
+    if (c->opts.eig_driver == 1) {
+        rs = rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, (rocblas_int)n, A,
+                              (rocblas_int)lda, w, E, info);
+        if (rs != rocblas_status_success)
+            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dsyevd status " + std::to_string(rs));
+    } else {
+        double* Z = (double*)ctx_buf(c, "eig_Z", (size_t)n * n * sizeof(double));
+        if (!Z) return SDPSR_OUT_OF_MEMORY;
+        rs = rocsolver_dsytrd(h, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)lda, w, E, tau);
+        if (rs != rocblas_status_success)
+            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dsytrd status " + std::to_string(rs));
+        rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)n,
+                              info);
+        if (rs != rocblas_status_success)
+            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dstedc status " + std::to_string(rs));
+        rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                              (rocblas_int)n, (rocblas_int)n, A, (rocblas_int)lda, tau, Z,
+                              (rocblas_int)n);
+        if (rs != rocblas_status_success)
+            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dormtr status " + std::to_string(rs));
+        if (hipMemcpy2DAsync(A, lda * sizeof(double), Z, n * sizeof(double), n * sizeof(double), n,
+                             hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            return ctx_fail(c, SDPSR_HIP_ERROR, "copy of eigenvectors failed");
+    }
+    rocblas_int hinfo = 0;
+    if (hipMemcpyAsync(&hinfo, info, sizeof(hinfo), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return ctx_fail(c, SDPSR_HIP_ERROR, "eigensolver info read-back failed");
+    if (hinfo != 0)
+        return ctx_fail(c, SDPSR_SOLVER_ERROR, "eigensolver did not converge, info=" + std::to_string(hinfo));
+    return SDPSR_OK;
+}
+
+}  // namespace sdpsr

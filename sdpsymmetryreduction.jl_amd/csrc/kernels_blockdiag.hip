@@ -1,0 +1,288 @@
+// Kernels of the block-diagonalisation stage (src/eigen_decomposition.jl:177-219,295-348,
+// src/diagonalize.jl:42-89): eigenspace block norms, the small products of
+// irreducible_decomposition, and basis_image as a segmented outer-product reduction.
+#include "sdpsr_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace sdpsr {
+
+static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// block_norms(Q'AQ, eigdec, Inf), src/eigen_decomposition.jl:177-193: max |M[i,j]| per
+// (eigenspace, eigenspace) block.  |x| >= 0 so the bit pattern orders like the value and
+// atomicMax on uint64 is exact.  A wave first reduces lanes that fall in the same block.
+// ---------------------------------------------------------------------------
+__global__ void block_norms_kernel(int64_t n, int64_t ld, const double* __restrict__ M,
+                                   const int32_t* __restrict__ space_of, int neig,
+                                   unsigned long long* __restrict__ norms) {
+    const int64_t len = n * n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x; e0 < len; e0 += stride) {
+        const int64_t e = e0 + threadIdx.x;
+        bool valid = e < len;
+        int64_t j = valid ? e / n : 0, i = valid ? e - j * n : 0;
+        int bi = space_of[i], bj = space_of[j];
+        unsigned long long v = valid ? (unsigned long long)__double_as_longlong(fabs(M[i + j * ld])) : 0ull;
+        int key = bi * neig + bj;
+        // lanes of a wave are consecutive i in one column (mostly one block): reduce runs
+        int prev_key = __shfl_up(key, 1, 64);
+        bool head = ((threadIdx.x & 63) == 0) || prev_key != key;
+        // segmented max via log-step scan over equal keys
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned long long ov = __shfl_down(v, o, 64);
+            int ok = __shfl_down(key, o, 64);
+            if ((int)(threadIdx.x & 63) + o < 64 && ok == key && ov > v) v = ov;
+        }
+        if (valid && head && v) atomicMax(&norms[key], v);
+    }
+}
+void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
+                        const int32_t* space_of, int neig, unsigned long long* norms) {
+    block_norms_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, M, space_of, neig, norms);
+}
+
+// ---------------------------------------------------------------------------
+// small dense helpers for irreducible_decomposition (src/eigen_decomposition.jl:329-344)
+// ---------------------------------------------------------------------------
+// out[j] = sum_i Q[i, col0 + j] * a[i]: one wave per column j
+__global__ void gemv_t_kernel(int64_t n, int64_t ld, const double* __restrict__ Q, int64_t col0,
+                              int64_t m, const double* __restrict__ a, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t j = wave; j < m; j += nw) {
+        const double* q = Q + (col0 + j) * ld;
+        double acc = 0;
+        for (int64_t i = lane; i < n; i += 64) acc = fma(q[i], a[i], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) out[j] = acc;
+    }
+}
+void launch_gemv_t(hipStream_t s, int64_t n, int64_t ld, const double* Q, int64_t col0,
+                   int64_t m, const double* a, double* out) {
+    gemv_t_kernel<<<grid_for(m * 64, 256), 256, 0, s>>>(n, ld, Q, col0, m, a, out);
+}
+
+// dst[i] = inv_norm[0] * sum_j Q[i, col0 + j] * w[j]
+__global__ void gemv_n_scaled_kernel(int64_t n, int64_t ld, const double* __restrict__ Q,
+                                     int64_t col0, int64_t m, const double* __restrict__ w,
+                                     const double* __restrict__ inv_norm,
+                                     double* __restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double sc = inv_norm[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double acc = 0;
+        for (int64_t j = 0; j < m; ++j) acc = fma(Q[i + (col0 + j) * ld], w[j], acc);
+        dst[i] = acc * sc;
+    }
+}
+void launch_gemv_n_scaled(hipStream_t s, int64_t n, int64_t ld, const double* Q, int64_t col0,
+                          int64_t m, const double* w, const double* inv_norm, double* dst) {
+    gemv_n_scaled_kernel<<<grid_for(n, 256), 256, 0, s>>>(n, ld, Q, col0, m, w, inv_norm, dst);
+}
+
+__global__ void copy_col_kernel(int64_t n, const double* __restrict__ src,
+                                double* __restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = src[i];
+}
+void launch_copy_col(hipStream_t s, int64_t n, const double* src, double* dst) {
+    copy_col_kernel<<<grid_for(n, 256), 256, 0, s>>>(n, src, dst);
+}
+
+__global__ void clamptol_kernel(int64_t len, double* __restrict__ a, double atol) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        double v = a[e];
+        a[e] = (fabs(v) < atol) ? 0.0 : v;
+    }
+}
+void launch_clamptol(hipStream_t s, int64_t len, double* a, double atol) {
+    clamptol_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, a, atol);
+}
+
+// out[0] = 1 / ||v||_2   (single block)
+__global__ void inv_norm_kernel(int64_t m, const double* __restrict__ v, double* out) {
+    __shared__ double sh[4];
+    double acc = 0;
+    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) acc = fma(v[i], v[i], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = 1.0 / sqrt(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+void launch_inv_norm(hipStream_t s, int64_t m, const double* v, double* out) {
+    inv_norm_kernel<<<1, 256, 0, s>>>(m, v, out);
+}
+
+// ---------------------------------------------------------------------------
+// basis_image, src/diagonalize.jl:64-89:
+//   blks[i][k][a,b] = sum over entries (r,c) of class i of Q_k[r,a] * Q_k[c,b]
+// Entries are grouped by class (stable radix sort by label), every class is cut into
+// chunks of BI_CHUNK entries; a workgroup = (chunk, tile of BI_OT outputs): threads walk
+// the entries, keep BI_OT accumulators in registers and reduce them across the workgroup.
+// Chunk partials are summed in chunk order by a second kernel (bitwise reproducible).
+// ---------------------------------------------------------------------------
+constexpr int BI_THREADS = 256;
+constexpr int BI_CHUNK = 4096;
+constexpr int BI_OT = 16;
+
+__global__ void __launch_bounds__(BI_THREADS)
+basis_image_kernel(int64_t n, int64_t S1, int64_t S, const double* __restrict__ Qrm,
+                   const uint32_t* __restrict__ ent, const int64_t* __restrict__ chunk_begin,
+                   const int64_t* __restrict__ chunk_end, const int32_t* __restrict__ descA,
+                   const int32_t* __restrict__ descB, double* __restrict__ partial) {
+    __shared__ int sA[BI_OT], sB[BI_OT];
+    __shared__ double red[BI_THREADS / 64][BI_OT];
+    const int64_t chunk = blockIdx.x;
+    const int64_t o0 = (int64_t)blockIdx.y * BI_OT;
+    if (threadIdx.x < BI_OT) {
+        int64_t o = o0 + threadIdx.x;
+        sA[threadIdx.x] = (o < S) ? descA[o] : 0;
+        sB[threadIdx.x] = (o < S) ? descB[o] : 0;
+    }
+    __syncthreads();
+    double acc[BI_OT];
+#pragma unroll
+    for (int o = 0; o < BI_OT; ++o) acc[o] = 0.0;
+    const int64_t b = chunk_begin[chunk], e_end = chunk_end[chunk];
+    for (int64_t p = b + threadIdx.x; p < e_end; p += BI_THREADS) {
+        const uint32_t lin = ent[p];
+        const int64_t c = lin / n, r = lin - c * n;
+        const double* qr = Qrm + r * S1;
+        const double* qc = Qrm + c * S1;
+#pragma unroll
+        for (int o = 0; o < BI_OT; ++o) acc[o] = fma(qr[sA[o]], qc[sB[o]], acc[o]);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < BI_OT; ++o) {
+        double v = acc[o];
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_down(v, sft, 64);
+        if (lane == 0) red[w][o] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < BI_OT) {
+        int64_t o = o0 + threadIdx.x;
+        if (o < S) {
+            double v = 0;
+            for (int k = 0; k < BI_THREADS / 64; ++k) v += red[k][threadIdx.x];
+            partial[chunk * S + o] = v;
+        }
+    }
+}
+
+__global__ void basis_image_reduce_kernel(int64_t d, int64_t S, const int64_t* __restrict__ chunk_ptr,
+                                          const double* __restrict__ partial, double atol,
+                                          double* __restrict__ out) {
+    const int64_t total = d * S;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t cls = t / S, o = t - cls * S;
+        double v = 0;
+        for (int64_t ch = chunk_ptr[cls]; ch < chunk_ptr[cls + 1]; ++ch) v += partial[ch * S + o];
+        out[t] = (fabs(v) < atol) ? 0.0 : v;
+    }
+}
+
+void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S,
+                        const double* Qrm, const uint32_t* ent, const int64_t* class_ptr,
+                        const int32_t* descA, const int32_t* descB, const int64_t* chunk_ptr,
+                        int64_t nchunks_total, const int32_t* chunk_class,
+                        const int64_t* chunk_begin, const int64_t* chunk_end, double* partial,
+                        double* out, double atol) {
+    (void)class_ptr;
+    (void)chunk_class;
+    if (nchunks_total > 0 && S > 0) {
+        dim3 g((unsigned)nchunks_total, (unsigned)((S + BI_OT - 1) / BI_OT));
+        basis_image_kernel<<<g, BI_THREADS, 0, s>>>(n, S1, S, Qrm, ent, chunk_begin, chunk_end,
+                                                    descA, descB, partial);
+    }
+    basis_image_reduce_kernel<<<grid_for(d * S, 256), 256, 0, s>>>(d, S, chunk_ptr, partial, atol,
+                                                                   out);
+}
+
+// Qrm[r * S1 + k] = Qcm[r + k * n]
+__global__ void transpose_to_rowmajor_kernel(int64_t n, int64_t S1, const double* __restrict__ Qcm,
+                                             double* __restrict__ Qrm) {
+    const int64_t total = n * S1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t r = t / S1, k = t - r * S1;
+        Qrm[t] = Qcm[r + k * n];
+    }
+}
+void launch_transpose_to_rowmajor(hipStream_t s, int64_t n, int64_t S1, const double* Qcm,
+                                  double* Qrm) {
+    transpose_to_rowmajor_kernel<<<grid_for(n * S1, 256), 256, 0, s>>>(n, S1, Qcm, Qrm);
+}
+
+// ---------------------------------------------------------------------------
+// entries grouped by class: _constraints(P), src/diagonalize.jl:42-50
+// ---------------------------------------------------------------------------
+__global__ void iota_kernel(int64_t len, uint32_t* __restrict__ v) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride)
+        v[e] = (uint32_t)e;
+}
+// class_start[l] = first position of label l in the sorted key array (sorted_keys ascending)
+__global__ void class_starts_kernel(int64_t len, const uint32_t* __restrict__ sorted_keys,
+                                    int64_t* __restrict__ class_start) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        uint32_t k = sorted_keys[e];
+        if (e == 0 || sorted_keys[e - 1] != k) class_start[k] = e;
+    }
+}
+
+int sort_entries_by_label(sdpsr_ctx* c, int64_t len, int64_t d, const uint32_t* L,
+                          uint32_t** ent_out, int64_t** class_ptr_host) {
+    hipStream_t s = c->stream;
+    uint32_t* idx_in = (uint32_t*)ctx_buf(c, "bi_idx_in", len * sizeof(uint32_t));
+    uint32_t* idx_out = (uint32_t*)ctx_buf(c, "bi_idx_out", len * sizeof(uint32_t));
+    uint32_t* key_out = (uint32_t*)ctx_buf(c, "bi_key_out", len * sizeof(uint32_t));
+    int64_t* cstart = (int64_t*)ctx_buf(c, "bi_cstart", (d + 2) * sizeof(int64_t));
+    if (!idx_in || !idx_out || !key_out || !cstart) return SDPSR_OUT_OF_MEMORY;
+    iota_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, idx_in);
+    int bits = 1;
+    while (((int64_t)1 << bits) <= d) ++bits;
+    size_t tmp_bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, L, key_out, idx_in, idx_out, (int)len, 0,
+                                       bits, s);
+    void* tmp = ctx_buf(c, "bi_sort_tmp", tmp_bytes);
+    if (!tmp) return SDPSR_OUT_OF_MEMORY;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, L, key_out, idx_in, idx_out,
+                                                      (int)len, 0, bits, s);
+    if (e != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "radix sort failed");
+    hipMemsetAsync(cstart, 0xFF, (d + 2) * sizeof(int64_t), s);  // -1 = class absent
+    class_starts_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, key_out, cstart);
+    int64_t* h = (int64_t*)malloc((d + 2) * sizeof(int64_t));
+    if (!h) return SDPSR_OUT_OF_MEMORY;
+    e = hipMemcpyAsync(h, cstart, (d + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        free(h);
+        return ctx_fail(c, SDPSR_HIP_ERROR, "class start read-back failed");
+    }
+    // class_ptr[i] .. class_ptr[i+1] = entries of label i (i = 0..d); fill absent classes
+    h[d + 1] = len;
+    for (int64_t l = d; l >= 0; --l)
+        if (h[l] < 0) h[l] = h[l + 1];
+    *ent_out = idx_out;
+    *class_ptr_host = h;
+    return SDPSR_OK;
+}
+
+}  // namespace sdpsr

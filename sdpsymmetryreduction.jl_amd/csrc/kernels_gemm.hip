@@ -1,0 +1,267 @@
+// C = A' * B on the gfx950 matrix cores, column-major operands (A: k x m, B: k x n, so both
+// are read along their contiguous dimension), MFMA tiles staged through LDS.
+//
+// Serves  mul!(X2, X, X)           src/partitions.jl:172   (X symmetric => X*X = X'X)
+//         Q' * A * Q               src/eigen_decomposition.jl:203 (A symmetric)
+//         A * F (first columns)    src/eigen_decomposition.jl:333
+//
+// Variants: int8 -> int32 (v_mfma_i32_32x32x32_i8), f32 (v_mfma_f32_32x32x2_f32, exact f32
+// fma chain), f64 (v_mfma_f64_16x16x4_f64).  One workgroup = 4 waves = one 128 x 128 tile
+// of C; a wave owns a 64 x 64 sub-tile.  K is walked in tiles of KB bytes per operand
+// row, register-staged and double-buffered in LDS (one barrier per K-tile); LDS rows are
+// padded by 16 B so the ds_read_b128 fragment reads are bank-conflict free.
+//
+// Fragment rule used throughout: a lane reads 16 contiguous bytes of "its" operand row
+// and uses them for 1 (i8), 4 (f32) or 2 (f64) consecutive MFMAs.  A and B fragments are
+// cut the same way, so each MFMA multiplies matching k indices; the order in which k is
+// consumed differs from the natural one, which only permutes an exact sum (integers) or
+// the fp rounding order (f32/f64).
+#include "sdpsr_internal.h"
+
+namespace sdpsr {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128;   // rows of C per workgroup (i, from operand A)
+constexpr int BN = 128;   // cols of C per workgroup (j, from operand B)
+constexpr int NT = 256;   // threads
+
+enum { KIND_I8 = 0, KIND_F32 = 1, KIND_F64 = 2 };
+
+template <int KIND> struct GemmTraits;
+template <> struct GemmTraits<KIND_I8> {
+    typedef int8_t in_t;
+    typedef int32_t out_t;
+    static constexpr int KB = 64;  // bytes of K per operand row per K-tile
+};
+template <> struct GemmTraits<KIND_F32> {
+    typedef float in_t;
+    typedef float out_t;
+    static constexpr int KB = 128;
+};
+template <> struct GemmTraits<KIND_F64> {
+    typedef double in_t;
+    typedef double out_t;
+    static constexpr int KB = 128;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(NT)
+gemm_tn_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag, int64_t lda,
+               const typename GemmTraits<KIND>::in_t* __restrict__ Bg, int64_t ldb,
+               typename GemmTraits<KIND>::out_t* __restrict__ Cg, int64_t ldc, int64_t strideA,
+               int64_t strideB, int64_t strideC) {
+    typedef GemmTraits<KIND> TR;
+    typedef typename TR::in_t in_t;
+    typedef typename TR::out_t out_t;
+    constexpr int KB = TR::KB;
+    constexpr int ES = sizeof(in_t);
+    constexpr int KE = KB / ES;          // k elements per K-tile
+    constexpr int RS = KB + 16;          // padded LDS row stride (bytes)
+    constexpr int CH = KB / 16;          // 16-byte chunks per row
+    constexpr int LPT = BM * CH / NT;    // chunks per thread per operand (2 or 4)
+    constexpr int OPB = BM * RS;         // bytes per operand tile in LDS
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // layout: [buf][operand][row][RS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wi = wave & 1;   // wave position along i
+    const int wj = wave >> 1;  // wave position along j
+
+    const int64_t i0 = (int64_t)blockIdx.x * BM;
+    const int64_t j0 = (int64_t)blockIdx.y * BN;
+    const char* Ab = reinterpret_cast<const char*>(Ag + (int64_t)blockIdx.z * strideA + i0 * lda);
+    const char* Bb = reinterpret_cast<const char*>(Bg + (int64_t)blockIdx.z * strideB + j0 * ldb);
+    out_t* C = Cg + (int64_t)blockIdx.z * strideC;
+
+    // staging assignment: chunk q = tid + s*NT -> row q / CH, chunk q % CH
+    int srow[LPT], scol[LPT];
+#pragma unroll
+    for (int s = 0; s < LPT; ++s) {
+        int q = tid + s * NT;
+        srow[s] = q / CH;
+        scol[s] = q % CH;
+    }
+    uint4 ra[LPT], rb[LPT];
+    auto load_tile = [&](int64_t kt) {
+        const int64_t kbyte = kt * KB;
+#pragma unroll
+        for (int s = 0; s < LPT; ++s) {
+            ra[s] = *reinterpret_cast<const uint4*>(Ab + (int64_t)srow[s] * lda * ES + kbyte + scol[s] * 16);
+            rb[s] = *reinterpret_cast<const uint4*>(Bb + (int64_t)srow[s] * ldb * ES + kbyte + scol[s] * 16);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* base = smem + buf * 2 * OPB;
+#pragma unroll
+        for (int s = 0; s < LPT; ++s) {
+            *reinterpret_cast<uint4*>(base + srow[s] * RS + scol[s] * 16) = ra[s];
+            *reinterpret_cast<uint4*>(base + OPB + srow[s] * RS + scol[s] * 16) = rb[s];
+        }
+    };
+
+    const int64_t nk = k / KE;
+
+    if constexpr (KIND == KIND_I8 || KIND == KIND_F32) {
+        // 32x32 MFMA tiles: 2 (j) x 2 (i) per wave.  MFMA "A" operand <- B tile (j),
+        // MFMA "B" operand <- A tile (i): D[jj][ii], lanes run along i (contiguous in C).
+        typedef typename std::conditional<KIND == KIND_I8, v16i, v16f>::type acc_t;
+        acc_t acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+        const int r32 = lane & 31, h = lane >> 5;
+
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const int buf = (int)(kt & 1);
+            if (kt + 1 < nk) load_tile(kt + 1);
+            const char* tA = smem + buf * 2 * OPB;  // rows i
+            const char* tB = tA + OPB;              // rows j
+            constexpr int NQ = KB / 32;             // 32-byte groups per row (2 halves x 16 B)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                uint4 fi[2], fj[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fi[t] = *reinterpret_cast<const uint4*>(tA + (wi * 64 + t * 32 + r32) * RS + q * 32 + h * 16);
+                    fj[t] = *reinterpret_cast<const uint4*>(tB + (wj * 64 + t * 32 + r32) * RS + q * 32 + h * 16);
+                }
+                if constexpr (KIND == KIND_I8) {
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti) {
+                            v4i a = {(int)fj[tj].x, (int)fj[tj].y, (int)fj[tj].z, (int)fj[tj].w};
+                            v4i b = {(int)fi[ti].x, (int)fi[ti].y, (int)fi[ti].z, (int)fi[ti].w};
+                            acc[tj][ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[tj][ti], 0, 0, 0);
+                        }
+                } else {
+                    const float* fjf0 = reinterpret_cast<const float*>(&fj[0]);
+                    const float* fjf1 = reinterpret_cast<const float*>(&fj[1]);
+                    const float* fif0 = reinterpret_cast<const float*>(&fi[0]);
+                    const float* fif1 = reinterpret_cast<const float*>(&fi[1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fjf0[e], fif0[e], acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fjf0[e], fif1[e], acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fjf1[e], fif0[e], acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fjf1[e], fif1[e], acc[1][1], 0, 0, 0);
+                    }
+                }
+            }
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+        // D[jj][ii]: ii = lane & 31, jj = (reg & 3) + 8 * (reg >> 2) + 4 * h
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int64_t ii = i0 + wi * 64 + ti * 32 + r32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t jj = j0 + wj * 64 + tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    C[ii + jj * ldc] = acc[tj][ti][r];
+                }
+            }
+    } else {
+        // f64: 16x16x4 tiles, 4 (j) x 4 (i) per wave; lane (r16 = lane & 15, g = lane >> 4)
+        v4d acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.0;
+        const int r16 = lane & 15, g = lane >> 4;
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const int buf = (int)(kt & 1);
+            if (kt + 1 < nk) load_tile(kt + 1);
+            const char* tA = smem + buf * 2 * OPB;
+            const char* tB = tA + OPB;
+            constexpr int NQ = KB / 64;  // 64-byte groups (4 lane groups x 16 B)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                v2d fi[4], fj[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    fi[t] = *reinterpret_cast<const v2d*>(tA + (wi * 64 + t * 16 + r16) * RS + q * 64 + g * 16);
+                    fj[t] = *reinterpret_cast<const v2d*>(tB + (wj * 64 + t * 16 + r16) * RS + q * 64 + g * 16);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                        for (int ti = 0; ti < 4; ++ti)
+                            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[tj][e], fi[ti][e], acc[tj][ti], 0, 0, 0);
+            }
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+        // D[jj][ii]: ii = lane & 15, jj = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                const int64_t ii = i0 + wi * 64 + ti * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t jj = j0 + wj * 64 + tj * 16 + g + 4 * r;
+                    C[ii + jj * ldc] = acc[tj][ti][r];
+                }
+            }
+    }
+}
+
+template <int KIND>
+static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
+                        const typename GemmTraits<KIND>::in_t* A, int64_t lda,
+                        const typename GemmTraits<KIND>::in_t* B, int64_t ldb,
+                        typename GemmTraits<KIND>::out_t* C, int64_t ldc, int batch,
+                        int64_t strideA, int64_t strideB, int64_t strideC) {
+    constexpr int KB = GemmTraits<KIND>::KB;
+    constexpr size_t lds = 2 * 2 * BM * (KB + 16);
+    dim3 grid((unsigned)(m / BM), (unsigned)(n / BN), (unsigned)batch);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<KIND>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    gemm_tn_kernel<KIND><<<grid, NT, lds, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC);
+}
+
+void launch_gemm_tn_i8(hipStream_t s, int64_t m, int64_t n, int64_t k, const int8_t* A,
+                       int64_t lda, const int8_t* B, int64_t ldb, int32_t* C, int64_t ldc,
+                       int batch, int64_t strideA, int64_t strideB, int64_t strideC) {
+    launch_gemm<KIND_I8>(s, m, n, k, A, lda, B, ldb, C, ldc, batch, strideA, strideB, strideC);
+}
+void launch_gemm_tn_f32(hipStream_t s, int64_t m, int64_t n, int64_t k, const float* A,
+                        int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                        int batch, int64_t strideA, int64_t strideB, int64_t strideC) {
+    launch_gemm<KIND_F32>(s, m, n, k, A, lda, B, ldb, C, ldc, batch, strideA, strideB, strideC);
+}
+void launch_gemm_tn_f64(hipStream_t s, int64_t m, int64_t n, int64_t k, const double* A,
+                        int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                        int batch, int64_t strideA, int64_t strideB, int64_t strideC) {
+    launch_gemm<KIND_F64>(s, m, n, k, A, lda, B, ldb, C, ldc, batch, strideA, strideB, strideC);
+}
+
+}  // namespace sdpsr

@@ -1,0 +1,636 @@
+// Partition kernels for gfx950: label gather (fill!/randomize!), projection onto L,
+// signatures, and the canonical partition refinement.
+//
+// Reference semantics restated here:
+//   fill!/randomize!      src/partitions.jl:68-75, src/abstract_part.jl:107-110
+//   _clamp_round!         src/utils.jl:34-53
+//   x .-= projL(x)        src/partitions.jl:161, src/utils.jl:62-66
+//   Partition(M), refine! src/partitions.jl:24-35,44-66
+//
+// All of these are HBM-bound: one pass over n^2 entries each, 16-byte accesses per lane,
+// grid sized to a few blocks per CU with grid-stride loops.
+#include "sdpsr_internal.h"
+
+namespace sdpsr {
+
+static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// fill / randomize / clamp_round
+// ---------------------------------------------------------------------------
+__global__ void fill_f64_kernel(int64_t len, const uint32_t* __restrict__ L,
+                                const double* __restrict__ values, double* __restrict__ M) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        uint32_t l = L[e];
+        M[e] = l ? values[l - 1] : 0.0;
+    }
+}
+
+__global__ void randomize_f64_kernel(int64_t len, const uint32_t* __restrict__ L, uint64_t key,
+                                     double* __restrict__ M) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        uint32_t l = L[e];
+        M[e] = l ? sdpsr_class_uniform(key, l) : 0.0;
+    }
+}
+
+__global__ void clamp_round_kernel(int64_t len, double* __restrict__ a, double atol,
+                                   double scale) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride)
+        a[e] = sdpsr_clamp_round(a[e], atol, scale);
+}
+
+void launch_fill_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* values,
+                     double* M) {
+    fill_f64_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, values, M);
+}
+void launch_randomize_f64(hipStream_t s, int64_t len, const uint32_t* L, uint64_t key,
+                          double* M) {
+    randomize_f64_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, key, M);
+}
+void launch_clamp_round(hipStream_t s, int64_t len, double* a, double atol, double scale) {
+    clamp_round_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, a, atol, scale);
+}
+
+// ---------------------------------------------------------------------------
+// channel gathers for the square step.  One thread = 16 consecutive rows of one
+// column of the padded ld x ld matrix; each channel gets one 16-byte store (int8) or
+// four (f32).  Padding rows/columns are zero.
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ void gather_i8_kernel(int64_t n, int64_t ld, const uint32_t* __restrict__ L,
+                                 uint64_t key, int8_t* __restrict__ X) {
+    const int64_t chunks_per_col = ld / 16;
+    const int64_t total = chunks_per_col * ld;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += stride) {
+        const int64_t j = c / chunks_per_col;
+        const int64_t i0 = (c - j * chunks_per_col) * 16;
+        uint32_t out[T][4];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) out[t][w] = 0;
+        if (j < n) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t i = i0 + q;
+                uint32_t l = (i < n) ? L[i + j * n] : 0u;
+                uint64_t bits = l ? sdpsr_class_bits(key, l) : 0ull;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    out[t][q >> 2] |= (uint32_t)((bits >> (8 * t)) & 0xFFull) << (8 * (q & 3));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            uint4 v = make_uint4(out[t][0], out[t][1], out[t][2], out[t][3]);
+            *reinterpret_cast<uint4*>(X + (int64_t)t * ld * ld + i0 + j * ld) = v;
+        }
+    }
+}
+
+void launch_gather_i8(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
+                      uint64_t key, int8_t* X) {
+    int g = grid_for(ld / 16 * ld, 256);
+    switch (T) {
+        case 1: gather_i8_kernel<1><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+        case 2: gather_i8_kernel<2><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+        case 3: gather_i8_kernel<3><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+        case 4: gather_i8_kernel<4><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+        case 5: gather_i8_kernel<5><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+        case 6: gather_i8_kernel<6><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+        case 7: gather_i8_kernel<7><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+        default: gather_i8_kernel<8><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+    }
+}
+
+__global__ void gather_f32_kernel(int64_t n, int64_t ld, int T, int vmax,
+                                  const uint32_t* __restrict__ L, uint64_t key,
+                                  float* __restrict__ X) {
+    const int64_t chunks_per_col = ld / 4;
+    const int64_t total = chunks_per_col * ld;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += stride) {
+        const int64_t j = c / chunks_per_col;
+        const int64_t i0 = (c - j * chunks_per_col) * 4;
+        uint64_t bits[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = i0 + q;
+            uint32_t l = (i < n && j < n) ? L[i + j * n] : 0u;
+            bits[q] = l ? (sdpsr_class_bits(key, l) | (1ull << 63)) : 0ull;  // bit 63: nonzero class
+        }
+        for (int t = 0; t < T; ++t) {
+            float4 v;
+            v.x = bits[0] ? (float)sdpsr_class_small(bits[0], t, vmax) : 0.f;
+            v.y = bits[1] ? (float)sdpsr_class_small(bits[1], t, vmax) : 0.f;
+            v.z = bits[2] ? (float)sdpsr_class_small(bits[2], t, vmax) : 0.f;
+            v.w = bits[3] ? (float)sdpsr_class_small(bits[3], t, vmax) : 0.f;
+            *reinterpret_cast<float4*>(X + (int64_t)t * ld * ld + i0 + j * ld) = v;
+        }
+    }
+}
+
+void launch_gather_f32(hipStream_t s, int64_t n, int64_t ld, int T, int vmax, const uint32_t* L,
+                       uint64_t key, float* X) {
+    gather_f32_kernel<<<grid_for(ld / 4 * ld, 256), 256, 0, s>>>(n, ld, T, vmax, L, key, X);
+}
+
+__global__ void gather_f64_padded_kernel(int64_t n, int64_t ld, const uint32_t* __restrict__ L,
+                                         uint64_t key, double* __restrict__ X) {
+    const int64_t chunks_per_col = ld / 2;
+    const int64_t total = chunks_per_col * ld;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += stride) {
+        const int64_t j = c / chunks_per_col;
+        const int64_t i0 = (c - j * chunks_per_col) * 2;
+        double2 v;
+        uint32_t l0 = (i0 < n && j < n) ? L[i0 + j * n] : 0u;
+        uint32_t l1 = (i0 + 1 < n && j < n) ? L[i0 + 1 + j * n] : 0u;
+        v.x = l0 ? sdpsr_class_uniform(key, l0) : 0.0;
+        v.y = l1 ? sdpsr_class_uniform(key, l1) : 0.0;
+        *reinterpret_cast<double2*>(X + i0 + j * ld) = v;
+    }
+}
+
+void launch_gather_f64_padded(hipStream_t s, int64_t n, int64_t ld, const uint32_t* L,
+                              uint64_t key, double* X) {
+    gather_f64_padded_kernel<<<grid_for(ld / 2 * ld, 256), 256, 0, s>>>(n, ld, L, key, X);
+}
+
+template <typename T>
+__global__ void pad_copy_kernel(int64_t n, int64_t ld, const T* __restrict__ src,
+                                T* __restrict__ dst) {
+    const int64_t total = ld * ld;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += stride) {
+        const int64_t j = c / ld, i = c - j * ld;
+        dst[c] = (i < n && j < n) ? src[i + j * n] : T(0);
+    }
+}
+template <typename T>
+__global__ void unpad_copy_kernel(int64_t n, int64_t ld, const T* __restrict__ src,
+                                  T* __restrict__ dst) {
+    const int64_t total = n * n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += stride) {
+        const int64_t j = c / n, i = c - j * n;
+        dst[c] = src[i + j * ld];
+    }
+}
+void launch_pad_copy(hipStream_t s, int64_t n, int64_t ld, const void* src, void* dst,
+                     int elem_bytes) {
+    int g = grid_for(ld * ld, 256);
+    if (elem_bytes == 1)
+        pad_copy_kernel<int8_t><<<g, 256, 0, s>>>(n, ld, (const int8_t*)src, (int8_t*)dst);
+    else if (elem_bytes == 4)
+        pad_copy_kernel<float><<<g, 256, 0, s>>>(n, ld, (const float*)src, (float*)dst);
+    else
+        pad_copy_kernel<double><<<g, 256, 0, s>>>(n, ld, (const double*)src, (double*)dst);
+}
+void launch_unpad_copy(hipStream_t s, int64_t n, int64_t ld, const void* src, void* dst,
+                       int elem_bytes) {
+    int g = grid_for(n * n, 256);
+    if (elem_bytes == 4)
+        unpad_copy_kernel<float><<<g, 256, 0, s>>>(n, ld, (const float*)src, (float*)dst);
+    else
+        unpad_copy_kernel<double><<<g, 256, 0, s>>>(n, ld, (const double*)src, (double*)dst);
+}
+
+// ---------------------------------------------------------------------------
+// projection  y = x - U (U' x)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;  // valid in thread 0
+}
+
+// grid = (nblk, r).  partial[k * nblk + b]
+__global__ void proj_coef_kernel(int64_t len, const double* __restrict__ U,
+                                 const uint32_t* __restrict__ L, uint64_t key,
+                                 const double* __restrict__ xin, double* __restrict__ partial) {
+    __shared__ double sh[8];
+    const int k = blockIdx.y;
+    const double* Uk = U + (int64_t)k * len;
+    double acc = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        double x;
+        if (xin) {
+            x = xin[e];
+        } else {
+            uint32_t l = L[e];
+            x = l ? sdpsr_class_uniform(key, l) : 0.0;
+        }
+        acc = fma(Uk[e], x, acc);
+    }
+    double r = block_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) partial[(int64_t)k * gridDim.x + blockIdx.x] = r;
+}
+
+__global__ void proj_coef_final_kernel(int nblk, const double* __restrict__ partial,
+                                       double* __restrict__ coef) {
+    __shared__ double sh[8];
+    const int k = blockIdx.x;
+    double acc = 0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc += partial[(int64_t)k * nblk + b];
+    double r = block_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) coef[k] = r;
+}
+
+void launch_proj_coef(hipStream_t s, int64_t len, int64_t r, const double* U, const uint32_t* L,
+                      uint64_t key, const double* xin, double* partial, int nblk, double* coef) {
+    if (r <= 0) return;
+    dim3 g(nblk, (unsigned)r);
+    proj_coef_kernel<<<g, 256, 0, s>>>(len, U, L, key, xin, partial);
+    proj_coef_final_kernel<<<(unsigned)r, 256, 0, s>>>(nblk, partial, coef);
+}
+
+__global__ void proj_apply_kernel(int64_t len, int r, const double* __restrict__ U,
+                                  const uint32_t* __restrict__ L, uint64_t key,
+                                  const double* __restrict__ xin, const double* __restrict__ coef,
+                                  double atol, double scale, int do_round,
+                                  double* __restrict__ yout, uint64_t* __restrict__ sig) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        uint32_t l = L ? L[e] : 0u;
+        double x;
+        if (xin)
+            x = xin[e];
+        else
+            x = l ? sdpsr_class_uniform(key, l) : 0.0;
+        double p = 0;
+        for (int k = 0; k < r; ++k) p = fma(U[(int64_t)k * len + e], coef[k], p);
+        double y = x - p;
+        if (do_round) y = sdpsr_clamp_round(y, atol, scale);
+        if (yout) yout[e] = y;
+        if (sig) {
+            uint64_t kb = (uint64_t)__double_as_longlong(y);
+            uint64_t h = 0;
+            if (l != 0 || kb != 0) {
+                h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
+                if (h == 0) h = 1;
+            }
+            sig[e] = h;
+        }
+    }
+}
+
+void launch_proj_apply(hipStream_t s, int64_t len, int64_t r, const double* U, const uint32_t* L,
+                       uint64_t key, const double* xin, const double* coef, double atol,
+                       double scale, int do_round, double* yout, uint64_t* sig) {
+    proj_apply_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, (int)r, U, L, key, xin, coef, atol,
+                                                         scale, do_round, yout, sig);
+}
+
+// ---------------------------------------------------------------------------
+// signatures
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t finish_sig(uint32_t l, bool all_zero, uint64_t h) {
+    if (l == 0 && all_zero) return 0;
+    return h ? h : 1;
+}
+
+__global__ void sig_f64_kernel(int64_t len, const uint32_t* __restrict__ L,
+                               const double* __restrict__ v, uint64_t* __restrict__ sig) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        uint32_t l = L ? L[e] : 0u;
+        uint64_t kb = (uint64_t)__double_as_longlong(v[e]);
+        sig[e] = finish_sig(l, kb == 0, sdpsr_sig_mix(sdpsr_sig_start(l), kb));
+    }
+}
+void launch_sig_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* v,
+                    uint64_t* sig) {
+    sig_f64_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, v, sig);
+}
+
+// v is a padded ld x ld matrix; output sig is dense n x n
+__global__ void sig_f64_rounded_kernel(int64_t n, int64_t ld, const uint32_t* __restrict__ L,
+                                       const double* __restrict__ v, double atol, double scale,
+                                       uint64_t* __restrict__ sig) {
+    const int64_t len = n * n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const int64_t j = e / n, i = e - j * n;
+        uint32_t l = L[e];
+        double y = sdpsr_clamp_round(v[i + j * ld], atol, scale);
+        uint64_t kb = (uint64_t)__double_as_longlong(y);
+        sig[e] = finish_sig(l, kb == 0, sdpsr_sig_mix(sdpsr_sig_start(l), kb));
+    }
+}
+void launch_sig_f64_rounded(hipStream_t s, int64_t n, int64_t ld, const uint32_t* L,
+                            const double* v, double atol, double scale, uint64_t* sig) {
+    sig_f64_rounded_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, L, v, atol, scale, sig);
+}
+
+__global__ void sig_u32_kernel(int64_t len, const uint32_t* __restrict__ L,
+                               const uint32_t* __restrict__ k, uint64_t* __restrict__ sig) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        uint32_t l = L ? L[e] : 0u;
+        uint32_t kk = k[e];
+        sig[e] = finish_sig(l, kk == 0, sdpsr_sig_mix(sdpsr_sig_start(l), (uint64_t)kk));
+    }
+}
+void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_t* k,
+                    uint64_t* sig) {
+    sig_u32_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, k, sig);
+}
+
+template <typename CT>
+__global__ void sig_channels_kernel(int64_t n, int64_t ld, int T, const uint32_t* __restrict__ L,
+                                    const CT* __restrict__ C, uint64_t* __restrict__ sig) {
+    const int64_t len = n * n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const int64_t j = e / n, i = e - j * n;
+        uint32_t l = L[e];
+        uint64_t h = sdpsr_sig_start(l);
+        bool allz = true;
+        for (int t = 0; t < T; ++t) {
+            CT c = C[(int64_t)t * ld * ld + i + j * ld];
+            int32_t ci = (int32_t)c;  // exact: f32 channels hold integers < 2^24
+            allz = allz && (ci == 0);
+            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)ci);
+        }
+        sig[e] = finish_sig(l, allz, h);
+    }
+}
+void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
+                    const int32_t* C, uint64_t* sig) {
+    sig_channels_kernel<int32_t><<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, T, L, C, sig);
+}
+void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
+                    const float* C, uint64_t* sig) {
+    sig_channels_kernel<float><<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, T, L, C, sig);
+}
+
+// ---------------------------------------------------------------------------
+// Canonical refinement of 64-bit signatures.
+//
+//   pass A  every block dedups its REFINE_BLOCK entries in an LDS hash table (sig -> min
+//           index), then publishes each distinct signature once to the global table
+//           (write-once 64-bit CAS slots + atomicMin of the first index); the global slot
+//           of every entry is parked in labels_out.
+//   pass B  per block: count entries that are the first occurrence of their class.
+//   scan    exclusive scan of the block counts (one block).
+//   pass C  rank first occurrences inside the block -> label of the class (1-based, in
+//           column-major first-occurrence order = the reference's canonical numbering).
+//   pass D  labels_out[e] = label of its slot.
+// ---------------------------------------------------------------------------
+constexpr int REFINE_THREADS = 256;
+constexpr int REFINE_PER_THREAD = 4;
+constexpr int REFINE_BLOCK = REFINE_THREADS * REFINE_PER_THREAD;  // 1024 entries
+constexpr int LDS_SLOTS = 2048;
+constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+constexpr int MAX_PROBES = 4096;
+
+size_t refine_block_entries() { return REFINE_BLOCK; }
+
+__device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned long long* tab,
+                                                          uint32_t mask, uint32_t* counters) {
+    uint32_t idx = (uint32_t)sg & mask;
+    for (int probe = 0; probe < MAX_PROBES; ++probe) {
+        unsigned long long cur = tab[idx];  // slots are write-once: a stale read can only be 0
+        if (cur == sg) return idx;
+        if (cur == 0ull) {
+            unsigned long long old = atomicCAS(&tab[idx], 0ull, (unsigned long long)sg);
+            if (old == 0ull) {
+                uint32_t cnt = atomicAdd(&counters[0], 1u);
+                if (cnt + 1 > (mask >> 1) + (mask >> 2)) counters[1] = 1u;  // > 75% full
+                return idx;
+            }
+            if (old == sg) return idx;
+        }
+        idx = (idx + 1) & mask;
+    }
+    counters[1] = 1u;  // overflow: host retries with a larger table
+    return NO_SLOT;
+}
+
+__global__ void __launch_bounds__(REFINE_THREADS)
+refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
+                     uint32_t* __restrict__ slot_out, unsigned long long* __restrict__ tab_sig,
+                     uint32_t* __restrict__ tab_min, uint32_t mask, uint32_t* counters) {
+    __shared__ unsigned long long l_sig[LDS_SLOTS];
+    __shared__ uint32_t l_min[LDS_SLOTS];
+    __shared__ uint32_t l_gslot[LDS_SLOTS];
+    const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
+            l_sig[i] = 0ull;
+            l_min[i] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        const int64_t base = blk * REFINE_BLOCK;
+        uint64_t my[REFINE_PER_THREAD];
+        int myslot[REFINE_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < REFINE_PER_THREAD; ++q) {
+            // entry order inside the block does not matter for pass A
+            const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+            uint64_t sg = (e < len) ? sig[e] : 0ull;
+            my[q] = sg;
+            myslot[q] = -1;
+            if (sg) {
+                uint32_t idx = (uint32_t)(sg >> 40) & (LDS_SLOTS - 1);
+                while (true) {
+                    unsigned long long cur = l_sig[idx];
+                    if (cur == sg) break;
+                    if (cur == 0ull) {
+                        unsigned long long old = atomicCAS(&l_sig[idx], 0ull, (unsigned long long)sg);
+                        if (old == 0ull || old == sg) break;
+                    }
+                    idx = (idx + 1) & (LDS_SLOTS - 1);
+                }
+                atomicMin(&l_min[idx], (uint32_t)e);
+                myslot[q] = (int)idx;
+            }
+        }
+        __syncthreads();
+        // publish distinct signatures of this block
+        for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
+            unsigned long long sg = l_sig[i];
+            if (sg) {
+                uint32_t g = global_find_or_insert(sg, tab_sig, mask, counters);
+                if (g != NO_SLOT) atomicMin(&tab_min[g], l_min[i]);
+                l_gslot[i] = g;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < REFINE_PER_THREAD; ++q) {
+            const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+            if (e < len) slot_out[e] = (myslot[q] >= 0) ? l_gslot[myslot[q]] : NO_SLOT;
+        }
+        __syncthreads();
+    }
+}
+
+// thread t of the block owns entries base + 4t .. 4t+3 (index order matters here)
+__device__ __forceinline__ int first_flags(int64_t len, int64_t base,
+                                           const uint32_t* __restrict__ slot,
+                                           const uint32_t* __restrict__ tab_min, int* flags,
+                                           uint32_t* slots) {
+    int cnt = 0;
+    const int64_t e0 = base + (int64_t)threadIdx.x * REFINE_PER_THREAD;
+#pragma unroll
+    for (int q = 0; q < REFINE_PER_THREAD; ++q) {
+        const int64_t e = e0 + q;
+        uint32_t sl = (e < len) ? slot[e] : NO_SLOT;
+        slots[q] = sl;
+        int f = 0;
+        if (sl != NO_SLOT) f = (tab_min[sl] == (uint32_t)e);
+        flags[q] = f;
+        cnt += f;
+    }
+    return cnt;
+}
+
+__global__ void __launch_bounds__(REFINE_THREADS)
+refine_count_kernel(int64_t len, const uint32_t* __restrict__ slot,
+                    const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ blk_cnt) {
+    __shared__ int sh[REFINE_THREADS / 64];
+    const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        int flags[REFINE_PER_THREAD];
+        uint32_t slots[REFINE_PER_THREAD];
+        int cnt = first_flags(len, blk * REFINE_BLOCK, slot, tab_min, flags, slots);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < REFINE_THREADS / 64; ++w) t += sh[w];
+            blk_cnt[blk] = (uint32_t)t;
+        }
+        __syncthreads();
+    }
+}
+
+// exclusive scan of blk_cnt[0..nblk) in place; counters[2] = total
+__global__ void __launch_bounds__(1024)
+refine_scan_kernel(int64_t nblk, uint32_t* __restrict__ blk_cnt, uint32_t* counters) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t base = 0; base < nblk; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        uint32_t v = (i < nblk) ? blk_cnt[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        uint32_t incl = x + woff + carry;
+        if (i < nblk) blk_cnt[i] = incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counters[2] = carry;
+}
+
+__global__ void __launch_bounds__(REFINE_THREADS)
+refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
+                   const uint32_t* __restrict__ tab_min, const uint32_t* __restrict__ blk_off,
+                   uint32_t* __restrict__ tab_lab) {
+    __shared__ int wsum[REFINE_THREADS / 64];
+    const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        int flags[REFINE_PER_THREAD];
+        uint32_t slots[REFINE_PER_THREAD];
+        int cnt = first_flags(len, blk * REFINE_BLOCK, slot, tab_min, flags, slots);
+        int x = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        int excl = x - cnt + woff;
+        uint32_t lab = blk_off[blk] + (uint32_t)excl;
+#pragma unroll
+        for (int q = 0; q < REFINE_PER_THREAD; ++q)
+            if (flags[q]) tab_lab[slots[q]] = ++lab;
+        __syncthreads();
+    }
+}
+
+__global__ void refine_label_kernel(int64_t len, uint32_t* __restrict__ slot_inout,
+                                    const uint32_t* __restrict__ tab_lab) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        uint32_t sl = slot_inout[e];
+        slot_inout[e] = (sl == NO_SLOT) ? 0u : tab_lab[sl];
+    }
+}
+
+void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out,
+                   const RefineWs& ws) {
+    const size_t cap = (size_t)1 << ws.log2cap;
+    hipMemsetAsync(ws.tab_sig, 0, cap * sizeof(uint64_t), s);
+    hipMemsetAsync(ws.tab_min, 0xFF, cap * sizeof(uint32_t), s);
+    hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint32_t), s);
+    const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
+    const int g = (int)(nblk < 256 * 5 ? nblk : 256 * 5);
+    refine_insert_kernel<<<g, REFINE_THREADS, 0, s>>>(len, sig, labels_out,
+                                                      (unsigned long long*)ws.tab_sig, ws.tab_min,
+                                                      (uint32_t)(cap - 1), ws.counters);
+    const int g2 = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
+    refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt);
+    refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
+    refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt,
+                                                     ws.tab_lab);
+    refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, labels_out, ws.tab_lab);
+}
+
+// ---------------------------------------------------------------------------
+// symmetric label check
+// ---------------------------------------------------------------------------
+__global__ void check_symmetric_kernel(int64_t n, const uint32_t* __restrict__ L,
+                                       uint32_t* flag) {
+    const int64_t len = n * n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const int64_t j = e / n, i = e - j * n;
+        if (i > j && L[e] != L[j + i * n]) bad = true;
+    }
+    if (bad) flag[0] = 1u;
+}
+void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag) {
+    hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
+    check_symmetric_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, L, flag);
+}
+
+}  // namespace sdpsr

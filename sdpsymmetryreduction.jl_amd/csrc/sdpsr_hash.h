@@ -1,0 +1,67 @@
+// Counter-based random values per class and the 64-bit signature mix.
+// Usable from host and device code (plain integer arithmetic).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SDPSR_HD __host__ __device__ __forceinline__
+#else
+#define SDPSR_HD inline
+#endif
+
+SDPSR_HD uint64_t sdpsr_fmix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// key of one draw: seed and stream id are folded once on the host.
+SDPSR_HD uint64_t sdpsr_stream_key(uint64_t seed, uint64_t stream) {
+    return sdpsr_fmix64(seed + 0x9E3779B97F4A7C15ULL * (stream + 1));
+}
+
+// 64 random bits of class `label` (1-based) in draw `key`.
+SDPSR_HD uint64_t sdpsr_class_bits(uint64_t key, uint32_t label) {
+    return sdpsr_fmix64(key + 0x9E3779B97F4A7C15ULL * (uint64_t)label);
+}
+
+// uniform [0,1) double, rand(Float64) of src/abstract_part.jl:108
+SDPSR_HD double sdpsr_class_uniform(uint64_t key, uint32_t label) {
+    return (double)(sdpsr_class_bits(key, label) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// channel t (0..7) int8 value of the class: byte t of the 64 bits, as signed.
+SDPSR_HD int sdpsr_class_i8(uint64_t bits, int t) { return (int)(int8_t)(bits >> (8 * t)); }
+
+// integer value in [-vmax, vmax] for the fp32-exact mode (7 bits per channel used).
+SDPSR_HD int sdpsr_class_small(uint64_t bits, int t, int vmax) {
+    uint32_t b = (uint32_t)(bits >> (8 * t)) & 0xFFu;
+    return (int)((b * (uint32_t)(2 * vmax + 1)) >> 8) - vmax;
+}
+
+// signature chaining: h' = mix(h, v)
+SDPSR_HD uint64_t sdpsr_sig_mix(uint64_t h, uint64_t v) {
+    return sdpsr_fmix64(h + 0x9E3779B97F4A7C15ULL + v * 0xD6E8FEB86659FD93ULL);
+}
+
+// start of a signature chain from the old label
+SDPSR_HD uint64_t sdpsr_sig_start(uint32_t label) {
+    return sdpsr_fmix64(0x51ED270B0F3A4C27ULL ^ (uint64_t)label);
+}
+
+// round-to-nearest restatement of _clamp_round!/unsafe_round (src/utils.jl:34-53):
+// |a| < atol -> +0.0; else mantissa in [0.5,1) kept to `scale` = 10^sigdigits steps.
+SDPSR_HD double sdpsr_clamp_round(double a, double atol, double scale) {
+    double aa = a < 0 ? -a : a;
+    if (aa < atol) return 0.0;
+    int e;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double x = frexp(a, &e);
+    double y = rint(scale * x) / scale;
+    return ldexp(y, e);
+#else
+    double x = __builtin_frexp(a, &e);
+    double y = __builtin_rint(scale * x) / scale;
+    return __builtin_ldexp(y, e);
+#endif
+}

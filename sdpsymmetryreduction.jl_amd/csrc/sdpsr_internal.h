@@ -1,0 +1,183 @@
+// Internal declarations shared by the host orchestration (api.cpp) and the kernel
+// translation units.  Nothing here is part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sdpsr.h"
+#include "sdpsr_hash.h"
+
+struct rocblas_handle_wrap;  // opaque (eigen.cpp)
+
+// ---------------------------------------------------------------------------
+// grow-only named device buffers: no hipMalloc inside steady-state loops
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct sdpsr_ctx {
+    int device = 0;
+    uint64_t seed = 0;
+    uint64_t stream_counter = 0;  // fresh RNG stream per randomize call
+    sdpsr_opts opts{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::map<std::string, DevBuf> bufs;
+    void* pinned = nullptr;  // small pinned host scratch for scalar read-backs
+    size_t pinned_bytes = 0;
+    void* rocblas = nullptr;  // rocblas_handle, created lazily
+    // --- block-diagonalisation state kept between phase 1 and phase 2 ---
+    int64_t bd_n = 0, bd_d = 0;
+    std::vector<int32_t> bd_sizes;
+    int64_t bd_sum_s = 0, bd_sum_sq = 0;
+    bool bd_valid = false;
+    bool bd_labels_owned = false;
+    // hash table capacity hint (log2) for the next refine
+    int table_log2_hint = 12;
+    hipEvent_t ev[2 * SDPSR_T_COUNT] = {};
+};
+
+void* ctx_buf(sdpsr_ctx* c, const char* name, size_t bytes);  // throws std::bad_alloc-like via status
+int ctx_fail(sdpsr_ctx* c, int status, const std::string& msg);
+
+#define HIP_TRY(c, expr)                                                              \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess)                                                         \
+            return ctx_fail((c), SDPSR_HIP_ERROR,                                     \
+                            std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// kernels_partition.hip
+// ---------------------------------------------------------------------------
+namespace sdpsr {
+
+// M[e] = values[L[e]-1] (0 -> 0.0)
+void launch_fill_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* values,
+                     double* M);
+// M[e] = uniform(key, L[e])
+void launch_randomize_f64(hipStream_t s, int64_t len, const uint32_t* L, uint64_t key, double* M);
+// in-place clamp+round
+void launch_clamp_round(hipStream_t s, int64_t len, double* a, double atol, double scale);
+// int8 / f32 channel matrices, padded to ld (>= n, multiple of 16), zero in the padding.
+// X[t] is at X + t*ld*ld.
+void launch_gather_i8(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
+                      uint64_t key, int8_t* X);
+void launch_gather_f32(hipStream_t s, int64_t n, int64_t ld, int T, int vmax, const uint32_t* L,
+                       uint64_t key, float* X);
+void launch_gather_f64_padded(hipStream_t s, int64_t n, int64_t ld, const uint32_t* L,
+                              uint64_t key, double* X);
+// dense copy with padding: dst[ld x ld] <- src[n x n], zero padding (templated by bytes)
+void launch_pad_copy(hipStream_t s, int64_t n, int64_t ld, const void* src, void* dst,
+                     int elem_bytes);
+void launch_unpad_copy(hipStream_t s, int64_t n, int64_t ld, const void* src, void* dst,
+                       int elem_bytes);
+
+// projection: coef[k] = sum_e U[e,k] * x[e] with x[e] = uniform(key, L[e]) (Lx == nullptr)
+// or x[e] = xin[e].  partial: r * nblk doubles scratch.
+void launch_proj_coef(hipStream_t s, int64_t len, int64_t r, const double* U, const uint32_t* L,
+                      uint64_t key, const double* xin, double* partial, int nblk, double* coef);
+// y[e] = x[e] - sum_k U[e,k] coef[k]; optional outputs: yout (rounded value, fp64),
+// sig (signature chained on L).  x as above.
+void launch_proj_apply(hipStream_t s, int64_t len, int64_t r, const double* U, const uint32_t* L,
+                       uint64_t key, const double* xin, const double* coef, double atol,
+                       double scale, int do_round, double* yout, uint64_t* sig);
+
+// signatures.  sig = 0 <=> (L == 0 and key == 0).  L may be nullptr (all zero labels).
+void launch_sig_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* v, uint64_t* sig);
+void launch_sig_f64_rounded(hipStream_t s, int64_t n, int64_t ld, const uint32_t* L,
+                            const double* v, double atol, double scale, uint64_t* sig);
+void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_t* k,
+                    uint64_t* sig);
+// T channels of int32 / f32 squares, padded ld, C[t] at C + t*ld*ld
+void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
+                    const int32_t* C, uint64_t* sig);
+void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
+                    const float* C, uint64_t* sig);
+
+// canonical relabel of signatures (hash table + first-occurrence ranking).
+// Workspace layout is owned by the caller (see refine_workspace_bytes).
+struct RefineWs {
+    uint64_t* tab_sig;   // cap
+    uint32_t* tab_min;   // cap
+    uint32_t* tab_lab;   // cap
+    uint32_t* blk_cnt;   // nblk + 1
+    uint32_t* counters;  // [0] = inserted, [1] = overflow flag, [2] = nparts
+    int log2cap;
+    int nblk;
+};
+size_t refine_block_entries();
+void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out,
+                   const RefineWs& ws);
+
+// symmetric-labels check: flag[0] = 1 if some L[i,j] != L[j,i]
+void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag);
+
+// ---------------------------------------------------------------------------
+// kernels_gemm.hip:  C = A' * B (column-major), MFMA tiles staged through LDS.
+// Operands must be padded: k multiple of KT, m and n multiples of 128, pointers 16-B
+// aligned, lda/ldb multiples of 16 bytes.
+// ---------------------------------------------------------------------------
+void launch_gemm_tn_i8(hipStream_t s, int64_t m, int64_t n, int64_t k, const int8_t* A,
+                       int64_t lda, const int8_t* B, int64_t ldb, int32_t* C, int64_t ldc,
+                       int batch, int64_t strideA, int64_t strideB, int64_t strideC);
+void launch_gemm_tn_f32(hipStream_t s, int64_t m, int64_t n, int64_t k, const float* A,
+                        int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                        int batch, int64_t strideA, int64_t strideB, int64_t strideC);
+void launch_gemm_tn_f64(hipStream_t s, int64_t m, int64_t n, int64_t k, const double* A,
+                        int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                        int batch, int64_t strideA, int64_t strideB, int64_t strideC);
+
+// ---------------------------------------------------------------------------
+// kernels_blockdiag.hip
+// ---------------------------------------------------------------------------
+// norms[bi*neig+bj] = max |M[i,j]| over the (bi,bj) eigenspace block; space_of[n] maps an
+// index to its eigenspace.  norms must be zeroed (as uint64 bit patterns of doubles).
+void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
+                        const int32_t* space_of, int neig, unsigned long long* norms);
+// y = A * x for symmetric A (n x n, ld) and nv vectors (columns of X, ldx): Y[:,v]
+void launch_symm_multi_gemv(hipStream_t s, int64_t n, int64_t ld, const double* A,
+                            const double* X, int64_t ldx, int nv, double* Y, int64_t ldy);
+// out[j] = sum_i Q[i, col0 + j] * a[i], j < m   (Q' a over a column range)
+void launch_gemv_t(hipStream_t s, int64_t n, int64_t ld, const double* Q, int64_t col0,
+                   int64_t m, const double* a, double* out);
+// dst[i] (+)= alpha_dev[0] * sum_j Q[i, col0+j] * w[j]
+void launch_gemv_n_scaled(hipStream_t s, int64_t n, int64_t ld, const double* Q, int64_t col0,
+                          int64_t m, const double* w, const double* inv_norm, double* dst);
+// copy column / clamp
+void launch_copy_col(hipStream_t s, int64_t n, const double* src, double* dst);
+void launch_clamptol(hipStream_t s, int64_t len, double* a, double atol);
+// norm2 of a vector -> out[0] = 1/||v||
+void launch_inv_norm(hipStream_t s, int64_t m, const double* v, double* out);
+
+// basis image.  Qrm: row-major n x S1 (Q_hat rows contiguous).  entries sorted by class:
+// ent[e] = linear index, class_ptr[d+1].  desc: per output (colA, colB) pairs (S of them).
+void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S,
+                        const double* Qrm, const uint32_t* ent, const int64_t* class_ptr,
+                        const int32_t* descA, const int32_t* descB, const int64_t* chunk_ptr,
+                        int64_t nchunks_total, const int32_t* chunk_class,
+                        const int64_t* chunk_begin, const int64_t* chunk_end, double* partial,
+                        double* out, double atol);
+void launch_transpose_to_rowmajor(hipStream_t s, int64_t n, int64_t S1, const double* Qcm,
+                                  double* Qrm);
+// stable sort of entries by label (label 0 dropped): ent sorted, hist[d+1]
+int sort_entries_by_label(sdpsr_ctx* c, int64_t len, int64_t d, const uint32_t* L,
+                          uint32_t** ent_out, int64_t** class_ptr_host);
+
+// ---------------------------------------------------------------------------
+// eigen.cpp (rocSOLVER)
+// ---------------------------------------------------------------------------
+// A (n x n, leading dimension lda) is overwritten with the eigenvectors; w[n] ascending.
+int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w);
+void destroy_handle(sdpsr_ctx* c);
+
+}  // namespace sdpsr

@@ -1,0 +1,271 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+golden fixtures.  Bit-exact for labels / integer products; stated tolerances for fp."""
+import ctypes as C
+import pathlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def _fl(a, dt):
+    return np.ascontiguousarray(np.asarray(a, dtype=dt).ravel(order="F"))
+
+
+# ------------------------------------------------------------------ primitives
+def test_partition_from_values_matches_oracle(pkg, oracle, gpu_ctx):
+    rng = np.random.default_rng(0)
+    for shape in [(1, 1), (3, 3), (10, 10), (37, 37), (64, 64), (130, 130), (257, 255)]:
+        M = rng.integers(0, 9, size=shape).astype(np.float64) * 0.125
+        M[rng.random(shape) < 0.05] = -0.0  # isequal: -0.0 is its own class
+        P = pkg.Partition.from_matrix(M, ctx=gpu_ctx)
+        R = oracle.partition_from_values(M)
+        assert P.nparts == R.nparts
+        assert np.array_equal(P.matrix, R.matrix)
+
+
+def test_partition_all_distinct_and_all_zero(pkg, oracle, gpu_ctx):
+    M = np.arange(1, 300 * 300 + 1, dtype=np.float64).reshape(300, 300)
+    P = pkg.Partition.from_matrix(M, ctx=gpu_ctx)
+    assert P.nparts == 90000
+    assert np.array_equal(P.matrix, oracle.partition_from_values(M).matrix)
+    Z = np.zeros((17, 17))
+    P = pkg.Partition.from_matrix(Z, ctx=gpu_ctx)
+    assert P.nparts == 0 and not P.matrix.any()
+
+
+def test_integer_ctor_and_counts(pkg, oracle, gpu_ctx):
+    # test/runtests.jl:13-20
+    rng = np.random.default_rng(5)
+    M = rng.integers(1, 11, size=(10, 10))
+    M[0, 0] = 0
+    P = pkg.Partition.from_matrix(M, ctx=gpu_ctx)
+    assert pkg.dim(P) == len(np.unique(M)) - 1
+    assert np.array_equal(P.matrix, oracle.partition_from_labels(M).matrix)
+    assert pkg.dim(pkg.Partition.from_matrix(M.astype(float), ctx=gpu_ctx)) == len(np.unique(M)) - 1
+
+
+def test_refine_triple_and_random(pkg, oracle, gpu_ctx):
+    # test/runtests.jl:22-25
+    P1 = pkg.Partition.from_matrix(np.array([[1, 2, 2], [2, 3, 3], [2, 3, 3]]), ctx=gpu_ctx)
+    P2 = pkg.Partition.from_matrix(np.array([[1, 1, 2], [1, 1, 2], [1, 1, 3]]), ctx=gpu_ctx)
+    P3 = pkg.refine(P1, P2, ctx=gpu_ctx)
+    assert P3.nparts == 6
+    assert np.array_equal(P3.matrix, np.array([[1, 2, 4], [2, 3, 5], [2, 3, 6]]))
+    rng = np.random.default_rng(7)
+    for n, k1, k2 in [(50, 5, 7), (200, 40, 3), (333, 1000, 1000)]:
+        A = rng.integers(0, k1, size=(n, n))
+        B = rng.integers(0, k2, size=(n, n))
+        Pa = pkg.Partition.from_matrix(A, ctx=gpu_ctx)
+        Pb = pkg.Partition.from_matrix(B, ctx=gpu_ctx)
+        ref = oracle.refine(oracle.partition_from_labels(A), oracle.partition_from_labels(B))
+        got = pkg.refine(Pa, Pb, ctx=gpu_ctx)
+        assert got.nparts == ref.nparts
+        assert np.array_equal(got.matrix, ref.matrix)
+
+
+def test_fill_and_randomize_roundtrip(pkg, oracle, gpu_ctx):
+    rng = np.random.default_rng(2)
+    A = rng.integers(0, 12, size=(40, 40))
+    P = pkg.Partition.from_matrix(A, ctx=gpu_ctx)
+    vals = rng.random(P.nparts)
+    M = pkg.fill(P, vals, ctx=gpu_ctx)
+    assert np.array_equal(M, oracle.fill(oracle.Partition(P.nparts, P.matrix.astype(np.int64)), vals))
+    with pytest.raises(ValueError):
+        pkg.fill(P, vals[:-1], ctx=gpu_ctx)
+    # test/runtests.jl:27: part(rndPart(P1)) == P1
+    R = pkg.randomize(P, ctx=gpu_ctx)
+    assert ((R >= 0) & (R < 1)).all() and (R[P.matrix == 0] == 0).all()
+    assert pkg.Partition.from_matrix(R, ctx=gpu_ctx) == P
+
+
+def test_clamp_round_and_projection(pkg, oracle, gpu_ctx):
+    lib = pkg.load_library()
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.standard_normal(5000) * 10.0 ** rng.integers(-12, 6, 5000), [0.0625, 1e-10, -1e-9, 0.0]])
+    got = a.copy()
+    gpu_ctx.check(lib.sdpsr_clamp_round(gpu_ctx._h, got.size, C.c_void_p(got.ctypes.data), 1.4901161193847656e-8, 0))
+    ref = oracle.clamp_round(a)
+    assert np.array_equal(got, ref)  # same arithmetic: bit-exact
+    # x .-= projL(x): nothing left in the row space of A (test/runtests.jl:29-37 analogue)
+    n2, r = 4096, 5
+    A = rng.standard_normal((r, n2))
+    U = oracle.rowspace_basis(A)
+    x = rng.standard_normal(n2)
+    y = x.copy()
+    Uf = np.asfortranarray(U)
+    gpu_ctx.check(lib.sdpsr_project_out(gpu_ctx._h, n2, C.c_void_p(y.ctypes.data), C.c_void_p(Uf.ctypes.data), r, 0))
+    assert np.allclose(y, x - oracle.project_colspace(x, U), atol=1e-12)
+    assert np.abs(A @ y).max() < 1e-10
+
+
+# ------------------------------------------------------------------ the square
+@pytest.mark.parametrize("n", [1, 10, 57, 128, 200, 384])
+def test_square_i8_exact(pkg, gpu_ctx, n):
+    lib = pkg.load_library()
+    rng = np.random.default_rng(n)
+    X = rng.integers(-128, 128, size=(n, n)).astype(np.int8)
+    X = np.triu(X) + np.triu(X, 1).T  # symmetric
+    X = X.astype(np.int8)
+    out = np.zeros(n * n, dtype=np.int32)
+    Xf = _fl(X, np.int8)
+    gpu_ctx.check(lib.sdpsr_square_i8(gpu_ctx._h, n, C.c_void_p(Xf.ctypes.data), C.c_void_p(out.ctypes.data), 0))
+    ref = X.astype(np.int64) @ X.astype(np.int64)
+    assert np.array_equal(out.reshape(n, n, order="F"), ref)
+
+
+@pytest.mark.parametrize("n", [7, 130, 256])
+def test_square_f32_exact_on_small_integers(pkg, gpu_ctx, n):
+    lib = pkg.load_library()
+    rng = np.random.default_rng(n)
+    vmax = int(np.floor(np.sqrt(2 ** 24 / n)))
+    vmax = min(vmax, 127)
+    X = rng.integers(-vmax, vmax + 1, size=(n, n))
+    X = np.triu(X) + np.triu(X, 1).T
+    out = np.zeros(n * n, dtype=np.float32)
+    Xf = _fl(X, np.float32)
+    gpu_ctx.check(lib.sdpsr_square_f32(gpu_ctx._h, n, C.c_void_p(Xf.ctypes.data), C.c_void_p(out.ctypes.data), 0))
+    assert np.array_equal(out.reshape(n, n, order="F").astype(np.int64), X @ X)
+
+
+@pytest.mark.parametrize("n", [5, 129, 300])
+def test_square_f64_and_gemm_tn(pkg, gpu_ctx, n):
+    lib = pkg.load_library()
+    rng = np.random.default_rng(n)
+    X = rng.random((n, n))
+    X = (X + X.T) / 2
+    out = np.zeros(n * n)
+    Xf = _fl(X, np.float64)
+    gpu_ctx.check(lib.sdpsr_square_f64(gpu_ctx._h, n, C.c_void_p(Xf.ctypes.data), C.c_void_p(out.ctypes.data), 0))
+    ref = X @ X
+    # fp64 MFMA vs OpenBLAS: summation order differs; 1e-13 relative to |X||X|
+    assert np.abs(out.reshape(n, n, order="F") - ref).max() <= 1e-13 * n
+    # general C = A' B with an asymmetric B (catches a transposed C write)
+    m, nn, k = n, max(1, n // 2 + 3), n + 11
+    A = np.asfortranarray(rng.standard_normal((k, m)))
+    B = np.asfortranarray(rng.standard_normal((k, nn)))
+    Cc = np.zeros((m, nn), order="F")
+    gpu_ctx.check(lib.sdpsr_gemm_tn_f64(gpu_ctx._h, m, nn, k, C.c_void_p(A.ctypes.data), k, C.c_void_p(B.ctypes.data), k,
+                                        C.c_void_p(Cc.ctypes.data), m, 0))
+    assert np.abs(Cc - A.T @ B).max() <= 1e-12 * k
+
+
+def test_syev_matches_lapack(pkg, gpu_ctx):
+    lib = pkg.load_library()
+    rng = np.random.default_rng(1)
+    for n in (3, 64, 200):
+        A = rng.standard_normal((n, n))
+        A = np.asfortranarray((A + A.T) / 2)
+        w = np.zeros(n)
+        V = np.zeros((n, n), order="F")
+        gpu_ctx.check(lib.sdpsr_syev_f64(gpu_ctx._h, n, C.c_void_p(A.ctypes.data), C.c_void_p(w.ctypes.data), C.c_void_p(V.ctypes.data), 0))
+        assert np.allclose(w, np.linalg.eigvalsh(A), rtol=1e-10, atol=1e-10)
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-10
+        assert np.abs(A @ V - V * w).max() < 1e-9
+
+
+# ------------------------------------------------------------------ the whole path
+def _problem(problems, name):
+    if name == "petersen":
+        return problems.theta_prime_problem(problems.petersen_adjacency())
+    if name.startswith("er"):
+        return problems.theta_prime_problem(problems.er_graph_adjacency(int(name[2:])))
+    if name == "esc16j":
+        fa, fb = problems.read_qapdata(ROOT / "tests" / "golden" / "esc16j.dat")
+        return problems.qap_problem(fa, fb)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("mode", ["i8", "f32", "f64"])
+@pytest.mark.parametrize("name", ["petersen", "er3", "er5", "er7", "esc16j"])
+def test_admissible_subspace_matches_golden(pkg, problems, golden, name, mode):
+    sq = {"i8": pkg.SQUARE_I8, "f32": pkg.SQUARE_F32, "f64": pkg.SQUARE_F64}[mode]
+    Cv, A, b = _problem(problems, name)
+    setup = pkg.admissible_setup(Cv, A, b)
+    for seed in (1, 2):
+        with pkg.Context(seed=seed, square_mode=sq) as ctx:
+            P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)
+            assert P.nparts == int(golden[f"{name}_P"].max())
+            assert np.array_equal(P.matrix, golden[f"{name}_P"]), (name, mode, seed)
+
+
+@pytest.mark.parametrize("name,eps", [("petersen", None), ("er3", None), ("er5", None), ("er7", None),
+                                      ("esc16j", None), ("numerical_issues", 1e-7), ("circ64", None), ("circ256", None)])
+def test_block_diagonalize_matches_pins(pkg, oracle, golden, gpu_ctx, name, eps):
+    L = golden[f"{name}_P"]
+    P = pkg.Partition(int(L.max()), L.copy())
+    kw = {} if eps is None else {"epsilon": eps}
+    bd = pkg.blockDiagonalize(P, ctx=gpu_ctx, **kw)
+    assert sorted(bd.blkSizes) == list(golden[f"{name}_blk"])
+    # spectrum invariant: block eigenvalues within 1e-6 rel
+    x = np.random.default_rng(8).random(P.nparts)
+    Po = oracle.Partition(P.nparts, L.astype(np.int64))
+    full, blk = oracle.spectrum_invariant(Po, bd.blks, x)
+    assert len(full) == len(blk)
+    assert np.allclose(full, blk, rtol=1e-6, atol=1e-8)
+    # blks are exactly Q_k' 1[P==i] Q_k of the returned Q_hat
+    ref = oracle.basis_image([np.asarray(q) for q in bd.Q_hat], Po)
+    for i in range(P.nparts):
+        for k in range(len(bd.blkSizes)):
+            assert np.allclose(bd.blks[i][k], ref[i][k], atol=1e-10)
+
+
+def test_cyclic_c3_raises_invalid_field(pkg, gpu_ctx):
+    # test/runtests.jl:50-56
+    C3 = np.array([[1, 3, 2], [2, 1, 3], [3, 2, 1]])
+    P = pkg.Partition.from_matrix(C3, ctx=gpu_ctx)
+    with pytest.raises(pkg.InvalidDecompositionField):
+        pkg.blockDiagonalize(P, ctx=gpu_ctx)
+
+
+def test_numerical_issues_never_throws(pkg, golden, gpu_ctx):
+    # test/numerical_issues.jl:91-94 (10 000 runs on the CPU there; 300 launches here)
+    L = golden["numerical_issues_P"]
+    P = pkg.Partition(1312, L.copy())
+    for _ in range(300):
+        ne, nc = pkg.eigen_decomposition(P, atol=1e-7, ctx=gpu_ctx)
+        assert nc == 2
+
+
+def test_generic_graph_reaches_maximal_dimension(pkg, problems, oracle):
+    # BASELINE.json configs[1] at a size the oracle finishes in seconds: trivial symmetry
+    n = 96
+    Cv, A, b = problems.theta_prime_problem(problems.gnp_adjacency(n, 0.5, seed=3))
+    ref = oracle.admissible_subspace(Cv, A, b, rng=np.random.default_rng(0))
+    with pkg.Context(seed=5) as ctx:
+        P = pkg.admissible_subspace(Cv, A, b, ctx=ctx)
+    assert ref.nparts == (n * n + n) // 2 == P.nparts
+    assert np.array_equal(P.matrix, ref.matrix)
+
+
+def test_synthetic_scheme_fixed_point_and_idempotence(pkg, problems):
+    n = 512
+    Ls, d = problems.synthetic_jordan_partition(n, seed=1)
+    Cv, A, b = problems.partition_as_sdp(Ls, seed=1)
+    with pkg.Context(seed=9) as ctx:
+        P = pkg.admissible_subspace(Cv, A, b, ctx=ctx)
+        assert P.nparts == d and np.array_equal(P.matrix, Ls)
+        # idempotence: feeding the result back changes nothing
+        Cv2, A2, b2 = problems.partition_as_sdp(P.matrix.astype(np.int64), seed=2)
+        P2 = pkg.admissible_subspace(Cv2, A2, b2, ctx=ctx)
+        assert np.array_equal(P2.matrix, P.matrix)
+        bd = pkg.blockDiagonalize(P, ctx=ctx)
+        assert sorted(bd.blkSizes) == [1] * d
+
+
+def test_dense_convenience_entry(pkg, problems, golden, gpu_ctx):
+    lib = pkg.load_library()
+    Cv, A, b = _problem(problems, "er5")
+    n = 31
+    m = A.shape[0]
+    Af = np.asfortranarray(A)
+    P = np.zeros(n * n, dtype=np.uint32)
+    d = C.c_int64(0)
+    it = C.c_int32(0)
+    gpu_ctx.check(lib.sdpsr_admissible_subspace_dense(gpu_ctx._h, n, m, C.c_void_p(Cv.ctypes.data), C.c_void_p(Af.ctypes.data),
+                                                      C.c_void_p(b.ctypes.data), 1.4901161193847656e-8, C.c_void_p(P.ctypes.data),
+                                                      C.byref(d), C.byref(it), None, 0))
+    assert d.value == 15
+    assert np.array_equal(P.reshape(n, n, order="F"), golden["er5_P"])
