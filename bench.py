@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- reductions/s of the Jordan-reduction hot path on MI355X.
+
+One "step" = one reduction = admissible_subspace (device loop) + blockDiagonalize
+(eigen_decomposition + irreducible_decomposition + basis_image) of BASELINE.json
+configs[3]: a synthetic Jordan algebra of order N = 4096 with 34 basis matrices (symmetric
+circulant scheme on Z_32 (x) {I, J-I} on 128 points, conjugated by a seeded permutation),
+wrapped as an SDP.  Inputs (C_L, X0_L, U) are resident in HBM before the timed region; the
+host-side setup stage (src/partitions.jl:117-142) is outside the hot path.
+
+N ranks (one per GPU): every rank runs an independent random restart of the same reduction
+(its own seed), the ranks agree on the partition with allreduce(MIN)/allreduce(MAX) over the
+label matrix (RCCL), then each rank block-diagonalises.  value = restarts finished by all
+ranks per second ("weak": per-GPU work is fixed).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+FP64_MFMA_PEAK_TF = 78.6    # public MI355X spec (fp64 matrix); not in the local guide
+I8_MFMA_PEAK_TOPS = 5000.0  # ~2x bf16 dense (MI355X_MICROARCH.md matrix-core table)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(pr, n_sample, seed):
+    """The CPU oracle (NumPy/SciPy restatement, NOT Julia) timed on a bounded sample: one full
+    reduction of the same generator at order n_sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sdpsr_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    Ls, d = pr.synthetic_jordan_partition(n_sample, seed=seed)
+    Cv, A, b = pr.partition_as_sdp(Ls, seed=1)
+    setup = O.admissible_setup(Cv, A, b)
+    t0 = time.perf_counter()
+    P = O.admissible_subspace(Cv, A, b, rng=np.random.default_rng(0), setup=setup)
+    t1 = time.perf_counter()
+    sizes, blks, _ = O.block_diagonalize(P, rng=np.random.default_rng(1))
+    t2 = time.perf_counter()
+    assert np.array_equal(P.matrix, Ls)
+    return {"adm_s": t1 - t0, "bd_s": t2 - t1, "threads": thr, "n": n_sample, "dim": int(d)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--mode", default="i8", choices=["i8", "f32", "f64"])
+    ap.add_argument("--cpu-n", type=int, default=2048, help="order of the bounded CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    pr = pkg.problems
+    L = pkg._lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    n = args.n
+    Ls, d = pr.synthetic_jordan_partition(n, seed=1)
+    Cv, A, b = pr.partition_as_sdp(Ls, seed=1)
+    n_, CL, X0L, U = pkg.admissible_setup(Cv, A, b)
+    r = U.shape[1]
+    tCL = torch.from_numpy(CL).to(dev)
+    tX0 = torch.from_numpy(X0L).to(dev)
+    tU = torch.from_numpy(np.ascontiguousarray(U.T)).to(dev) if r else None  # (r, n^2) rows = columns of U
+    tP = torch.empty(n * n, dtype=torch.int32, device=dev)
+    golden = torch.from_numpy(np.ascontiguousarray(Ls.ravel(order="F")).astype(np.int32)).to(dev)
+    mode = {"i8": L.SQUARE_I8, "f32": L.SQUARE_F32, "f64": L.SQUARE_F64}[args.mode]
+    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode)
+    lib = ctx._lib
+    atol = 1.4901161193847656e-08
+    blk_buf = {}
+    phase = np.zeros(L.T_COUNT)
+    iters_total = 0
+
+    def vp(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def one_step(check=False):
+        nonlocal iters_total
+        dd = C.c_int64(0)
+        it = C.c_int32(0)
+        ms = (C.c_double * L.T_COUNT)()
+        ctx.check(lib.sdpsr_admissible_subspace(ctx._h, n, vp(tCL), vp(tX0), vp(tU), r, atol, vp(tP), C.byref(dd),
+                                                C.byref(it), C.cast(ms, C.c_void_p), L.MEM_DEVICE))
+        iters_total += it.value
+        for i in range(L.T_COUNT):
+            phase[i] += ms[i]
+        if world > 1:  # agree the partition across restarts (canonical labels: equal w.p. 1)
+            lo = tP.clone()
+            hi = tP.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if check and not bool((lo == hi).all()):
+                raise RuntimeError("ranks disagree on the partition")
+        if check:
+            assert dd.value == d and bool((tP == golden).all()), "partition differs from the generator's closure"
+        nb = C.c_int32(0)
+        ssq = C.c_int64(0)
+        ss = C.c_int64(0)
+        ms1 = (C.c_double * L.T_COUNT)()
+        ctx.check(lib.sdpsr_block_diagonalize(ctx._h, n, vp(tP), dd.value, atol, C.byref(nb), C.byref(ssq), C.byref(ss),
+                                              C.cast(ms1, C.c_void_p), L.MEM_DEVICE))
+        key = (dd.value, ssq.value)
+        if key not in blk_buf:
+            blk_buf[key] = torch.empty(max(1, dd.value * ssq.value), dtype=torch.float64, device=dev)
+        ms2 = (C.c_double * L.T_COUNT)()
+        ctx.check(lib.sdpsr_block_images(ctx._h, vp(blk_buf[key]), None, C.cast(ms2, C.c_void_p), L.MEM_DEVICE))
+        for i in range(1, L.T_COUNT):
+            phase[i] += ms1[i] + ms2[i]
+        if check:
+            assert nb.value == d, (nb.value, d)  # commutative scheme: d blocks of size 1
+        return nb.value
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(check=True)
+    phase[:] = 0
+    iters_total = 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    one_step(check=True)  # results still correct after the timed region
+
+    # ---- roofline leg: per-launch duration of the hot kernels, HIP events on ctx's stream ----
+    def prof(kind, nn, aux=0, reps=10):
+        v = C.c_double(0)
+        ctx.check(lib.sdpsr_profile_kernel(ctx._h, kind, nn, aux, reps, C.byref(v)))
+        return v.value
+
+    kernels = {}
+    roof = None
+    cpu = None
+    if rank == 0:
+        flops = 2.0 * n ** 3
+        for name, kind, peak, unit in (("square_i8", 0, I8_MFMA_PEAK_TOPS, "TOP/s"), ("square_f32", 1, FP32_MFMA_PEAK_TF, "TFLOP/s"),
+                                       ("gemm_f64", 2, FP64_MFMA_PEAK_TF, "TFLOP/s")):
+            ms = prof(kind, n)
+            ach = flops / (ms * 1e-3) / 1e12
+            kernels[name] = {"ms": round(ms, 4), "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                             "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4)}
+        ms = prof(3, n, aux=d, reps=5)  # refine: 16 B per entry algorithmic (8 value + 4 old + 4 new label)
+        gbs = 16.0 * n * n / (ms * 1e-3) / 1e9
+        kernels["refine"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        ms = prof(4, n, aux=max(r, 1), reps=5)  # gather+project+signature: (4 + 8r)*2 read + 8 write per entry
+        gbs = ((4.0 + 8.0 * max(r, 1)) * 2 + 8.0) * n * n / (ms * 1e-3) / 1e9
+        kernels["project_sig"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        # the hand-written kernel that takes the most time inside one reduction
+        k64 = kernels["gemm_f64"]
+        roof = {"kernel": "gemm_tn_kernel<f64> (Q'AQ, 2 launches per reduction)", "bound": "mfma", "achieved": k64["achieved"],
+                "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": k64["frac"], "traffic": None,
+                "algorithmic": "2*N^3 flop per launch"}
+        if args.cpu_n > 0:
+            cb = cpu_baseline(pr, args.cpu_n, seed=1)
+            scale = (n / cb["n"]) ** 3
+            est = (cb["adm_s"] + cb["bd_s"]) * scale
+            cpu = {"value": round(1.0 / est, 6), "unit": "reductions/s", "cores": cb["threads"], "kind": "port",
+                   "sample": f"one full oracle reduction (NumPy/SciPy restatement, not Julia) at N={cb['n']}, dim {cb['dim']}: "
+                             f"admissible_subspace {cb['adm_s']:.2f} s + blockDiagonalize {cb['bd_s']:.2f} s measured; "
+                             f"value extrapolated to N={n} by (N/{cb['n']})^3 = {scale:.0f}x"}
+    total_red = args.steps * world
+    if rank == 0:
+        out = {
+            "metric": "N x N SDP reductions/sec (admissible_subspace+blockDiagonalize) at N=4096",
+            "value": round(total_red / dt, 4), "unit": "reductions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"i8": "int8 square (int32 acc) + f64 eigen", "f32": "f32 square + f64 eigen", "f64": "f64"}[args.mode],
+            "data": "synthetic",
+            "config": {"workload": f"configs[3]: synthetic Jordan algebra N={n}, {d} basis matrices (circulant Z_32 (x) K_128 scheme, seeded permutation), "
+                                   f"square_mode={args.mode}, 4 channels", "N": n, "dim": int(d), "restarts_per_step": world,
+                       "iterations_per_reduction": iters_total / max(1, args.steps)},
+            "phase_ms_per_step": {k: round(phase[i] / args.steps, 3) for k, i in
+                                  (("project", L.T_PROJECT), ("square", L.T_SQUARE), ("refine", L.T_REFINE), ("eigen", L.T_EIGEN),
+                                   ("iso_QtAQ", L.T_ISO), ("irreducible", L.T_IRRED), ("basis_image", L.T_IMAGE))},
+            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -189,6 +189,16 @@ int sdpsr_eigen_decomposition(sdpsr_ctx* ctx, int64_t n, const uint32_t* P, int6
 int sdpsr_syev_f64(sdpsr_ctx* ctx, int64_t n, const double* A, double* values, double* vectors,
                    int mem);
 
+/* ---- measurement hook (bench.py roofline leg) --------------------------------- */
+/* Times `reps` back-to-back launches of one hot kernel on ctx's stream with HIP events, on
+   resident synthetic data of order n (n is rounded up to the kernel's tile).  kind:
+   0 = square int8 MFMA (one channel), 1 = square fp32 MFMA, 2 = square / Q'AQ fp64 MFMA,
+   3 = partition refine of n*n signatures with `aux` distinct classes,
+   4 = fused gather+projection+signature pass with r = aux basis vectors.
+   ms_per_launch[0] = average milliseconds per launch. */
+int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps,
+                         double* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1229,3 +1229,89 @@ int sdpsr_syev_f64(sdpsr_ctx* c, int64_t n, const double* A, double* values, dou
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// measurement hook
+// ---------------------------------------------------------------------------
+namespace sdpsr {
+void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t* sig);
+}
+
+extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t aux, int reps,
+                                    double* ms_per_launch) {
+    CHECK_CTX(c);
+    if (!ms_per_launch || n < 1 || reps < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    hipStream_t s = c->stream;
+    const int64_t ld = round_up(n, 128);
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    int st = SDPSR_OK;
+    if (kind >= 0 && kind <= 2) {
+        const size_t es = kind == 0 ? 1 : (kind == 1 ? 4 : 8);
+        const size_t os = kind == 0 ? 4 : es;
+        void* X = ctx_buf(c, "prof_x", (size_t)ld * ld * es);
+        void* Cc = ctx_buf(c, "prof_c", (size_t)ld * ld * os);
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)ld * ld * 4);
+        if (!X || !Cc || !Lb) return SDPSR_OUT_OF_MEMORY;
+        // random symmetric operand with full-range values (not zeros: clocks differ on zeros)
+        HIP_TRY(c, hipMemsetAsync(Lb, 0, (size_t)ld * ld * 4, s));
+        launch_fill_test_sig(s, ld * ld / 2, 1 << 20, (uint64_t*)Lb);  // pseudo-random labels
+        if (kind == 0) launch_gather_i8(s, ld, ld, 1, Lb, 12345, (int8_t*)X);
+        else if (kind == 1) launch_gather_f32(s, ld, ld, 1, 45, Lb, 12345, (float*)X);
+        else launch_gather_f64_padded(s, ld, ld, Lb, 12345, (double*)X);
+        auto run = [&]() {
+            if (kind == 0) launch_gemm_tn_i8(s, ld, ld, ld, (int8_t*)X, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, 1, 0, 0, 0);
+            else if (kind == 1) launch_gemm_tn_f32(s, ld, ld, ld, (float*)X, ld, (float*)X, ld, (float*)Cc, ld, 1, 0, 0, 0);
+            else launch_gemm_tn_f64(s, ld, ld, ld, (double*)X, ld, (double*)X, ld, (double*)Cc, ld, 1, 0, 0, 0);
+        };
+        run();
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) run();
+        HIP_TRY(c, hipEventRecord(e1, s));
+    } else if (kind == 3) {
+        const int64_t len = n * n;
+        uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)len * 4);
+        if (!sig || !Lb) return SDPSR_OUT_OF_MEMORY;
+        launch_fill_test_sig(s, len, std::max<int64_t>(aux, 1), sig);
+        int64_t np = 0;
+        st = refine_signatures(c, len, sig, Lb, &np);  // warm-up + table sizing
+        if (st) return st;
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) {
+            st = refine_signatures(c, len, sig, Lb, &np);
+            if (st) return st;
+        }
+        HIP_TRY(c, hipEventRecord(e1, s));
+    } else if (kind == 4) {
+        const int64_t len = n * n, r = std::max<int64_t>(aux, 0);
+        uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)len * 4);
+        double* U = (double*)ctx_buf(c, "prof_u", (size_t)len * std::max<int64_t>(r, 1) * 8);
+        double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * 512 * 8);
+        double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
+        if (!sig || !Lb || !U || !partial || !coef) return SDPSR_OUT_OF_MEMORY;
+        HIP_TRY(c, hipMemsetAsync(Lb, 0, (size_t)len * 4, s));
+        launch_fill_test_sig(s, len / 2, 1000, (uint64_t*)Lb);
+        HIP_TRY(c, hipMemsetAsync(U, 0, (size_t)len * std::max<int64_t>(r, 1) * 8, s));
+        auto run = [&]() {
+            launch_proj_coef(s, len, r, U, Lb, 777, nullptr, partial, 512, coef);
+            launch_proj_apply(s, len, r, U, Lb, 777, nullptr, coef, 1.5e-8, 1e7, 1, nullptr, sig);
+        };
+        run();
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) run();
+        HIP_TRY(c, hipEventRecord(e1, s));
+    } else {
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "unknown kernel kind");
+    }
+    HIP_TRY(c, hipEventSynchronize(e1));
+    HIP_TRY(c, hipGetLastError());
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    ms_per_launch[0] = (double)ms / reps;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return SDPSR_OK;
+}

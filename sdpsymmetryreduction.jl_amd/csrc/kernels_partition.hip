@@ -633,4 +633,16 @@ void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_
     check_symmetric_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, L, flag);
 }
 
+// synthetic signatures with `nclasses` distinct non-zero values (measurement hook)
+__global__ void fill_test_sig_kernel(int64_t len, int64_t nclasses, uint64_t* __restrict__ sig) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        uint64_t cls = sdpsr_fmix64((uint64_t)e * 0x9E3779B97F4A7C15ULL + 17) % (uint64_t)nclasses;
+        sig[e] = sdpsr_fmix64(cls + 1) | 1ull;
+    }
+}
+void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t* sig) {
+    fill_test_sig_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, nclasses, sig);
+}
+
 }  // namespace sdpsr
