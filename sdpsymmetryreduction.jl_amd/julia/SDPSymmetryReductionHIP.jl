@@ -1,0 +1,136 @@
+# SDPSymmetryReductionHIP.jl -- Julia-side binding of libsdpsr_hip.so (include/sdpsr.h).
+#
+# WRITTEN BLIND: there is no Julia toolchain in the build image, so this file has never been
+# executed.  It shows the binding a maintainer of SDPSymmetryReduction.jl would add: a new
+# `AbstractPartition` backend whose whole-function specialisations are one `ccall` each
+# (the generic functions call `mul!`/`eigen` on plain matrices, so the backend specialises
+# `admissible_subspace(::Type{HIPPartition}, ...)`, `diagonalize(::Type{Float64}, ::HIPPartition)`
+# and `basis_image(Q, ::HIPPartition)`, exactly where test/partitions_set.jl plugs in its
+# `Partition{BitSet}`).
+module SDPSymmetryReductionHIP
+
+import SDPSymmetryReduction as SR
+using LinearAlgebra, SparseArrays
+
+const libsdpsr = get(ENV, "SDPSR_HIP_LIB", "libsdpsr_hip.so")
+const MEM_HOST = Cint(0)
+
+struct StatusError <: Exception
+    code::Cint
+    msg::String
+end
+
+mutable struct Context
+    handle::Ptr{Cvoid}
+    function Context(; device::Integer=0, seed::Integer=rand(UInt64))
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        st = ccall((:sdpsr_create, libsdpsr), Cint, (Cint, UInt64, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                   device, seed % UInt64, C_NULL, h)
+        st == 0 || throw(StatusError(st, "sdpsr_create"))
+        ctx = new(h[])
+        finalizer(c -> ccall((:sdpsr_destroy, libsdpsr), Cvoid, (Ptr{Cvoid},), c.handle), ctx)
+        return ctx
+    end
+end
+
+const DEFAULT_CTX = Ref{Union{Nothing,Context}}(nothing)
+ctx() = (DEFAULT_CTX[] === nothing && (DEFAULT_CTX[] = Context()); DEFAULT_CTX[])
+
+function check(c::Context, st::Cint)
+    st == 0 && return
+    msg = unsafe_string(ccall((:sdpsr_last_error, libsdpsr), Cstring, (Ptr{Cvoid},), c.handle))
+    st == 1 && throw(SR.InvalidDecompositionField(Float64, ComplexF64))   # eigen_decomposition.jl:140
+    st == 2 && throw(SR.NumericalInconsistency("eigen_decomposition", msg)) # :152
+    st == 3 && throw(DimensionMismatch(msg))                               # diagonalize.jl:6
+    st == 4 && throw(InexactError(:refine!, UInt32, 0))                    # partitions.jl:63
+    throw(StatusError(st, msg))
+end
+
+# ---- the partition backend (AbstractPartition contract, abstract_part.jl:7-16) ----------
+mutable struct HIPPartition <: SR.AbstractPartition
+    nparts::Int
+    matrix::Matrix{UInt32}
+end
+SR.dim(p::HIPPartition) = p.nparts
+Base.size(p::HIPPartition, args...) = size(p.matrix, args...)
+Base.:(==)(p::HIPPartition, q::HIPPartition) = p.nparts == q.nparts && p.matrix == q.matrix
+
+function HIPPartition(M::AbstractMatrix{<:AbstractFloat})               # partitions.jl:24-35
+    Md = Matrix{Float64}(M); out = Matrix{UInt32}(undef, size(M)); n = Ref{Int64}(0)
+    c = ctx()
+    check(c, ccall((:sdpsr_partition_from_f64, libsdpsr), Cint,
+                   (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{UInt32}, Ref{Int64}, Cint),
+                   c.handle, length(Md), Md, out, n, MEM_HOST))
+    return HIPPartition(n[], out)
+end
+function HIPPartition(M::AbstractMatrix{<:Integer})                      # partitions.jl:37-60
+    Mi = Matrix{UInt32}(M); out = similar(Mi); n = Ref{Int64}(0)
+    c = ctx()
+    check(c, ccall((:sdpsr_partition_from_u32, libsdpsr), Cint,
+                   (Ptr{Cvoid}, Int64, Ptr{UInt32}, Ptr{UInt32}, Ref{Int64}, Cint),
+                   c.handle, length(Mi), Mi, out, n, MEM_HOST))
+    return HIPPartition(n[], out)
+end
+function SR.refine!(p::HIPPartition, q::HIPPartition)                   # partitions.jl:62-66
+    d = Ref{Int64}(p.nparts); c = ctx()
+    check(c, ccall((:sdpsr_refine, libsdpsr), Cint,
+                   (Ptr{Cvoid}, Int64, Ptr{UInt32}, Ref{Int64}, Ptr{UInt32}, Int64, Cint),
+                   c.handle, length(p.matrix), p.matrix, d, q.matrix, q.nparts, MEM_HOST))
+    p.nparts = d[]
+    return p
+end
+function Base.fill!(M::AbstractMatrix{Float64}, p::HIPPartition; values::AbstractVector) # :68-75
+    @assert length(values) == SR.dim(p)
+    v = Vector{Float64}(values); c = ctx()
+    check(c, ccall((:sdpsr_fill, libsdpsr), Cint,
+                   (Ptr{Cvoid}, Int64, Ptr{UInt32}, Ptr{Float64}, Int64, Ptr{Float64}, Cint),
+                   c.handle, length(p.matrix), p.matrix, v, length(v), M, MEM_HOST))
+    return M
+end
+SR._constraints(p::HIPPartition) = SR._constraints(SR.Partition{UInt32}(p.nparts, p.matrix))
+
+# ---- admissible_subspace: setup on the host (partitions.jl:117-142), loop on the device ----
+function SR.admissible_subspace(::Type{HIPPartition}, C::AbstractVector{T}, A::AbstractMatrix{T},
+                                b::AbstractVector{T}; verbose::Bool=false,
+                                atol=Base.rtoldefault(real(T))) where {T<:AbstractFloat}
+    n = isqrt(length(C)); @assert n^2 == length(C)
+    A′ = A'; F = qr(A′)
+    U = Matrix(F.Q)[:, 1:rank(A)]                      # orthonormal basis of rowspace(A)
+    proj(v) = U * (U' * v)
+    c = Vector(C); c .-= proj(c); SR._clamp_round!(c, atol=atol); SR._symmetrize!(c, n)
+    x0, _ = SR.Krylov.craig(A, b); SR._symmetrize!(x0, n); x0 = proj(x0); SR._clamp_round!(x0, atol=atol)
+    P = Matrix{UInt32}(undef, n, n); d = Ref{Int64}(0); it = Ref{Int32}(0); cx = ctx()
+    check(cx, ccall((:sdpsr_admissible_subspace, libsdpsr), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Float64,
+                     Ptr{UInt32}, Ref{Int64}, Ref{Int32}, Ptr{Float64}, Cint),
+                    cx.handle, n, c, x0, U, size(U, 2), atol, P, d, it, C_NULL, MEM_HOST))
+    verbose && @info "Minimal admissible subspace converged in $(it[]) iterations at dimension:" final = d[]
+    return HIPPartition(d[], P)
+end
+
+# ---- blockDiagonalize(Float64, P) (compat.jl:46-68) -------------------------------------
+function SR.blockDiagonalize(::Type{Float64}, P::HIPPartition, verbose=true;
+                             epsilon=Base.rtoldefault(Float64))
+    n = size(P, 1); cx = ctx()
+    nb = Ref{Int32}(0); ssq = Ref{Int64}(0); ss = Ref{Int64}(0)
+    check(cx, ccall((:sdpsr_block_diagonalize, libsdpsr), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{UInt32}, Int64, Float64, Ref{Int32}, Ref{Int64}, Ref{Int64},
+                     Ptr{Float64}, Cint),
+                    cx.handle, n, P.matrix, P.nparts, epsilon, nb, ssq, ss, C_NULL, MEM_HOST))
+    sizes = Vector{Int32}(undef, nb[])
+    check(cx, ccall((:sdpsr_block_sizes, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{Int32}), cx.handle, sizes))
+    flat = Vector{Float64}(undef, P.nparts * ssq[])
+    check(cx, ccall((:sdpsr_block_images, libsdpsr), Cint,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint),
+                    cx.handle, flat, C_NULL, C_NULL, MEM_HOST))
+    blks = Vector{Vector{Matrix{Float64}}}(undef, P.nparts)
+    for i in 1:P.nparts
+        off = (i - 1) * ssq[]; blks[i] = Matrix{Float64}[]
+        for s in sizes
+            push!(blks[i], reshape(flat[off+1:off+s*s], Int(s), Int(s))); off += s * s
+        end
+    end
+    return (blkSizes=Int.(sizes), blks=blks)
+end
+
+end # module

@@ -1,0 +1,72 @@
+"""world_size-2 gloo tests (CPU) of the restart-agreement step used by bench.py --gpus N."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from sdpsr_amd import parallel as par  # noqa
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 24
+    Ls, d = pkg.problems.synthetic_jordan_partition(n, seed=3)
+    flat = torch.from_numpy(np.ascontiguousarray(Ls.ravel(order="F")).astype(np.int64))
+    # 1) equal canonical labels on every rank: agreement without a meet
+    ok, out = par.agree_partition(flat.clone(), par.relabel_numpy)
+    res = {"agree_equal": ok and bool((out == flat).all())}
+    # 2) rank 1 missed a split (merges classes 1 and 2): the meet restores the finer partition
+    mine = flat.clone()
+    if rank == 1:
+        mine[mine == 2] = 1
+        # keep it canonical like a real (coarser) result would be
+        mine, _ = par.relabel_numpy(mine)
+    ok2, meet = par.agree_partition(mine, par.relabel_numpy)
+    res["meet_is_finer"] = (not ok2) and bool((meet == flat).all())
+    # 3) zero class survives the hash combination
+    z = flat.clone()
+    z[:7] = 0
+    if rank == 1:
+        z[z == 3] = 4
+        z, _ = par.relabel_numpy(z)
+    else:
+        z, _ = par.relabel_numpy(z)
+    _, meet2 = par.agree_partition(z, par.relabel_numpy)
+    res["zero_kept"] = bool((meet2[:7] == 0).all()) and bool((meet2[7:] != 0).all())
+    res["seeds_differ"] = par.restart_seed(5, 0) != par.restart_seed(5, 1)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_agreement_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in got:
+        assert all(res.values()), (rank, res)
