@@ -1220,9 +1220,14 @@ int sdpsr_syev_f64(sdpsr_ctx* c, int64_t n, const double* A, double* values, dou
     double* dV = out_dev(c, "ev_vec", vectors, (size_t)n * n, mem, &st);
     double* dW = out_dev(c, "ev_val", values, (size_t)n, mem, &st);
     if (st) return st;
-    HIP_TRY(c, hipMemcpyAsync(dV, dA, (size_t)n * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    st = syev_device(c, n, dV, n, dW);
+    const int64_t ld = round_up(n, 128);
+    double* Ap = (double*)ctx_buf(c, "ev_pad", (size_t)ld * ld * 8);
+    if (!Ap) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemsetAsync(Ap, 0, (size_t)ld * ld * 8, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(Ap, ld * 8, dA, n * 8, n * 8, n, hipMemcpyDeviceToDevice, c->stream));
+    st = syev_device(c, n, Ap, ld, dW);
     if (st) return st;
+    HIP_TRY(c, hipMemcpy2DAsync(dV, n * 8, Ap, ld * 8, n * 8, n, hipMemcpyDeviceToDevice, c->stream));
     st = out_finish(c, vectors, dV, (size_t)n * n, mem);
     if (st) return st;
     return out_finish(c, values, dW, (size_t)n, mem);

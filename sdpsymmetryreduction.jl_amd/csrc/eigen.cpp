@@ -11,6 +11,10 @@
 
 namespace sdpsr {
 
+size_t sytrd_workspace_doubles(int64_t n, int64_t ld);
+void launch_sytrd(hipStream_t s, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau,
+                  double* ws);
+
 static int ensure_handle(sdpsr_ctx* c) {
     if (!c->rocblas) {
         rocblas_handle h = nullptr;
@@ -47,9 +51,17 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w) {
     } else {
         double* Z = (double*)ctx_buf(c, "eig_Z", (size_t)n * n * sizeof(double));
         if (!Z) return SDPSR_OUT_OF_MEMORY;
-        rs = rocsolver_dsytrd(h, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)lda, w, E, tau);
-        if (rs != rocblas_status_success)
-            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dsytrd status " + std::to_string(rs));
+        if (c->opts.eig_driver == 2 || (lda & 1)) {
+            rs = rocsolver_dsytrd(h, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)lda, w, E, tau);
+            if (rs != rocblas_status_success)
+                return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dsytrd status " + std::to_string(rs));
+        } else {
+            // hand-written tridiagonalisation (kernels_sytrd.hip); LAPACK-compatible output
+            double* ws = (double*)ctx_buf(c, "eig_sytrd_ws", sytrd_workspace_doubles(n, lda) * sizeof(double));
+            if (!ws) return SDPSR_OUT_OF_MEMORY;
+            launch_sytrd(c->stream, n, A, lda, w, E, tau, ws);
+            if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "sytrd launch failed");
+        }
         rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)n,
                               info);
         if (rs != rocblas_status_success)

@@ -1,0 +1,384 @@
+// Householder tridiagonalisation A = Q T Q' of the generic algebra element for gfx950
+// (first phase of eigen(A), src/eigen_decomposition.jl:246; LAPACK dsytrd/dlatrd, lower).
+//
+// Design (MI355X-first, not a translation of dlatrd's BLAS-2 call sequence):
+//  * the full symmetric trailing matrix is kept (both triangles), so the big product
+//    p = A v of every column is a set of contiguous column dots: one wave per column,
+//    16-byte loads, v staged once per workgroup in LDS, no atomics, no cross-workgroup
+//    reduction for p (bitwise reproducible);
+//  * two launches per column, both spread over the whole chip:
+//      form_kernel (j):   finish W(:, j-1) from the column dots (corrections with the panel
+//                         V, W; the v'Av term comes from per-workgroup partials), then form
+//                         the updated column a_j = A(:,j) - V W(j,:)' - W V(j,:)' and its
+//                         partial squared norms;
+//      symv_kernel (j):   every workgroup redundantly finishes the reflector scalars
+//                         (beta, tau, scale) from the partial norms, builds v in LDS and
+//                         computes its share of p = A v, W'v, V'v and v'p;
+//  * after NB columns the trailing matrix gets the rank-2NB update A -= V W' + W V' (both
+//    triangles) in one tiled kernel.
+// Output is LAPACK-compatible (d, e, tau, reflectors below the subdiagonal of A), so the
+// tridiagonal solve (rocSOLVER stedc) and the back-transformation (ormtr) plug in unchanged.
+#include "sdpsr_internal.h"
+
+namespace sdpsr {
+
+constexpr int SY_NB = 32;       // panel width
+constexpr int SY_THREADS = 256;
+
+struct SytrdArgs {
+    double* A;        // n x n, leading dimension ld (even), full symmetric on entry
+    int64_t ld;
+    int n;
+    double* Vp;       // ld x NB panel of reflectors (explicit, v[j+1] = 1)
+    double* Wp;       // ld x NB panel W
+    double* p0;       // n: A v
+    double* g1;       // NB: W' v
+    double* g2;       // NB: V' v
+    double* part_norm;  // per form-workgroup partial sum of a[r]^2, r >= j+2
+    double* part_vav;   // per symv-workgroup partial of v' (A v)
+    double* d;
+    double* e;
+    double* tau;
+};
+
+// ---------------------------------------------------------------------------
+// form_kernel: rows r in [j, n); a workgroup owns SY_FROWS = 64 rows, its 4 waves split the
+// panel columns (c = wave, wave + 4, ...) so that the 2 x cf strided panel reads of a row are
+// spread over four waves and issued in batches; partial sums meet in LDS.
+//   do_finish: column jf = j-1 (panel column cf) gets its W column.
+//   do_form:   column j is updated with the finished panel columns and its norm partials
+//              are produced.  n_vav = number of part_vav entries written by symv(jf).
+// ---------------------------------------------------------------------------
+constexpr int SY_FROWS = 64;
+
+__global__ void __launch_bounds__(SY_THREADS)
+sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_vav) {
+    __shared__ double s_g1[SY_NB], s_g2[SY_NB], s_wrow[SY_NB + 1], s_vrow[SY_NB + 1];
+    __shared__ double s_part[4][2][SY_FROWS];
+    __shared__ double s_scal[2];  // tau, alpha2
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, q = tid >> 6;
+    const int64_t ld = a.ld;
+    const int n = a.n;
+    const int jf = j - 1;
+
+    if (do_finish) {
+        if (tid < cf) {
+            s_g1[tid] = a.g1[tid];
+            s_g2[tid] = a.g2[tid];
+        }
+        if (q == 1) {  // wave 1: fixed-shape tree reductions (bitwise reproducible)
+            double vav = 0;
+            for (int b = lane; b < n_vav; b += 64) vav += a.part_vav[b];
+            double gg = (lane < cf) ? a.g1[lane] * a.g2[lane] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                vav += __shfl_down(vav, o, 64);
+                gg += __shfl_down(gg, o, 64);
+            }
+            if (lane == 0) {
+                const double tau = a.tau[jf];
+                const double dot = tau * (vav - 2.0 * gg);  // p'v with p = tau (A v - V g1 - W g2)
+                s_scal[0] = tau;
+                s_scal[1] = -0.5 * tau * dot;
+            }
+        }
+    }
+    if (do_form && tid < cf) {  // rows of the finished panel columns (before this launch)
+        s_wrow[tid] = a.Wp[j + (int64_t)tid * ld];
+        s_vrow[tid] = a.Vp[j + (int64_t)tid * ld];
+    }
+    __syncthreads();
+    if (do_finish && do_form && tid == 0) {
+        // row j of the W column that this launch finishes: needed by every row of the form part
+        double s = 0;
+        for (int c = 0; c < cf; ++c) s += s_vrow[c] * s_g1[c] + s_wrow[c] * s_g2[c];
+        const double vj = a.Vp[j + (int64_t)cf * ld];
+        s_wrow[cf] = s_scal[0] * (a.p0[j] - s) + s_scal[1] * vj;
+        s_vrow[cf] = vj;
+    }
+
+    const int r = j + blockIdx.x * SY_FROWS + lane;
+    double sf = 0, sm = 0;
+    if (r < n) {
+#pragma unroll 4
+        for (int c = q; c < cf; c += 4) {
+            const double v = a.Vp[r + (int64_t)c * ld];
+            const double w = a.Wp[r + (int64_t)c * ld];
+            if (do_finish) sf += v * s_g1[c] + w * s_g2[c];
+            if (do_form) sm += v * s_wrow[c] + w * s_vrow[c];
+        }
+    }
+    s_part[q][0][lane] = sf;
+    s_part[q][1][lane] = sm;
+    __syncthreads();
+    if (q != 0) return;
+    double sq = 0;
+    if (r < n) {
+        sf = s_part[0][0][lane] + s_part[1][0][lane] + s_part[2][0][lane] + s_part[3][0][lane];
+        sm = s_part[0][1][lane] + s_part[1][1][lane] + s_part[2][1][lane] + s_part[3][1][lane];
+        double wnew = 0, v = 0;
+        if (do_finish) {
+            v = a.Vp[r + (int64_t)cf * ld];
+            wnew = s_scal[0] * (a.p0[r] - sf) + s_scal[1] * v;
+            a.Wp[r + (int64_t)cf * ld] = wnew;
+            // LAPACK storage of the finished reflector: v below the subdiagonal of column jf
+            if (r >= jf + 2) a.A[r + (int64_t)jf * ld] = v;
+        }
+        if (do_form) {
+            double x = a.A[r + (int64_t)j * ld];
+            if (do_finish) sm += v * s_wrow[cf] + wnew * s_vrow[cf];
+            x -= sm;
+            a.A[r + (int64_t)j * ld] = x;
+            if (r == j) a.d[j] = x;
+            if (r >= j + 2) sq = x * x;
+        }
+    }
+    if (do_form) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+        if (lane == 0) a.part_norm[blockIdx.x] = sq;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// symv_kernel(j): reflector of column j (panel column cf), then column dots.
+//   work items: trailing columns k in [j+1, n) -> p0[k];  cf columns of Wp -> g1;  cf columns
+//   of Vp -> g2.  n_norm = number of part_norm entries written by form(j).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(SY_THREADS)
+sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm) {
+    extern __shared__ __attribute__((aligned(16))) double s_v[];  // rows r0 .. n (r0 even)
+    __shared__ double s_bcast[3];
+    __shared__ double s_red[SY_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t ld = a.ld;
+    const int n = a.n;
+    const int r0 = (j + 1) & ~1;  // even start so that 16-byte loads are aligned
+    const int len = n - r0;       // entries of s_v
+    if (wave == 0) {
+        double xn2 = 0;
+        for (int b = lane; b < n_norm; b += 64) xn2 += a.part_norm[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xn2 += __shfl_down(xn2, o, 64);
+      if (lane == 0) {
+        const double alpha = a.A[(j + 1) + (int64_t)j * ld];
+        double beta, tau, scale;
+        if (xn2 == 0.0) {  // dlarfg: H = I
+            tau = 0.0;
+            beta = alpha;
+            scale = 0.0;
+        } else {
+            beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        s_bcast[0] = beta;
+        s_bcast[1] = tau;
+        s_bcast[2] = scale;
+        if (blockIdx.x == 0) {
+            a.e[j] = beta;
+            a.tau[j] = tau;
+        }
+      }
+    }
+    __syncthreads();
+    const double scale = s_bcast[2];
+    for (int t = tid; t < len; t += SY_THREADS) {
+        const int r = r0 + t;
+        double v;
+        if (r <= j) v = 0.0;
+        else if (r == j + 1) v = 1.0;
+        else v = a.A[r + (int64_t)j * ld] * scale;
+        s_v[t] = v;
+        if (blockIdx.x == 0 && r > j) a.Vp[r + (int64_t)cf * ld] = v;
+    }
+    if ((len & 1) && tid == 0) s_v[len] = 0.0;  // pad for the double2 reads
+    __syncthreads();
+
+    const int ncols = n - (j + 1);
+    const int nwork = ncols + 2 * cf;
+    const int wpb = SY_THREADS / 64;
+    double vav = 0;
+    const int len2 = (len + 1) >> 1;  // double2 elements
+    const double2* sv2 = reinterpret_cast<const double2*>(s_v);
+    for (int w = blockIdx.x * wpb + wave; w < nwork; w += gridDim.x * wpb) {
+        const double* col;
+        if (w < ncols) col = a.A + (int64_t)(j + 1 + w) * ld;
+        else if (w < ncols + cf) col = a.Wp + (int64_t)(w - ncols) * ld;
+        else col = a.Vp + (int64_t)(w - ncols - cf) * ld;
+        const double2* c2 = reinterpret_cast<const double2*>(col + r0);
+        double acc0 = 0, acc1 = 0;
+        int t = lane;
+        for (; t + 64 < len2; t += 128) {  // two independent 16-byte loads in flight per lane
+            double2 x0 = c2[t], x1 = c2[t + 64];
+            double2 v0 = sv2[t], v1 = sv2[t + 64];
+            acc0 = fma(x0.x, v0.x, acc0);
+            acc0 = fma(x0.y, v0.y, acc0);
+            acc1 = fma(x1.x, v1.x, acc1);
+            acc1 = fma(x1.y, v1.y, acc1);
+        }
+        for (; t < len2; t += 64) {
+            double2 x0 = c2[t];
+            double2 v0 = sv2[t];
+            // the last double2 of an odd-length column may run one element past row n-1:
+            // rows are padded (ld >= n + 1 or the s_v pad is zero), see host wrapper
+            acc0 = fma(x0.x, v0.x, acc0);
+            acc0 = fma(x0.y, v0.y, acc0);
+        }
+        double acc = acc0 + acc1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) {
+            if (w < ncols) {
+                a.p0[j + 1 + w] = acc;
+                vav += acc * s_v[(j + 1 + w) - r0];
+            } else if (w < ncols + cf) {
+                a.g1[w - ncols] = acc;
+            } else {
+                a.g2[w - ncols - cf] = acc;
+            }
+        }
+    }
+    if (lane == 0) s_red[wave] = vav;
+    __syncthreads();
+    if (tid == 0) a.part_vav[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// ---------------------------------------------------------------------------
+// rank-2NB update of the trailing matrix (both triangles):
+//   A[r, s] -= sum_c V[r,c] W[s,c] + W[r,c] V[s,c],   r, s >= j1
+// 64 x 64 tile per workgroup, 4 x 4 outputs per thread, panels staged in LDS.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(SY_THREADS)
+sytrd_syr2k_kernel(SytrdArgs a, int j1, int cnt) {
+    constexpr int CH = 16;  // panel columns staged per pass (4 x 16 x 64 doubles = 32 KiB)
+    __shared__ double sVr[CH][64], sWr[CH][64], sVs[CH][64], sWs[CH][64];
+    const int tid = threadIdx.x;
+    const int64_t ld = a.ld;
+    const int n = a.n;
+    const int rb = j1 + blockIdx.x * 64, sb = j1 + blockIdx.y * 64;
+    const int tr = (tid & 15) * 4, ts = (tid >> 4) * 4;
+    double acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+    for (int c0 = 0; c0 < cnt; c0 += CH) {
+        const int cc = (cnt - c0 < CH) ? cnt - c0 : CH;
+        __syncthreads();
+        for (int t = tid; t < 64 * cc; t += SY_THREADS) {
+            const int c = t / 64, q = t % 64;
+            const int rr = rb + q, ss = sb + q;
+            sVr[c][q] = (rr < n) ? a.Vp[rr + (int64_t)(c0 + c) * ld] : 0.0;
+            sWr[c][q] = (rr < n) ? a.Wp[rr + (int64_t)(c0 + c) * ld] : 0.0;
+            sVs[c][q] = (ss < n) ? a.Vp[ss + (int64_t)(c0 + c) * ld] : 0.0;
+            sWs[c][q] = (ss < n) ? a.Wp[ss + (int64_t)(c0 + c) * ld] : 0.0;
+        }
+        __syncthreads();
+        for (int c = 0; c < cc; ++c) {
+            double vr[4], wr[4], vs[4], ws[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                vr[x] = sVr[c][tr + x];
+                wr[x] = sWr[c][tr + x];
+                vs[x] = sVs[c][ts + x];
+                ws[x] = sWs[c][ts + x];
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x][y] = fma(vr[x], ws[y], fma(wr[x], vs[y], acc[x][y]));
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        const int s = sb + ts + y;
+        if (s >= n) continue;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int r = rb + tr + x;
+            if (r < n) a.A[r + (int64_t)s * ld] -= acc[x][y];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host driver.  A: n x n, ld even and >= n + (n odd ? 1 : 0) so that the 16-byte column
+// reads of the symv kernel stay inside the allocation (callers pad ld to a multiple of 128).
+// ws: Vp, Wp (ld*NB each), p0 (n), g1/g2 (NB), part_norm/part_vav (<= 4096 each).
+// ---------------------------------------------------------------------------
+size_t sytrd_workspace_doubles(int64_t n, int64_t ld) {
+    return (size_t)2 * ld * SY_NB + (size_t)n + 2 * SY_NB + 2 * 4096 + 64;
+}
+
+void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
+                  double* ws) {
+    const int n = (int)n64;
+    SytrdArgs a;
+    a.A = A;
+    a.ld = ld;
+    a.n = n;
+    a.Vp = ws;
+    a.Wp = a.Vp + ld * SY_NB;
+    a.p0 = a.Wp + ld * SY_NB;
+    a.g1 = a.p0 + n;
+    a.g2 = a.g1 + SY_NB;
+    a.part_norm = a.g2 + SY_NB;
+    a.part_vav = a.part_norm + 4096;
+    a.d = d;
+    a.e = e;
+    a.tau = tau;
+    hipMemsetAsync(ws, 0, sytrd_workspace_doubles(n, ld) * sizeof(double), s);
+    if (n == 1) {
+        hipMemcpyAsync(d, A, sizeof(double), hipMemcpyDeviceToDevice, s);
+        return;
+    }
+    int n_vav = 0;
+    int cf = 0;  // panel column of the column currently being formed
+    const size_t lds_v = ((size_t)n + 4) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_set = true;
+    }
+    // column 0: plain form (no panel yet)
+    {
+        const int nb_form = (n + SY_FROWS - 1) / SY_FROWS;
+        sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, 0, 0, 0, 1, 0);
+    }
+    for (int j = 0; j <= n - 2; ++j) {
+        // reflector of column j + column dots
+        const int n_norm = (n - j + SY_FROWS - 1) / SY_FROWS;
+        const int nwork = (n - j - 1) + 2 * cf;
+        int nblk = (nwork + 3) / 4;
+        // at least two columns per wave once there is enough work, to amortise the v staging
+        if (nblk > 512) nblk = 512;
+        if (nblk < 1) nblk = 1;
+        sytrd_symv_kernel<<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        n_vav = nblk;
+        const int jn = j + 1;
+        const int rows = n - jn;
+        const int nb_form = (rows + SY_FROWS - 1) / SY_FROWS;
+        if (cf + 1 < SY_NB && jn <= n - 1) {
+            // finish W(:, cf) and form column j+1 inside the same panel
+            sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, cf, 1, 1, n_vav);
+            ++cf;
+        } else {
+            // panel complete: finish W, update the trailing matrix, start a new panel
+            sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, cf, 1, 0, n_vav);
+            const int cnt = cf + 1;
+            const int tr = n - jn;
+            if (tr > 0) {
+                dim3 g((tr + 63) / 64, (tr + 63) / 64);
+                sytrd_syr2k_kernel<<<g, SY_THREADS, 0, s>>>(a, jn, cnt);
+                sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, 0, 0, 1, 0);
+            }
+            cf = 0;
+        }
+    }
+}
+
+}  // namespace sdpsr

@@ -155,7 +155,7 @@ def test_square_f64_and_gemm_tn(pkg, gpu_ctx, n):
 def test_syev_matches_lapack(pkg, gpu_ctx):
     lib = pkg.load_library()
     rng = np.random.default_rng(1)
-    for n in (3, 64, 200):
+    for n in (1, 2, 3, 33, 64, 65, 200, 777):
         A = rng.standard_normal((n, n))
         A = np.asfortranarray((A + A.T) / 2)
         w = np.zeros(n)
