@@ -62,10 +62,12 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w) {
             launch_sytrd(c->stream, n, A, lda, w, E, tau, ws);
             if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "sytrd launch failed");
         }
-        rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)n,
-                              info);
+        if (c->opts.eig_driver == 3)
+            rs = rocsolver_dsteqr(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)n, info);
+        else
+            rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)n, info);
         if (rs != rocblas_status_success)
-            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dstedc status " + std::to_string(rs));
+            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver tridiagonal solver status " + std::to_string(rs));
         rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
                               (rocblas_int)n, (rocblas_int)n, A, (rocblas_int)lda, tau, Z,
                               (rocblas_int)n);

@@ -61,6 +61,25 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
     const int64_t ld = a.ld;
     const int n = a.n;
     const int jf = j - 1;
+    const int r = j + blockIdx.x * SY_FROWS + lane;
+
+    // independent loads first (they overlap the reductions below)
+    double pre_v = 0, pre_p0 = 0, pre_x = 0;
+    if (q == 0 && r < n) {
+        if (do_finish) {
+            pre_v = a.Vp[r + (int64_t)cf * ld];
+            pre_p0 = a.p0[r];
+        }
+        if (do_form) pre_x = a.A[r + (int64_t)j * ld];
+    }
+    double pv[SY_NB / 4], pw[SY_NB / 4];
+#pragma unroll
+    for (int u = 0; u < SY_NB / 4; ++u) {
+        const int c = q + 4 * u;
+        const bool ok = (r < n) && (c < cf);
+        pv[u] = ok ? a.Vp[r + (int64_t)c * ld] : 0.0;
+        pw[u] = ok ? a.Wp[r + (int64_t)c * ld] : 0.0;
+    }
 
     if (do_finish) {
         if (tid < cf) {
@@ -98,15 +117,13 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
         s_vrow[cf] = vj;
     }
 
-    const int r = j + blockIdx.x * SY_FROWS + lane;
     double sf = 0, sm = 0;
-    if (r < n) {
-#pragma unroll 4
-        for (int c = q; c < cf; c += 4) {
-            const double v = a.Vp[r + (int64_t)c * ld];
-            const double w = a.Wp[r + (int64_t)c * ld];
-            if (do_finish) sf += v * s_g1[c] + w * s_g2[c];
-            if (do_form) sm += v * s_wrow[c] + w * s_vrow[c];
+#pragma unroll
+    for (int u = 0; u < SY_NB / 4; ++u) {
+        const int c = q + 4 * u;
+        if (c < cf) {
+            if (do_finish) sf += pv[u] * s_g1[c] + pw[u] * s_g2[c];
+            if (do_form) sm += pv[u] * s_wrow[c] + pw[u] * s_vrow[c];
         }
     }
     s_part[q][0][lane] = sf;
@@ -119,14 +136,14 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
         sm = s_part[0][1][lane] + s_part[1][1][lane] + s_part[2][1][lane] + s_part[3][1][lane];
         double wnew = 0, v = 0;
         if (do_finish) {
-            v = a.Vp[r + (int64_t)cf * ld];
-            wnew = s_scal[0] * (a.p0[r] - sf) + s_scal[1] * v;
+            v = pre_v;
+            wnew = s_scal[0] * (pre_p0 - sf) + s_scal[1] * v;
             a.Wp[r + (int64_t)cf * ld] = wnew;
             // LAPACK storage of the finished reflector: v below the subdiagonal of column jf
             if (r >= jf + 2) a.A[r + (int64_t)jf * ld] = v;
         }
         if (do_form) {
-            double x = a.A[r + (int64_t)j * ld];
+            double x = pre_x;
             if (do_finish) sm += v * s_wrow[cf] + wnew * s_vrow[cf];
             x -= sm;
             a.A[r + (int64_t)j * ld] = x;
@@ -146,6 +163,7 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
 //   work items: trailing columns k in [j+1, n) -> p0[k];  cf columns of Wp -> g1;  cf columns
 //   of Vp -> g2.  n_norm = number of part_norm entries written by form(j).
 // ---------------------------------------------------------------------------
+template <int SY_MAXV>  // rows of column j held in registers per thread: n <= SY_MAXV * 256
 __global__ void __launch_bounds__(SY_THREADS)
 sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm) {
     extern __shared__ __attribute__((aligned(16))) double s_v[];  // rows r0 .. n (r0 even)
@@ -157,6 +175,14 @@ sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm) {
     const int n = a.n;
     const int r0 = (j + 1) & ~1;  // even start so that 16-byte loads are aligned
     const int len = n - r0;       // entries of s_v
+    // raw column j (unscaled) first, so that these loads overlap the norm reduction
+    double raw[SY_MAXV];
+    const int nper = (len + SY_THREADS - 1) / SY_THREADS;
+#pragma unroll
+    for (int u = 0; u < SY_MAXV; ++u) {
+        const int t = tid + u * SY_THREADS;
+        raw[u] = (u < nper && t < len && r0 + t >= j + 2) ? a.A[(r0 + t) + (int64_t)j * ld] : 0.0;
+    }
     if (wave == 0) {
         double xn2 = 0;
         for (int b = lane; b < n_norm; b += 64) xn2 += a.part_norm[b];
@@ -185,14 +211,18 @@ sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm) {
     }
     __syncthreads();
     const double scale = s_bcast[2];
-    for (int t = tid; t < len; t += SY_THREADS) {
-        const int r = r0 + t;
-        double v;
-        if (r <= j) v = 0.0;
-        else if (r == j + 1) v = 1.0;
-        else v = a.A[r + (int64_t)j * ld] * scale;
-        s_v[t] = v;
-        if (blockIdx.x == 0 && r > j) a.Vp[r + (int64_t)cf * ld] = v;
+#pragma unroll
+    for (int u = 0; u < SY_MAXV; ++u) {
+        const int t = tid + u * SY_THREADS;
+        if (u < nper && t < len) {
+            const int r = r0 + t;
+            double v;
+            if (r <= j) v = 0.0;
+            else if (r == j + 1) v = 1.0;
+            else v = raw[u] * scale;
+            s_v[t] = v;
+            if (blockIdx.x == 0 && r > j) a.Vp[r + (int64_t)cf * ld] = v;
+        }
     }
     if ((len & 1) && tid == 0) s_v[len] = 0.0;  // pad for the double2 reads
     __syncthreads();
@@ -203,42 +233,65 @@ sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm) {
     double vav = 0;
     const int len2 = (len + 1) >> 1;  // double2 elements
     const double2* sv2 = reinterpret_cast<const double2*>(s_v);
-    for (int w = blockIdx.x * wpb + wave; w < nwork; w += gridDim.x * wpb) {
+    auto col_ptr = [&](int w) -> const double2* {
         const double* col;
         if (w < ncols) col = a.A + (int64_t)(j + 1 + w) * ld;
         else if (w < ncols + cf) col = a.Wp + (int64_t)(w - ncols) * ld;
         else col = a.Vp + (int64_t)(w - ncols - cf) * ld;
-        const double2* c2 = reinterpret_cast<const double2*>(col + r0);
-        double acc0 = 0, acc1 = 0;
+        return reinterpret_cast<const double2*>(col + r0);
+    };
+    auto emit = [&](int w, double acc) {
+        if (w < ncols) {
+            a.p0[j + 1 + w] = acc;
+            vav += acc * s_v[(j + 1 + w) - r0];
+        } else if (w < ncols + cf) {
+            a.g1[w - ncols] = acc;
+        } else {
+            a.g2[w - ncols - cf] = acc;
+        }
+    };
+    // a wave walks two columns at a time: four 16-byte loads in flight per lane, and every v
+    // value read from LDS serves both columns.  (The tail double2 of an odd-length column
+    // reads one element past row n-1: ld is even and > n there, and the matching s_v pad is 0.)
+    const int nwaves = gridDim.x * wpb;
+    const int npairs = (nwork + 1) >> 1;
+    for (int pr = blockIdx.x * wpb + wave; pr < npairs; pr += nwaves) {
+        const int w0 = 2 * pr, w1 = (2 * pr + 1 < nwork) ? 2 * pr + 1 : 2 * pr;
+        const double2* c0 = col_ptr(w0);
+        const double2* c1 = col_ptr(w1);
+        double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
         int t = lane;
-        for (; t + 64 < len2; t += 128) {  // two independent 16-byte loads in flight per lane
-            double2 x0 = c2[t], x1 = c2[t + 64];
-            double2 v0 = sv2[t], v1 = sv2[t + 64];
-            acc0 = fma(x0.x, v0.x, acc0);
-            acc0 = fma(x0.y, v0.y, acc0);
-            acc1 = fma(x1.x, v1.x, acc1);
-            acc1 = fma(x1.y, v1.y, acc1);
+        for (; t + 64 < len2; t += 128) {
+            const double2 x0 = c0[t], x1 = c0[t + 64];
+            const double2 y0 = c1[t], y1 = c1[t + 64];
+            const double2 v0 = sv2[t], v1 = sv2[t + 64];
+            a00 = fma(x0.x, v0.x, a00);
+            a00 = fma(x0.y, v0.y, a00);
+            a01 = fma(x1.x, v1.x, a01);
+            a01 = fma(x1.y, v1.y, a01);
+            a10 = fma(y0.x, v0.x, a10);
+            a10 = fma(y0.y, v0.y, a10);
+            a11 = fma(y1.x, v1.x, a11);
+            a11 = fma(y1.y, v1.y, a11);
         }
         for (; t < len2; t += 64) {
-            double2 x0 = c2[t];
-            double2 v0 = sv2[t];
-            // the last double2 of an odd-length column may run one element past row n-1:
-            // rows are padded (ld >= n + 1 or the s_v pad is zero), see host wrapper
-            acc0 = fma(x0.x, v0.x, acc0);
-            acc0 = fma(x0.y, v0.y, acc0);
+            const double2 x0 = c0[t];
+            const double2 y0 = c1[t];
+            const double2 v0 = sv2[t];
+            a00 = fma(x0.x, v0.x, a00);
+            a00 = fma(x0.y, v0.y, a00);
+            a10 = fma(y0.x, v0.x, a10);
+            a10 = fma(y0.y, v0.y, a10);
         }
-        double acc = acc0 + acc1;
+        double acc0 = a00 + a01, acc1 = a10 + a11;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        for (int o = 32; o > 0; o >>= 1) {
+            acc0 += __shfl_down(acc0, o, 64);
+            acc1 += __shfl_down(acc1, o, 64);
+        }
         if (lane == 0) {
-            if (w < ncols) {
-                a.p0[j + 1 + w] = acc;
-                vav += acc * s_v[(j + 1 + w) - r0];
-            } else if (w < ncols + cf) {
-                a.g1[w - ncols] = acc;
-            } else {
-                a.g2[w - ncols - cf] = acc;
-            }
+            emit(w0, acc0);
+            if (w1 != w0) emit(w1, acc1);
         }
     }
     if (lane == 0) s_red[wave] = vav;
@@ -247,18 +300,35 @@ sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm) {
 }
 
 // ---------------------------------------------------------------------------
-// rank-2NB update of the trailing matrix (both triangles):
+// rank-2NB update of the trailing matrix:
 //   A[r, s] -= sum_c V[r,c] W[s,c] + W[r,c] V[s,c],   r, s >= j1
+// Only tiles with r-tile >= s-tile are computed; every value is written to (r,s) AND (s,r), so
+// the trailing matrix stays bitwise symmetric.  (That matters: the column-dot symv reads
+// A(:,k) where the algebra means row k; with two independently rounded triangles the
+// mismatch, of the size of eps * |A| at the deflation panel, is re-injected at every later
+// column and the tridiagonalisation of a highly degenerate matrix loses ~5 digits.)
 // 64 x 64 tile per workgroup, 4 x 4 outputs per thread, panels staged in LDS.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(SY_THREADS)
-sytrd_syr2k_kernel(SytrdArgs a, int j1, int cnt) {
+sytrd_syr2k_kernel(SytrdArgs a, int j1, int cnt, int ntile) {
     constexpr int CH = 16;  // panel columns staged per pass (4 x 16 x 64 doubles = 32 KiB)
     __shared__ double sVr[CH][64], sWr[CH][64], sVs[CH][64], sWs[CH][64];
+    // linear tile index -> (bx >= by) of the lower triangle of tiles
+    int by = 0, bx = blockIdx.x;
+    {
+        // row-wise enumeration: tiles (bx, by) with by <= bx, index = bx*(bx+1)/2 + by
+        int t = blockIdx.x;
+        int x = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((x + 1) * (x + 2) / 2 <= t) ++x;
+        while (x * (x + 1) / 2 > t) --x;
+        bx = x;
+        by = t - x * (x + 1) / 2;
+    }
+    (void)ntile;
     const int tid = threadIdx.x;
     const int64_t ld = a.ld;
     const int n = a.n;
-    const int rb = j1 + blockIdx.x * 64, sb = j1 + blockIdx.y * 64;
+    const int rb = j1 + bx * 64, sb = j1 + by * 64;
     const int tr = (tid & 15) * 4, ts = (tid >> 4) * 4;
     double acc[4][4];
 #pragma unroll
@@ -299,7 +369,10 @@ sytrd_syr2k_kernel(SytrdArgs a, int j1, int cnt) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const int r = rb + tr + x;
-            if (r < n) a.A[r + (int64_t)s * ld] -= acc[x][y];
+            if (r >= n || r < s) continue;  // diagonal tiles: lower part only
+            const double val = a.A[r + (int64_t)s * ld] - acc[x][y];
+            a.A[r + (int64_t)s * ld] = val;
+            if (r != s) a.A[s + (int64_t)r * ld] = val;
         }
     }
 }
@@ -340,7 +413,13 @@ void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, 
     const size_t lds_v = ((size_t)n + 4) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<32>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<64>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         attr_set = true;
     }
@@ -353,11 +432,18 @@ void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, 
         // reflector of column j + column dots
         const int n_norm = (n - j + SY_FROWS - 1) / SY_FROWS;
         const int nwork = (n - j - 1) + 2 * cf;
-        int nblk = (nwork + 3) / 4;
-        // at least two columns per wave once there is enough work, to amortise the v staging
+        int nblk = (nwork + 7) / 8;  // one column pair per wave
         if (nblk > 512) nblk = 512;
         if (nblk < 1) nblk = 1;
-        sytrd_symv_kernel<<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        const int rows_left = n - j;
+        if (rows_left <= 8 * SY_THREADS)
+            sytrd_symv_kernel<8><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        else if (rows_left <= 16 * SY_THREADS)
+            sytrd_symv_kernel<16><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        else if (rows_left <= 32 * SY_THREADS)
+            sytrd_symv_kernel<32><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        else
+            sytrd_symv_kernel<64><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
         n_vav = nblk;
         const int jn = j + 1;
         const int rows = n - jn;
@@ -372,8 +458,8 @@ void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, 
             const int cnt = cf + 1;
             const int tr = n - jn;
             if (tr > 0) {
-                dim3 g((tr + 63) / 64, (tr + 63) / 64);
-                sytrd_syr2k_kernel<<<g, SY_THREADS, 0, s>>>(a, jn, cnt);
+                const int nt = (tr + 63) / 64;
+                sytrd_syr2k_kernel<<<nt * (nt + 1) / 2, SY_THREADS, 0, s>>>(a, jn, cnt, nt);
                 sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, 0, 0, 1, 0);
             }
             cf = 0;

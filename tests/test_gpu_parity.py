@@ -166,6 +166,24 @@ def test_syev_matches_lapack(pkg, gpu_ctx):
         assert np.abs(A @ V - V * w).max() < 1e-9
 
 
+def test_syev_degenerate_spectrum_residual(pkg, problems, gpu_ctx):
+    """Generic elements of symmetric algebras have a handful of eigenvalues with huge
+    multiplicities: the tridiagonalisation deflates after ~dim columns and then works on
+    rounding noise.  Residual must stay at eps*|A| level (the trailing matrix is kept bitwise
+    symmetric for exactly this case)."""
+    lib = pkg.load_library()
+    n = 1024
+    Ls, d = problems.synthetic_jordan_partition(n, seed=2)
+    A = np.asfortranarray(np.concatenate([[0.0], np.random.default_rng(0).random(d)])[Ls])
+    w = np.zeros(n)
+    V = np.zeros((n, n), order="F")
+    gpu_ctx.check(lib.sdpsr_syev_f64(gpu_ctx._h, n, C.c_void_p(A.ctypes.data), C.c_void_p(w.ctypes.data), C.c_void_p(V.ctypes.data), 0))
+    scale = np.abs(w).max()
+    assert np.abs(A @ V - V * w).max() <= 1e-13 * scale * 8
+    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+    assert np.allclose(w, np.linalg.eigvalsh(A), atol=1e-12 * scale)
+
+
 # ------------------------------------------------------------------ the whole path
 def _problem(problems, name):
     if name == "petersen":
