@@ -184,11 +184,28 @@ def main():
         ms = prof(4, n, aux=max(r, 1), reps=5)  # gather+project+signature: (4 + 8r)*2 read + 8 write per entry
         gbs = ((4.0 + 8.0 * max(r, 1)) * 2 + 8.0) * n * n / (ms * 1e-3) / 1e9
         kernels["project_sig"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        # the hand-written kernel that takes the most time inside one reduction
-        k64 = kernels["gemm_f64"]
-        roof = {"kernel": "gemm_tn_kernel<f64> (Q'AQ, 2 launches per reduction)", "bound": "mfma", "achieved": k64["achieved"],
-                "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": k64["frac"], "traffic": None,
-                "algorithmic": "2*N^3 flop per launch"}
+        # the kernel that takes the most time inside one reduction: the column-dot (symv) kernel of
+        # the tridiagonalisation, launched once per column j; algorithmic bytes of launch j =
+        # 8*(n-j-1)^2 (the trailing matrix is read once), i.e. 8*(n-1)n(2n-1)/6 / (n-1) on average
+        ms = prof(5, n)
+        avg_bytes = 8.0 * n * (2 * n - 1) / 6.0
+        gbs = avg_bytes / (ms * 1e-3) / 1e9
+        kernels["sytrd_symv"] = {"ms": round(ms, 5), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "launches_per_reduction": n - 1}
+        ms6 = prof(6, n, reps=2)
+        kernels["sytrd_total"] = {"ms": round(ms6, 3), "note": "whole tridiagonalisation: symv + form + syr2k launches"}
+        # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 +
+        # WRITE_SIZE, tools/pmc_probe.py): bench.py cannot collect PMC counters itself
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_sytrd_symv_n{n}.json")))
+            traffic = round(pj["traffic_bytes_per_launch"])
+        except Exception:
+            pass
+        roof = {"kernel": "sytrd_symv_kernel (tridiagonalisation column dots, n-1 launches per reduction)", "bound": "hbm",
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(avg_bytes),
+                "algorithmic": "8*(n-j-1)^2 bytes for column j; average 8*n*(2n-1)/6 bytes per launch"}
         if args.cpu_n > 0:
             cb = cpu_baseline(pr, args.cpu_n, seed=1)
             scale = (n / cb["n"]) ** 3

@@ -1240,6 +1240,9 @@ int sdpsr_syev_f64(sdpsr_ctx* c, int64_t n, const double* A, double* values, dou
 // ---------------------------------------------------------------------------
 namespace sdpsr {
 void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t* sig);
+size_t sytrd_workspace_doubles(int64_t n, int64_t ld);
+void launch_sytrd(hipStream_t s, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
+void launch_sytrd_symv_sweep(hipStream_t s, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
 }
 
 extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t aux, int reps,
@@ -1308,6 +1311,41 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         HIP_TRY(c, hipEventRecord(e0, s));
         for (int i = 0; i < reps; ++i) run();
         HIP_TRY(c, hipEventRecord(e1, s));
+    } else if (kind == 5 || kind == 6) {
+        // 5: the symv kernel of the tridiagonalisation alone, one launch per column j = 0..n-2
+        //    (ms_per_launch = total / (n-1));  6: the whole tridiagonalisation (ms per sytrd)
+        double* A = (double*)ctx_buf(c, "prof_x", (size_t)ld * ld * 8);
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)ld * ld * 4);
+        double* ws = (double*)ctx_buf(c, "eig_sytrd_ws", sytrd_workspace_doubles(n, ld) * 8);
+        double* dd = (double*)ctx_buf(c, "prof_d", (size_t)3 * n * 8);
+        if (!A || !Lb || !ws || !dd) return SDPSR_OUT_OF_MEMORY;
+        // symmetric pseudo-random matrix: labels symmetric in (i,j)
+        std::vector<uint32_t> hl((size_t)n * n);
+        for (int64_t j2 = 0; j2 < n; ++j2)
+            for (int64_t i2 = 0; i2 < n; ++i2) {
+                const int64_t lo = std::min(i2, j2), hi = std::max(i2, j2);
+                hl[(size_t)i2 + j2 * n] = (uint32_t)(sdpsr_fmix64((uint64_t)(lo * 1315423911ll + hi)) | 1u);
+            }
+        HIP_TRY(c, hipMemcpyAsync(Lb, hl.data(), (size_t)n * n * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const int runs = (kind == 5) ? 1 : reps;
+        launch_gather_f64_padded(s, n, ld, Lb, 999, A);
+        if (kind == 6) launch_sytrd(s, n, A, ld, dd, dd + n, dd + 2 * n, ws);  // warm-up
+        launch_gather_f64_padded(s, n, ld, Lb, 999, A);
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < runs; ++i) {
+            if (kind == 5) launch_sytrd_symv_sweep(s, n, A, ld, dd, dd + n, dd + 2 * n, ws);
+            else launch_sytrd(s, n, A, ld, dd, dd + n, dd + 2 * n, ws);
+        }
+        HIP_TRY(c, hipEventRecord(e1, s));
+        HIP_TRY(c, hipEventSynchronize(e1));
+        float ms5 = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms5, e0, e1));
+        ms_per_launch[0] = (kind == 5) ? (double)ms5 / (double)std::max<int64_t>(n - 1, 1) : (double)ms5 / runs;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        HIP_TRY(c, hipGetLastError());
+        return SDPSR_OK;
     } else {
         return ctx_fail(c, SDPSR_BAD_ARGUMENT, "unknown kernel kind");
     }

@@ -467,4 +467,44 @@ void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, 
     }
 }
 
+// measurement hook: only the symv launches of a full tridiagonalisation (same grid shapes and
+// memory traffic, numerically meaningless because form/syr2k are skipped)
+void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e,
+                             double* tau, double* ws) {
+    const int n = (int)n64;
+    SytrdArgs a;
+    a.A = A;
+    a.ld = ld;
+    a.n = n;
+    a.Vp = ws;
+    a.Wp = a.Vp + ld * SY_NB;
+    a.p0 = a.Wp + ld * SY_NB;
+    a.g1 = a.p0 + n;
+    a.g2 = a.g1 + SY_NB;
+    a.part_norm = a.g2 + SY_NB;
+    a.part_vav = a.part_norm + 4096;
+    a.d = d;
+    a.e = e;
+    a.tau = tau;
+    hipMemsetAsync(ws, 0, sytrd_workspace_doubles(n, ld) * sizeof(double), s);
+    const size_t lds_v = ((size_t)n + 4) * sizeof(double);
+    for (int j = 0; j <= n - 2; ++j) {
+        const int cf = j % SY_NB;
+        const int n_norm = (n - j + SY_FROWS - 1) / SY_FROWS;
+        const int nwork = (n - j - 1) + 2 * cf;
+        int nblk = (nwork + 7) / 8;
+        if (nblk > 512) nblk = 512;
+        if (nblk < 1) nblk = 1;
+        const int rows_left = n - j;
+        if (rows_left <= 8 * SY_THREADS)
+            sytrd_symv_kernel<8><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        else if (rows_left <= 16 * SY_THREADS)
+            sytrd_symv_kernel<16><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        else if (rows_left <= 32 * SY_THREADS)
+            sytrd_symv_kernel<32><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        else
+            sytrd_symv_kernel<64><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+    }
+}
+
 }  // namespace sdpsr
