@@ -6,6 +6,7 @@ The directory name is not an importable dotted name; load it with
 from . import problems  # noqa: F401
 from . import parallel  # noqa: F401
 from . import _lib  # noqa: F401
+from . import api  # noqa: F401
 from ._lib import (MEM_DEVICE, MEM_HOST, SQUARE_AUTO, SQUARE_F32, SQUARE_F64, SQUARE_I8,  # noqa: F401
                    load_library)
 from .api import (BlockDiagonalization, Context, DimensionMismatch, InvalidDecompositionField,  # noqa: F401

@@ -470,7 +470,13 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
             unsigned long long sg = l_sig[i];
             if (sg) {
                 uint32_t g = global_find_or_insert(sg, tab_sig, mask, counters);
-                if (g != NO_SLOT) atomicMin(&tab_min[g], l_min[i]);
+                // tab_min only ever decreases, so a (possibly stale) plain read that is already
+                // <= our candidate proves the atomic cannot change anything: skip it.  In the
+                // few-classes regime this removes almost every contended atomic on the hot slots.
+                if (g != NO_SLOT) {
+                    const uint32_t mine = l_min[i];
+                    if (tab_min[g] > mine) atomicMin(&tab_min[g], mine);
+                }
                 l_gslot[i] = g;
             }
         }

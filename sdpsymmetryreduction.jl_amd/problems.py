@@ -209,3 +209,25 @@ def partition_as_sdp(L, seed=0):
     A = np.eye(n).ravel(order="F")[None, :]
     b = np.array([1.0])
     return C, A, b
+
+
+def grid_qap_instance(rows=5, cols=6, seed=0, symmetric_flow=True):
+    """Synthetic "nug30-shaped" QAP (BASELINE.json configs[2]; the real nug30 data is not in the
+    reference's test/qapdata): n = rows*cols facilities, distance = Manhattan metric of the
+    rows x cols grid, flow = seeded sparse symmetric integer matrix.  With
+    ``symmetric_flow`` the flow is made invariant under the grid's reflections so that the
+    relaxation has a non-trivial symmetry group (otherwise dim(P) = (N^2+N)/2)."""
+    n = rows * cols
+    pts = np.array([(i, j) for i in range(rows) for j in range(cols)])
+    dist = np.abs(pts[:, None, :] - pts[None, :, :]).sum(-1).astype(np.float64)
+    rng = np.random.default_rng(seed)
+    flow = np.zeros((n, n))
+    mask = np.triu(rng.random((n, n)) < 0.25, 1)
+    vals = rng.integers(1, 6, size=(n, n))
+    flow[mask] = vals[mask]
+    flow = flow + flow.T
+    if symmetric_flow:
+        idx = np.arange(n).reshape(rows, cols)
+        perms = [idx.ravel(), idx[::-1, :].ravel(), idx[:, ::-1].ravel(), idx[::-1, ::-1].ravel()]
+        flow = sum(flow[np.ix_(p, p)] for p in perms)
+    return flow, dist

@@ -1,0 +1,88 @@
+"""BASELINE.json configs at (or near) their full sizes on the GPU.  Where the CPU oracle
+finishes in seconds the comparison is bit-exact against it; at N >= 4096 the checks are the
+size-independent properties of the domain: the generator's partition is a fixed point
+(known closure), idempotence, seed independence, block sizes known by construction."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_gnp1024_theta_prime(pkg, problems, oracle):
+    """configs[1]: G(1024, 0.5) theta': trivial symmetry, the loop must end at
+    dim = (n^2+n)/2 = 524800 with the oracle's canonical matrix; the eigen path on the generic
+    element gives one isomorphism class of 1024 one-dimensional eigenspaces."""
+    n = 1024
+    Cv, A, b = problems.theta_prime_problem(problems.gnp_adjacency(n, 0.5, seed=11))
+    ref = oracle.admissible_subspace(Cv, A, b, rng=np.random.default_rng(0))
+    assert ref.nparts == (n * n + n) // 2
+    with pkg.Context(seed=21) as ctx:
+        P = pkg.admissible_subspace(Cv, A, b, ctx=ctx)
+        assert P.nparts == ref.nparts
+        assert np.array_equal(P.matrix, ref.matrix)
+        assert P.iterations <= 3
+        ne, nc = pkg.eigen_decomposition(P, atol=1.4901161193847656e-8, ctx=ctx)
+        assert ne == n and nc == 1
+        assert pkg.diagonalize(P, atol=1.4901161193847656e-8, ctx=ctx) == [n]  # 1024*1025/2 = dim
+
+
+def test_config2_qap_grid30(pkg, problems, oracle):
+    """configs[2]: QAP relaxation with n = 30 facilities, N = 900, sparse A (61 x 810000)."""
+    flow, dist = problems.grid_qap_instance(5, 6, seed=4, symmetric_flow=True)
+    Cv, A, b = problems.qap_problem(flow, dist)
+    assert A.shape == (61, 810000)
+    setup = pkg.admissible_setup(Cv, A, b)
+    n, CL, X0L, U = setup
+    ref = oracle.admissible_subspace(Cv, A, b, rng=np.random.default_rng(0),
+                                     setup=(n, U, CL.reshape(n, n, order="F"), X0L.reshape(n, n, order="F")))
+    for mode in (pkg.SQUARE_I8, pkg.SQUARE_F64):
+        with pkg.Context(seed=31, square_mode=mode) as ctx:
+            P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)
+            assert P.nparts == ref.nparts
+            assert np.array_equal(P.matrix, ref.matrix)
+    assert ref.nparts < (n * n + n) // 2  # the grid symmetry gives a real reduction
+
+
+def test_config3_noncommutative_n4104(pkg, problems, golden):
+    """configs[3] variant: ER(7) Jordan algebra (x) {I, J-I} on 72 points, N = 4104, dim 36,
+    blocks [2,2,2,2,3] twice (known by construction)."""
+    L, d = problems.kron_with_complete(golden["er7_P"].astype(np.int64), 72, seed=5)
+    n = L.shape[0]
+    assert n == 4104 and d == 36
+    Cv, A, b = problems.partition_as_sdp(L, seed=2)
+    setup = pkg.admissible_setup(Cv, A, b)
+    mats = []
+    for seed in (1, 2):
+        with pkg.Context(seed=seed) as ctx:
+            P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)
+            assert P.nparts == d
+            mats.append(P.matrix)
+            if seed == 1:
+                bd = pkg.blockDiagonalize(P, ctx=ctx)
+                assert sorted(bd.blkSizes) == sorted([2, 2, 2, 2, 3] * 2)
+                # spectrum invariant on the block side only (the full 4104^2 eigensolve on the
+                # host is the oracle's job at small n): block spectra must be real symmetric
+                x = np.random.default_rng(3).random(d)
+                for k, s in enumerate(bd.blkSizes):
+                    B = sum(x[i] * bd.blks[i][k] for i in range(d))
+                    assert np.abs(B - B.T).max() < 1e-8
+    assert np.array_equal(mats[0], L) and np.array_equal(mats[1], L)
+
+
+def test_config4_n8192_fixed_point(pkg, problems):
+    """configs[4]: N = 8192 of the same generator family: closure known by construction,
+    idempotence, all blocks of size 1."""
+    n = 8192
+    L, d = problems.synthetic_jordan_partition(n, seed=8)
+    Cv, A, b = problems.partition_as_sdp(L, seed=3)
+    # trace-only A: the setup stage is analytic (saves a 67M x 1 QR on the host)
+    U = (np.eye(n).ravel(order="F") / np.sqrt(n))[:, None]
+    c = Cv - U[:, 0] * (U[:, 0] @ Cv)
+    CL = pkg.api.clamp_round_host(c, pkg.api.RTOL_DEFAULT)
+    X0L = pkg.api.clamp_round_host(U[:, 0] * (1.0 / np.sqrt(n)), pkg.api.RTOL_DEFAULT)
+    with pkg.Context(seed=77) as ctx:
+        P = pkg.admissible_subspace(None, None, None, ctx=ctx, setup=(n, CL, X0L, np.asfortranarray(U)))
+        assert P.nparts == d
+        assert np.array_equal(P.matrix, L)
+        ne, nc = pkg.eigen_decomposition(P, atol=1.4901161193847656e-8, ctx=ctx)
+        assert ne == d and nc == d  # commutative: every eigenspace its own class
