@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <functional>
 #include <numeric>
 
 #include "sdpsr_internal.h"
@@ -60,6 +62,16 @@ static void ctx_free_buf(sdpsr_ctx* c, const char* name) {
 
 namespace {
 
+// SDPSR_DEBUG=1: host wall-clock marks (relative to the previous mark)
+inline void dbg_mark(const char* what) {
+    static const bool on = getenv("SDPSR_DEBUG") != nullptr;
+    if (!on) return;
+    static auto last = std::chrono::steady_clock::now();
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sdpsr] +%8.3f ms  %s\n", std::chrono::duration<double, std::milli>(now - last).count(), what);
+    last = now;
+}
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) {
@@ -105,6 +117,39 @@ int out_finish(sdpsr_ctx* c, T* host, const T* dev, size_t count, int mem) {
 }
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Small host<->device transfers go through a growable pinned staging area: a hipMemcpyAsync
+// to or from pageable memory costs milliseconds of host time on this stack.
+void* ctx_pinned(sdpsr_ctx* c, size_t bytes) {
+    if (c->pinned_bytes >= bytes) return c->pinned;
+    hipStreamSynchronize(c->stream);
+    if (c->pinned) hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
+    size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+    if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) {
+        c->pinned = nullptr;
+        return nullptr;
+    }
+    c->pinned_bytes = want;
+    return c->pinned;
+}
+int d2h_sync(sdpsr_ctx* c, void* host, const void* dev, size_t bytes) {
+    void* p = ctx_pinned(c, bytes);
+    if (!p) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
+    HIP_TRY(c, hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(host, p, bytes);
+    return SDPSR_OK;
+}
+int h2d_sync(sdpsr_ctx* c, void* dev, const void* host, size_t bytes) {
+    void* p = ctx_pinned(c, bytes);
+    if (!p) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
+    memcpy(p, host, bytes);
+    HIP_TRY(c, hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDPSR_OK;
+}
 inline int ceil_log2(uint64_t x) {
     int l = 0;
     while ((uint64_t(1) << l) < x) ++l;
@@ -264,7 +309,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
         return SDPSR_HIP_ERROR;
     }
     c->own_stream = true;
-    c->pinned_bytes = 4096;
+    c->pinned_bytes = 1 << 16;
     if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         hipStreamDestroy(c->stream);
         delete c;
@@ -896,10 +941,24 @@ struct EigInfo {
     std::vector<int> kpart; // root of every eigenspace
 };
 
+
+// Source of "generic elements" for the dense driver: the label gather (gen == nullptr,
+// randomize!(A, P)) or a compressed representation B = W' A W of it (module-compression driver).
+struct ElemGen {
+    // writes an (n_eff x n_eff, leading dimension ld_eff, zero padded) symmetric matrix
+    std::function<int(double* dst)> make;
+};
+
+int make_element(sdpsr_ctx* c, const ElemGen* gen, int64_t n, int64_t ld, const uint32_t* L, double* dst) {
+    if (gen) return gen->make(dst);
+    launch_gather_f64_padded(c->stream, n, ld, L, next_key(c), dst);
+    return SDPSR_OK;
+}
+
 // eigen_decomposition (src/eigen_decomposition.jl:236-273) on the device.  On success the
 // padded buffers "bd_q" (eigenvectors, ld x ld) stay valid in ctx.
 int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, double atol, EigInfo& info,
-                               PhaseTimer& tm) {
+                               PhaseTimer& tm, const ElemGen* gen = nullptr) {
     hipStream_t s = c->stream;
     const int64_t ld = round_up(n, 128);
     uint32_t* flag = (uint32_t*)ctx_buf(c, "bd_flag", 64);
@@ -910,21 +969,26 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     if (!flag || !Q || !Ap || !Tp || !w) return SDPSR_OUT_OF_MEMORY;
     // a non-symmetric partition has a non-symmetric generic element: eigen() leaves the reals
     // (src/eigen_decomposition.jl:247-253)
-    launch_check_symmetric(s, n, L, flag);
-    uint32_t* hflag = (uint32_t*)c->pinned;
-    HIP_TRY(c, hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (hflag[0]) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
-                                  "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
+    if (!gen) {
+        launch_check_symmetric(s, n, L, flag);
+        uint32_t* hflag = (uint32_t*)c->pinned;
+        HIP_TRY(c, hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (hflag[0]) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
+                                      "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
+    }
     // Step 1-2: generic element and its eigendecomposition (:242-254)
     tm.begin(SDPSR_T_EIGEN);
-    launch_gather_f64_padded(s, n, ld, L, next_key(c), Q);
-    int st = syev_device(c, n, Q, ld, w);
+    int st = make_element(c, gen, n, ld, L, Q);
+    if (st) return st;
+    dbg_mark("eigen_decomposition: element made");
+    st = syev_device(c, n, Q, ld, w);
+    dbg_mark("eigen_decomposition: syev returned");
     tm.end();
     if (st) return st;
     info.vals.resize(n);
-    HIP_TRY(c, hipMemcpyAsync(info.vals.data(), w, n * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    st = d2h_sync(c, info.vals.data(), w, n * 8);
+    if (st) return st;
     tm.collect();
     // EigenDecomposition ctor (:19-40): new eigenspace where |dv| > atol
     info.ptrs.assign(1, 0);
@@ -944,16 +1008,18 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     int32_t* dspace = (int32_t*)ctx_buf(c, "bd_space", (size_t)n * 4);
     unsigned long long* dnorms = (unsigned long long*)ctx_buf(c, "bd_norms", (size_t)neig * neig * 8);
     if (!dspace || !dnorms) return SDPSR_OUT_OF_MEMORY;
-    HIP_TRY(c, hipMemcpyAsync(dspace, space_of.data(), n * 4, hipMemcpyHostToDevice, s));
+    st = h2d_sync(c, dspace, space_of.data(), n * 4);
+    if (st) return st;
     HIP_TRY(c, hipMemsetAsync(dnorms, 0, (size_t)neig * neig * 8, s));
-    launch_gather_f64_padded(s, n, ld, L, next_key(c), Ap);
+    st = make_element(c, gen, n, ld, L, Ap);
+    if (st) return st;
     launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);   // T = A Q (A symmetric)
     launch_gemm_tn_f64(s, ld, ld, ld, Q, ld, Tp, ld, Ap, ld, 1, 0, 0, 0);   // M = Q' T  (into Ap)
     launch_block_norms(s, n, ld, Ap, dspace, neig, dnorms);
     std::vector<double> norms((size_t)neig * neig);
-    HIP_TRY(c, hipMemcpyAsync(norms.data(), dnorms, (size_t)neig * neig * 8, hipMemcpyDeviceToHost, s));
     tm.end();
-    HIP_TRY(c, hipStreamSynchronize(s));
+    st = d2h_sync(c, norms.data(), dnorms, (size_t)neig * neig * 8);
+    if (st) return st;
     tm.collect();
     // blocks between eigenspaces of different dimension count as zero (:185-186); the kernel
     // computes the (bi, bj) max with bi = row space, symmetrise like end_norm[i,j] = end_norm[j,i]
@@ -989,7 +1055,12 @@ constexpr int KRYLOV_FALLBACK = -1000;
 namespace sdpsr {
 void launch_sym_gemv(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* x, double* y);
 void launch_lanczos_orth(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const int* tcur,
-                         double* W, int64_t ldw, const int* active, int nruns, double* alpha_out, double* beta_out);
+                         double* W, int64_t ldw, const int* active, int nruns, double* alpha_out, double* beta_out,
+                         double* nin_out);
+void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B);
+void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
+void launch_tall_times_small(hipStream_t s, int64_t n, int64_t ldi, const double* In, int kk, const double* S,
+                             int lds_, int ncols, double alpha, double beta, double* out, int64_t ldo);
 void launch_lanczos_init(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const double* X,
                          int64_t ldx, int nruns, double* norm0);
 void launch_lanczos_pack(hipStream_t s, int64_t n, int64_t ld, const double* H, int64_t hstride, const int* tcur,
@@ -1097,7 +1168,7 @@ int batched_lanczos(sdpsr_ctx* c, int64_t n, int64_t ld, const double* A, const 
             launch_lanczos_pack(s, n, ld, H, hstride, d_t, d_act, nruns, Vp, ld);
             launch_gemm_tn_f64(s, ld, np, ld, A, ld, Vp, ld, Wp, ld, 1, 0, 0, 0);  // W = A V (A symmetric)
         }
-        launch_lanczos_orth(s, n, ld, H, hstride, d_t, Wp, ld, d_act, nruns, d_ab, d_ab + nruns);
+        launch_lanczos_orth(s, n, ld, H, hstride, d_t, Wp, ld, d_act, nruns, d_ab, d_ab + nruns, nullptr);
         HIP_TRY(c, hipMemcpyAsync(hab.data(), d_ab, (size_t)nruns * 3 * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         for (int r = 0; r < nruns; ++r) {
@@ -1322,6 +1393,318 @@ bool krylov_eligible(const sdpsr_ctx* c, int64_t n, int64_t d) {
     return c->opts.eig_driver == 5;
 }
 
+
+// diagonalize(Float64, P) with the dense eigensolver (src/diagonalize.jl:25-40): on success the
+// device buffer "bd_qhat" holds Q_hat (n x S1 column-major, classes side by side).
+int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen* gen, double atol, EigInfo& info,
+                      std::vector<int32_t>& sizes, int64_t& S1, int64_t& S, PhaseTimer& tm) {
+    hipStream_t s = c->stream;
+    int st = eigen_decomposition_device(c, n, L, atol, info, tm, gen);
+    if (st) return st;
+
+    // irreducible_decomposition (src/eigen_decomposition.jl:295-348)
+    tm.begin(SDPSR_T_IRRED);
+    const int64_t ld = round_up(n, 128);
+    const int neig = (int)info.ptrs.size() - 1;
+    std::vector<int> roots;  // unique(Kpartition) in first-occurrence order (:303)
+    std::vector<std::vector<int>> members;
+    class_structure(info.kpart, roots, members);
+    sizes.assign(roots.size(), 0);
+    S1 = 0;
+    S = 0;
+    for (size_t p = 0; p < roots.size(); ++p) {
+        sizes[p] = (int32_t)members[p].size();
+        S1 += sizes[p];
+        S += (int64_t)sizes[p] * sizes[p];
+    }
+    double* Q = (double*)ctx_buf(c, "bd_q", (size_t)ld * ld * 8);
+    double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
+    if (!Q || !Qhat) return SDPSR_OUT_OF_MEMORY;
+    // first eigenvector of every eigenspace that sits in a merged class -> F; B = A3 * F
+    std::vector<int> fcol(neig, -1);
+    int nf = 0;
+    for (size_t p = 0; p < roots.size(); ++p)
+        if (members[p].size() > 1)
+            for (int j : members[p]) fcol[j] = nf++;
+    double* Bf = nullptr;
+    if (nf > 0) {
+        const int64_t nfp = round_up(nf, 128);
+        double* A3 = (double*)ctx_buf(c, "bd_a", (size_t)ld * ld * 8);
+        double* F = (double*)ctx_buf(c, "bd_f", (size_t)ld * nfp * 8);
+        Bf = (double*)ctx_buf(c, "bd_bf", (size_t)ld * nfp * 8);
+        if (!A3 || !F || !Bf) return SDPSR_OUT_OF_MEMORY;
+        st = make_element(c, gen, n, ld, L, A3);  // generic element #3 (:306)
+        if (st) return st;
+        HIP_TRY(c, hipMemsetAsync(F, 0, (size_t)ld * nfp * 8, s));
+        for (int j = 0; j < neig; ++j)
+            if (fcol[j] >= 0)
+                HIP_TRY(c, hipMemcpyAsync(F + (size_t)fcol[j] * ld, Q + (size_t)info.ptrs[j] * ld, n * 8,
+                                          hipMemcpyDeviceToDevice, s));
+        launch_gemm_tn_f64(s, ld, nfp, ld, A3, ld, F, ld, Bf, ld, 1, 0, 0, 0);  // B = A3' F = A3 F
+    }
+    double* wv = (double*)ctx_buf(c, "bd_wv", (size_t)n * 8);
+    double* cv = (double*)ctx_buf(c, "bd_cv", (size_t)n * 8);
+    double* inv = (double*)ctx_buf(c, "bd_inv", 64);
+    if (!wv || !cv || !inv) return SDPSR_OUT_OF_MEMORY;
+    int64_t col = 0;
+    for (size_t p = 0; p < roots.size(); ++p) {
+        const int i = roots[p];
+        const int64_t mi = info.ptrs[i + 1] - info.ptrs[i];
+        // first member: P1 = I -> first eigenvector of Ei (:311-313, :326)
+        launch_copy_col(s, n, Q + (size_t)info.ptrs[i] * ld, Qhat + (size_t)col * n);
+        ++col;
+        for (size_t q = 1; q < members[p].size(); ++q) {
+            const int j = members[p][q];
+            const int64_t mj = info.ptrs[j + 1] - info.ptrs[j];
+            // first column of P_blk = block(A,Ei,Ej)' is Qj' (A q_i1)             (:333)
+            launch_gemv_t(s, n, ld, Q, info.ptrs[j], mj, Bf + (size_t)fcol[i] * ld, wv);
+            // norm(P_blk[1,:]) = || Qi' (A q_j1) ||                              (:335)
+            launch_gemv_t(s, n, ld, Q, info.ptrs[i], mi, Bf + (size_t)fcol[j] * ld, cv);
+            launch_inv_norm(s, mi, cv, inv);
+            // column of P_hat = Qj * first column of the normalised block       (:338-344)
+            launch_gemv_n_scaled(s, n, ld, Q, info.ptrs[j], mj, wv, inv, Qhat + (size_t)col * n);
+            ++col;
+        }
+    }
+    launch_clamptol(s, n * S1, Qhat, atol);  // src/diagonalize.jl:39
+    tm.end();
+    HIP_TRY(c, hipGetLastError());
+    return SDPSR_OK;
+}
+
+
+
+// C = A' B for skinny outputs: the 128 x 128 output tiling alone would occupy a handful of
+// CUs, so K is split over the batch dimension of the same MFMA kernel and the partial tiles are
+// summed in fixed order.  Requires ldc == m (dense C) -- true for every caller.
+int gemm_tn_splitk(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                   int64_t ldb, double* C, int64_t ldc) {
+    const int64_t tiles = (m / 128) * (n / 128);
+    int Z = 1;
+    while (tiles * Z < 256 && (k / (2 * Z)) >= 128 && (k % (2 * Z * 16)) == 0) Z *= 2;
+    if (Z == 1 || ldc != m) {
+        launch_gemm_tn_f64(c->stream, m, n, k, A, lda, B, ldb, C, ldc, 1, 0, 0, 0);
+        return SDPSR_OK;
+    }
+    double* P = (double*)ctx_buf(c, "splitk_partials", (size_t)Z * m * n * 8);
+    if (!P) return SDPSR_OUT_OF_MEMORY;
+    const int64_t kz = k / Z;
+    launch_gemm_tn_f64(c->stream, m, n, kz, A, lda, B, ldb, P, m, Z, kz, kz, m * n);
+    launch_splitk_reduce(c->stream, m * n, Z, m * n, P, C);
+    return SDPSR_OK;
+}
+
+// ===========================================================================
+// Module-compression driver of diagonalize (DESIGN.md "module compression").
+//
+// For a random x the cyclic module M = <S> x (S = the partition subspace, <S> the associative
+// algebra it generates) is invariant under every element of S and contains every irreducible
+// constituent of the action with multiplicity min(s_k, m_k) >= 1, so Murota's algorithm run on
+// the restriction S|_M (dimension w = sum_k s_k min(s_k, m_k) <= sum_k s_k^2 < 2 dim(P))
+// finds the same blocks, and Q_hat = W * Q_hat_small (W an orthonormal basis of M) is a valid
+// Q_hat of the full problem.  M is grown one vector at a time: y = A z for a fresh generic
+// element A and a random z in the current span; y is appended if it leaves the span (CGS2);
+// three consecutive misses end the growth.  Only first powers of well-scaled matrices are
+// involved (unlike the Krylov driver), so the rank decisions are sharp (eps vs O(1)).
+// Cost: w passes over an n x n element + a dense w x w diagonalisation, against 4/3 n^3.
+// ===========================================================================
+int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d, double atol, EigInfo& info,
+                           std::vector<int32_t>& sizes, int64_t& S1, int64_t& S, PhaseTimer& tm) {
+    hipStream_t s = c->stream;
+    const int64_t ld = round_up(n, 128);
+    const int wmax = (int)std::min<int64_t>(std::min<int64_t>(n / 2, 500), 2 * d + 8);
+    if (wmax < 2) return krylov_fallback(c, "module too small to compress");
+    const int64_t wcap = round_up(wmax + 2, 128);
+    uint32_t* flag = (uint32_t*)ctx_buf(c, "bd_flag", 64);
+    double* W = (double*)ctx_buf(c, "cm_w", (size_t)ld * wcap * 8);
+    double* A = (double*)ctx_buf(c, "cm_a", (size_t)ld * ld * 8);
+    double* T = (double*)ctx_buf(c, "cm_t", (size_t)ld * wcap * 8);
+    double* zy = (double*)ctx_buf(c, "cm_zy", (size_t)ld * 2 * 8);
+    double* dout = (double*)ctx_buf(c, "cm_out", 64);
+    if (!flag || !W || !A || !T || !zy || !dout) return SDPSR_OUT_OF_MEMORY;
+    launch_check_symmetric(s, n, L, flag);
+    uint32_t* hflag = (uint32_t*)c->pinned;
+    HIP_TRY(c, hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (hflag[0]) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
+                                  "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
+    dbg_mark("compressed: buffers + symmetric check done");
+    tm.begin(SDPSR_T_EIGEN);
+    HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)ld * wcap * 8, s));
+    double* y = zy;
+    launch_random_vector(s, n, next_key(c), y);
+    launch_lanczos_init(s, n, ld, W, 0, y, ld, 1, dout);  // W[:,0] = x / |x|
+    int w = 1;
+    // Block growth: candidates Y = [A_a W, A_b W] for two fresh generic elements, projected off
+    // W (block CGS, twice); the new directions are selected by a pivoted Cholesky factorisation
+    // of the Gram matrix Y'Y (rank gap: O(1) against eps^2, sharp because every candidate is a
+    // first power of a well-scaled matrix) and orthonormalised as Y P R^-1, then once more
+    // against W.  The module is complete when a round adds nothing.
+    const int64_t ycap = 2 * wcap;
+    double* Y = (double*)ctx_buf(c, "cm_y", (size_t)ld * ycap * 8);
+    double* Cc = (double*)ctx_buf(c, "cm_c", (size_t)ycap * ycap * 8);
+    double* dSm = (double*)ctx_buf(c, "cm_sm", (size_t)ycap * ycap * 8);
+    double* Q1 = (double*)ctx_buf(c, "cm_q1", (size_t)ld * ycap * 8);
+    if (!Y || !Cc || !dSm || !Q1) return SDPSR_OUT_OF_MEMORY;
+    std::vector<double> hG, hS;
+    auto project_off_W = [&](double* Yb, int64_t ncolp, int ncol) {  // Yb -= W (W' Yb), twice
+        const int64_t wpp = round_up(w, 128);
+        for (int pass = 0; pass < 2; ++pass) {
+            gemm_tn_splitk(c, wpp, ncolp, ld, W, ld, Yb, ld, Cc, wpp);  // C = W' Y
+            launch_tall_times_small(s, n, ld, W, w, Cc, (int)wpp, ncol, -1.0, 1.0, Yb, ld);
+        }
+    };
+    // pivoted Cholesky of the m x m Gram matrix (leading dimension ldg): returns rank r, the
+    // pivot order and X = R11^-1 scattered into an m x r coefficient matrix (column-major, ld m)
+    auto gram_select = [&](const std::vector<double>& G, int64_t ldg, int m, double tol_abs, std::vector<double>& coef) -> int {
+        std::vector<double> Gm((size_t)m * m);
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) Gm[(size_t)i + (size_t)j * m] = 0.5 * (G[(size_t)i + (size_t)j * ldg] + G[(size_t)j + (size_t)i * ldg]);
+        std::vector<int> perm(m);
+        std::iota(perm.begin(), perm.end(), 0);
+        std::vector<double> R((size_t)m * m, 0.0);
+        int r = 0;
+        for (int kk2 = 0; kk2 < m; ++kk2) {
+            int p = kk2;
+            for (int i = kk2 + 1; i < m; ++i)
+                if (Gm[(size_t)i + (size_t)i * m] > Gm[(size_t)p + (size_t)p * m]) p = i;
+            if (!(Gm[(size_t)p + (size_t)p * m] > tol_abs)) break;
+            if (p != kk2) {
+                for (int i = 0; i < m; ++i) std::swap(Gm[(size_t)i + (size_t)kk2 * m], Gm[(size_t)i + (size_t)p * m]);
+                for (int j = 0; j < m; ++j) std::swap(Gm[(size_t)kk2 + (size_t)j * m], Gm[(size_t)p + (size_t)j * m]);
+                for (int i = 0; i < kk2; ++i) std::swap(R[(size_t)i + (size_t)kk2 * m], R[(size_t)i + (size_t)p * m]);
+                std::swap(perm[kk2], perm[p]);
+            }
+            const double rkk = std::sqrt(Gm[(size_t)kk2 + (size_t)kk2 * m]);
+            R[(size_t)kk2 + (size_t)kk2 * m] = rkk;
+            for (int j = kk2 + 1; j < m; ++j) R[(size_t)kk2 + (size_t)j * m] = Gm[(size_t)kk2 + (size_t)j * m] / rkk;
+            for (int j = kk2 + 1; j < m; ++j) {
+                const double rj = R[(size_t)kk2 + (size_t)j * m];
+                for (int i = kk2 + 1; i <= j; ++i) {
+                    Gm[(size_t)i + (size_t)j * m] -= R[(size_t)kk2 + (size_t)i * m] * rj;
+                    Gm[(size_t)j + (size_t)i * m] = Gm[(size_t)i + (size_t)j * m];
+                }
+            }
+            ++r;
+        }
+        // X = R11^-1 (upper triangular r x r), column by column
+        std::vector<double> X((size_t)r * r, 0.0);
+        for (int cc = 0; cc < r; ++cc) {
+            for (int i = cc; i >= 0; --i) {
+                double sum = (i == cc) ? 1.0 : 0.0;
+                for (int t = i + 1; t <= cc; ++t) sum -= R[(size_t)i + (size_t)t * m] * X[(size_t)t + (size_t)cc * r];
+                X[(size_t)i + (size_t)cc * r] = sum / R[(size_t)i + (size_t)i * m];
+            }
+        }
+        coef.assign((size_t)m * std::max(r, 1), 0.0);
+        for (int cc = 0; cc < r; ++cc)
+            for (int i = 0; i <= cc; ++i) coef[(size_t)perm[i] + (size_t)cc * m] = X[(size_t)i + (size_t)cc * r];
+        return r;
+    };
+    for (int round = 0; round < 40; ++round) {
+        const int64_t wpp = round_up(w, 128);
+        const int m = 2 * w;
+        const int64_t mp = 2 * wpp;
+        // candidates: Y[:, 0:w] = A_a W, Y[:, wpp : wpp + w] = A_b W
+        for (int half = 0; half < 2; ++half) {
+            launch_gather_f64_padded(s, n, ld, L, next_key(c), A);
+            gemm_tn_splitk(c, ld, wpp, ld, A, ld, W, ld, Y + (size_t)half * wpp * ld, ld);
+        }
+        // scale reference: the candidates before projection (after it, a complete module leaves
+        // only rounding noise and a relative test would compare noise with noise)
+        gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);
+        hG.resize((size_t)mp * mp);
+        { int e2 = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8); if (e2) return e2; }
+        double ref = 0;
+        for (int64_t i = 0; i < mp; ++i) ref = std::max(ref, hG[(size_t)i + (size_t)i * mp]);
+        project_off_W(Y, mp, (int)mp);
+        gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);  // Gram
+        { int e2 = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8); if (e2) return e2; }
+        // compact the two halves (columns w..wpp-1 of each half are zero)
+        std::vector<double> Gc((size_t)m * m);
+        auto src = [&](int i) { return (i < w) ? (int64_t)i : (int64_t)(wpp + (i - w)); };
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < m; ++i) Gc[(size_t)i + (size_t)j * m] = hG[(size_t)src(i) + (size_t)src(j) * mp];
+        std::vector<double> coefc;
+        const int r_new = gram_select(Gc, m, m, 1e-12 * ref, coefc);
+        if (r_new == 0) break;
+        if (w + r_new >= wmax) {
+            tm.end();
+            tm.collect();
+            return krylov_fallback(c, "module dimension exceeds " + std::to_string(wmax));
+        }
+        // Q1 = Y * coef (expand the compact coefficients to the padded row layout)
+        hS.assign((size_t)mp * r_new, 0.0);
+        for (int cc = 0; cc < r_new; ++cc)
+            for (int i = 0; i < m; ++i) hS[(size_t)src(i) + (size_t)cc * mp] = coefc[(size_t)i + (size_t)cc * m];
+        { int e2 = h2d_sync(c, dSm, hS.data(), (size_t)mp * r_new * 8); if (e2) return e2; }
+        const int64_t rp = round_up(r_new, 128);
+        HIP_TRY(c, hipMemsetAsync(Q1, 0, (size_t)ld * rp * 8, s));
+        launch_tall_times_small(s, n, ld, Y, (int)mp, dSm, (int)mp, r_new, 1.0, 0.0, Q1, ld);
+        // second orthonormalisation pass (CholQR2): off W again, then Gram + Cholesky of Q1 itself
+        project_off_W(Q1, rp, r_new);
+        gemm_tn_splitk(c, rp, rp, ld, Q1, ld, Q1, ld, Cc, rp);
+        hG.resize((size_t)rp * rp);
+        { int e2 = d2h_sync(c, hG.data(), Cc, (size_t)rp * rp * 8); if (e2) return e2; }
+        std::vector<double> coef2;
+        const int r2 = gram_select(hG, rp, r_new, 1e-6, coef2);  // Q1 columns have unit scale
+        if (r2 <= 0) break;
+        { int e2 = h2d_sync(c, dSm, coef2.data(), (size_t)r_new * r2 * 8); if (e2) return e2; }
+        launch_tall_times_small(s, n, ld, Q1, r_new, dSm, r_new, r2, 1.0, 0.0, W + (size_t)w * ld, ld);
+        w += r2;
+    }
+    // columns >= w must be zero for the padded products below
+    const int64_t wp = round_up(w, 128);
+    HIP_TRY(c, hipMemsetAsync(W + (size_t)w * ld, 0, (size_t)ld * (wcap - w) * 8, s));
+    tm.end();
+    tm.collect();
+    if (getenv("SDPSR_DEBUG")) fprintf(stderr, "[sdpsr] module compression: n=%lld dim(P)=%lld -> w=%d\n", (long long)n, (long long)d, w);
+
+    dbg_mark("compressed: module grown");
+    ElemGen gen;
+    gen.make = [&](double* dst) -> int {
+        launch_gather_f64_padded(s, n, ld, L, next_key(c), A);
+        gemm_tn_splitk(c, ld, wp, ld, A, ld, W, ld, T, ld);    // T = A W
+        gemm_tn_splitk(c, wp, wp, ld, W, ld, T, ld, dst, wp);  // B = W' T  (wp x wp)
+        launch_symmetrize(s, w, wp, dst);
+        return SDPSR_OK;
+    };
+    int st = dense_diagonalize(c, w, nullptr, &gen, atol, info, sizes, S1, S, tm);
+    if (st) return st;
+    dbg_mark("compressed: small dense diagonalize done");
+    // lift: Q_hat = W * Q_hat_small
+    tm.begin(SDPSR_T_IRRED);
+    double* qs = (double*)ctx_buf(c, "cm_qsmall", (size_t)w * S1 * 8);
+    double* small = (double*)ctx_buf(c, "bd_qhat", (size_t)w * S1 * 8);
+    if (!qs || !small) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(qs, small, (size_t)w * S1 * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
+    int* dlift = (int*)ctx_buf(c, "cm_lift", (size_t)S1 * 2 * 4);
+    if (!Qhat || !dlift) return SDPSR_OUT_OF_MEMORY;
+    std::vector<int> hl(2 * (size_t)S1);
+    for (int64_t i = 0; i < S1; ++i) {
+        hl[i] = 0;
+        hl[S1 + i] = w;
+    }
+    { int e2 = h2d_sync(c, dlift, hl.data(), (size_t)S1 * 2 * 4); if (e2) return e2; }
+    launch_ritz_combine(s, n, ld, W, 0, dlift, dlift + S1, qs, w, (int)S1, Qhat, n);
+    launch_clamptol(s, n * S1, Qhat, atol);
+    tm.end();
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    dbg_mark("compressed: lifted");
+    return SDPSR_OK;
+}
+
+// eig_driver: 0 auto (module compression when dim(P) is small against n, dense otherwise),
+// 4 dense forced, 5 experimental Krylov, 6 module compression forced, 1-3 rocSOLVER variants.
+bool compression_eligible(const sdpsr_ctx* c, int64_t n, int64_t d) {
+    if (c->opts.eig_driver == 6) return true;
+    if (c->opts.eig_driver != 0) return false;
+    return n >= 512 && 2 * d + 8 <= std::min<int64_t>(n / 2, 500);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1383,88 +1766,24 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
     } else {
         HIP_TRY(c, hipMemcpyAsync(L, P, len * 4, hipMemcpyHostToDevice, s));
     }
+    dbg_mark("block_diagonalize: entered, labels copied");
     const double atol = epsilon;  // diagonalize(T, P; atol=epsilon), src/compat.jl:53
     EigInfo info;
     std::vector<int32_t> sizes;
     int64_t S1 = 0, S = 0;
     st = KRYLOV_FALLBACK;
     if (krylov_eligible(c, n, d)) st = krylov_diagonalize(c, n, L, d, atol, info, sizes, &S1, &S, true, tm);
-    if (st == KRYLOV_FALLBACK && c->opts.eig_driver == 5)
-        return ctx_fail(c, SDPSR_SOLVER_ERROR, "Krylov driver not applicable to this partition (" + c->err + ")");
+    else if (compression_eligible(c, n, d)) st = compressed_diagonalize(c, n, L, d, atol, info, sizes, S1, S, tm);
+    if (st == KRYLOV_FALLBACK && (c->opts.eig_driver == 5 || c->opts.eig_driver == 6))
+        return ctx_fail(c, SDPSR_SOLVER_ERROR, "requested driver not applicable to this partition (" + c->err + ")");
     const bool used_krylov = (st == SDPSR_OK);
     if (st != SDPSR_OK && st != KRYLOV_FALLBACK) return st;
   if (!used_krylov) {
-    st = eigen_decomposition_device(c, n, L, atol, info, tm);
+    st = dense_diagonalize(c, n, L, nullptr, atol, info, sizes, S1, S, tm);
     if (st) return st;
-
-    // irreducible_decomposition (src/eigen_decomposition.jl:295-348)
-    tm.begin(SDPSR_T_IRRED);
-    const int64_t ld = round_up(n, 128);
-    const int neig = (int)info.ptrs.size() - 1;
-    std::vector<int> roots;  // unique(Kpartition) in first-occurrence order (:303)
-    std::vector<std::vector<int>> members;
-    class_structure(info.kpart, roots, members);
-    sizes.assign(roots.size(), 0);
-    S1 = 0;
-    S = 0;
-    for (size_t p = 0; p < roots.size(); ++p) {
-        sizes[p] = (int32_t)members[p].size();
-        S1 += sizes[p];
-        S += (int64_t)sizes[p] * sizes[p];
-    }
-    double* Q = (double*)ctx_buf(c, "bd_q", (size_t)ld * ld * 8);
-    double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
-    if (!Q || !Qhat) return SDPSR_OUT_OF_MEMORY;
-    // first eigenvector of every eigenspace that sits in a merged class -> F; B = A3 * F
-    std::vector<int> fcol(neig, -1);
-    int nf = 0;
-    for (size_t p = 0; p < roots.size(); ++p)
-        if (members[p].size() > 1)
-            for (int j : members[p]) fcol[j] = nf++;
-    double* Bf = nullptr;
-    if (nf > 0) {
-        const int64_t nfp = round_up(nf, 128);
-        double* A3 = (double*)ctx_buf(c, "bd_a", (size_t)ld * ld * 8);
-        double* F = (double*)ctx_buf(c, "bd_f", (size_t)ld * nfp * 8);
-        Bf = (double*)ctx_buf(c, "bd_bf", (size_t)ld * nfp * 8);
-        if (!A3 || !F || !Bf) return SDPSR_OUT_OF_MEMORY;
-        launch_gather_f64_padded(s, n, ld, L, next_key(c), A3);  // generic element #3 (:306)
-        HIP_TRY(c, hipMemsetAsync(F, 0, (size_t)ld * nfp * 8, s));
-        for (int j = 0; j < neig; ++j)
-            if (fcol[j] >= 0)
-                HIP_TRY(c, hipMemcpyAsync(F + (size_t)fcol[j] * ld, Q + (size_t)info.ptrs[j] * ld, n * 8,
-                                          hipMemcpyDeviceToDevice, s));
-        launch_gemm_tn_f64(s, ld, nfp, ld, A3, ld, F, ld, Bf, ld, 1, 0, 0, 0);  // B = A3' F = A3 F
-    }
-    double* wv = (double*)ctx_buf(c, "bd_wv", (size_t)n * 8);
-    double* cv = (double*)ctx_buf(c, "bd_cv", (size_t)n * 8);
-    double* inv = (double*)ctx_buf(c, "bd_inv", 64);
-    if (!wv || !cv || !inv) return SDPSR_OUT_OF_MEMORY;
-    int64_t col = 0;
-    for (size_t p = 0; p < roots.size(); ++p) {
-        const int i = roots[p];
-        const int64_t mi = info.ptrs[i + 1] - info.ptrs[i];
-        // first member: P1 = I -> first eigenvector of Ei (:311-313, :326)
-        launch_copy_col(s, n, Q + (size_t)info.ptrs[i] * ld, Qhat + (size_t)col * n);
-        ++col;
-        for (size_t q = 1; q < members[p].size(); ++q) {
-            const int j = members[p][q];
-            const int64_t mj = info.ptrs[j + 1] - info.ptrs[j];
-            // first column of P_blk = block(A,Ei,Ej)' is Qj' (A q_i1)             (:333)
-            launch_gemv_t(s, n, ld, Q, info.ptrs[j], mj, Bf + (size_t)fcol[i] * ld, wv);
-            // norm(P_blk[1,:]) = || Qi' (A q_j1) ||                              (:335)
-            launch_gemv_t(s, n, ld, Q, info.ptrs[i], mi, Bf + (size_t)fcol[j] * ld, cv);
-            launch_inv_norm(s, mi, cv, inv);
-            // column of P_hat = Qj * first column of the normalised block       (:338-344)
-            launch_gemv_n_scaled(s, n, ld, Q, info.ptrs[j], mj, wv, inv, Qhat + (size_t)col * n);
-            ++col;
-        }
-    }
-    launch_clamptol(s, n * S1, Qhat, atol);  // src/diagonalize.jl:39
-    tm.end();
-    HIP_TRY(c, hipGetLastError());
   }
 
+    dbg_mark("block_diagonalize: diagonalize done");
     // check_block_sizes (src/diagonalize.jl:1-11)
     int64_t final_dim = 0;
     for (int32_t sz : sizes) final_dim += (int64_t)sz * (sz + 1) / 2;

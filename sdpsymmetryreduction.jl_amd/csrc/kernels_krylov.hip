@@ -69,9 +69,9 @@ constexpr int LZ_THREADS = 1024;
 __global__ void __launch_bounds__(LZ_THREADS)
 lanczos_orth_kernel(int n, int64_t ld, double* __restrict__ H, int64_t hstride, const int* __restrict__ tcur,
                     const double* __restrict__ W, int64_t ldw, const int* __restrict__ active,
-                    double* __restrict__ alpha_out, double* __restrict__ beta_out) {
+                    double* __restrict__ alpha_out, double* __restrict__ beta_out, double* __restrict__ nin_out) {
     const int r = blockIdx.x;
-    if (!active[r]) return;
+    if (active && !active[r]) return;
     extern __shared__ __attribute__((aligned(16))) double s_w[];  // n doubles: the vector being orthogonalised
     __shared__ double s_c[512];        // coefficients of the current pass (t + 1 <= 512)
     __shared__ double s_alpha;
@@ -79,8 +79,24 @@ lanczos_orth_kernel(int n, int64_t ld, double* __restrict__ H, int64_t hstride, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = tcur[r];
     double* Hr = H + (int64_t)r * hstride;
-    for (int i = tid; i < n; i += LZ_THREADS) s_w[i] = W[i + (int64_t)r * ldw];
+    double sq0 = 0;
+    for (int i = tid; i < n; i += LZ_THREADS) {
+        const double v = W[i + (int64_t)r * ldw];
+        s_w[i] = v;
+        sq0 = fma(v, v, sq0);
+    }
     if (tid == 0) s_alpha = 0.0;
+    if (nin_out) {  // norm of the incoming vector (rank decisions of the module-compression driver)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq0 += __shfl_down(sq0, o, 64);
+        if (lane == 0) s_red[wave] = sq0;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0;
+            for (int q = 0; q < LZ_THREADS / 64; ++q) tot += s_red[q];
+            nin_out[r] = sqrt(tot);
+        }
+    }
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
         // c[h] = H[:,h] . w : one wave per stored vector
@@ -122,7 +138,8 @@ lanczos_orth_kernel(int n, int64_t ld, double* __restrict__ H, int64_t hstride, 
     for (int i = tid; i < n; i += LZ_THREADS) hn[i] = s_w[i] * inv;
 }
 void launch_lanczos_orth(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const int* tcur,
-                         double* W, int64_t ldw, const int* active, int nruns, double* alpha_out, double* beta_out) {
+                         double* W, int64_t ldw, const int* active, int nruns, double* alpha_out, double* beta_out,
+                         double* nin_out) {
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&lanczos_orth_kernel),
@@ -130,7 +147,7 @@ void launch_lanczos_orth(hipStream_t s, int64_t n, int64_t ld, double* H, int64_
         attr_set = true;
     }
     lanczos_orth_kernel<<<nruns, LZ_THREADS, (size_t)n * sizeof(double), s>>>((int)n, ld, H, hstride, tcur, W, ldw, active,
-                                                                            alpha_out, beta_out);
+                                                                            alpha_out, beta_out, nin_out);
 }
 
 // H_r[:, 0] = X[:, r] / ||X[:, r]||, norm0[r] = ||X[:, r]||   (one block per run)
@@ -208,6 +225,57 @@ __global__ void random_vector_kernel(int n, uint64_t key, double* __restrict__ x
 }
 void launch_random_vector(hipStream_t s, int64_t n, uint64_t key, double* x) {
     random_vector_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((int)n, key, x);
+}
+
+// B <- (B + B') / 2 on the leading m x m part (ld), in place
+__global__ void symmetrize_kernel(int m, int64_t ld, double* __restrict__ B) {
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && j < m && i > j) {
+        const double v = 0.5 * (B[i + (int64_t)j * ld] + B[j + (int64_t)i * ld]);
+        B[i + (int64_t)j * ld] = v;
+        B[j + (int64_t)i * ld] = v;
+    }
+}
+void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B) {
+    dim3 b(32, 8), g((unsigned)((m + 31) / 32), (unsigned)((m + 7) / 8));
+    symmetrize_kernel<<<g, b, 0, s>>>((int)m, ld, B);
+}
+
+// out[:, c] = beta * out[:, c] + alpha * sum_{t < kk} In[:, t] * S[t + c * lds]   (tall-skinny times small)
+__global__ void tall_times_small_kernel(int n, int64_t ldi, const double* __restrict__ In, int kk,
+                                        const double* __restrict__ S, int lds_, double alpha, double beta,
+                                        double* __restrict__ out, int64_t ldo) {
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* sc = S + (int64_t)c * lds_;
+    double acc = 0;
+    for (int t = 0; t < kk; ++t) acc = fma(In[(int64_t)t * ldi + i], sc[t], acc);
+    double* o = out + i + (int64_t)c * ldo;
+    *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc;
+}
+void launch_tall_times_small(hipStream_t s, int64_t n, int64_t ldi, const double* In, int kk, const double* S,
+                             int lds_, int ncols, double alpha, double beta, double* out, int64_t ldo) {
+    if (ncols <= 0) return;
+    dim3 g((unsigned)((n + 255) / 256), (unsigned)ncols);
+    tall_times_small_kernel<<<g, 256, 0, s>>>((int)n, ldi, In, kk, S, lds_, alpha, beta, out, ldo);
+}
+
+// C[e] = sum_z P[z * stride + e]  (split-K partial sums, fixed order)
+__global__ void splitk_reduce_kernel(int64_t len, int Z, int64_t stride, const double* __restrict__ P,
+                                     double* __restrict__ C) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += step) {
+        double acc = 0;
+        for (int z = 0; z < Z; ++z) acc += P[(int64_t)z * stride + e];
+        C[e] = acc;
+    }
+}
+void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C) {
+    int64_t g = (len + 255) / 256;
+    if (g > 2048) g = 2048;
+    splitk_reduce_kernel<<<(unsigned)g, 256, 0, s>>>(len, Z, stride, P, C);
 }
 
 }  // namespace sdpsr

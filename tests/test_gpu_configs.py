@@ -135,3 +135,40 @@ def test_krylov_driver_refuses_generic_partition(pkg, problems):
     with pkg.Context(seed=3) as ctx:
         ne, nc = pkg.eigen_decomposition(P, atol=1e-8, ctx=ctx)
         assert ne == n
+
+
+@pytest.mark.parametrize("name", ["circ256", "er7xK8", "circ1024", "er5xK20"])
+def test_module_compression_driver_agrees_with_dense(pkg, problems, oracle, golden, name):
+    """eig_driver 4 = dense on the n x n generic element, 6 = module compression (dense on the
+    w x w restriction to a cyclic module, w < 2 dim(P)), the default when dim(P) << n."""
+    if name == "er7xK8":
+        L, d = problems.kron_with_complete(golden["er7_P"].astype(np.int64), 8, seed=5)
+        expect = sorted([2, 2, 2, 2, 3] * 2)
+    elif name == "er5xK20":
+        L, d = problems.kron_with_complete(golden["er5_P"].astype(np.int64), 20, seed=6)
+        expect = sorted([2, 2, 2, 3] * 2)
+    elif name == "circ1024":
+        L, d = problems.synthetic_jordan_partition(1024, seed=4)
+        expect = [1] * d
+    else:
+        L = golden[f"{name}_P"].astype(np.int64)
+        d = int(L.max())
+        expect = list(golden[f"{name}_blk"])
+    P = pkg.Partition(d, L.astype(np.uint32))
+    Po = oracle.Partition(d, L)
+    x = np.random.default_rng(8).random(d)
+    for drv in (4, 6):
+        for seed in (3, 4):
+            with pkg.Context(seed=seed, eig_driver=drv) as ctx:
+                bd = pkg.blockDiagonalize(P, ctx=ctx)
+            assert sorted(bd.blkSizes) == expect, (name, drv)
+            full, blk = oracle.spectrum_invariant(Po, bd.blks, x)
+            assert len(full) == len(blk), (name, drv)
+            assert np.allclose(full, blk, rtol=1e-6, atol=1e-8), (name, drv)
+            for q in bd.Q_hat:  # orthonormal columns inside every block
+                q = np.asarray(q)
+                assert np.abs(q.T @ q - np.eye(q.shape[1])).max() < 1e-7
+            ref = oracle.basis_image_fast([np.asarray(q) for q in bd.Q_hat], Po)
+            for i in range(0, d, max(1, d // 7)):
+                for k in range(len(bd.blkSizes)):
+                    assert np.allclose(bd.blks[i][k], ref[i][k], atol=1e-9)
