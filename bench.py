@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--mode", default="i8", choices=["i8", "f32", "f64"])
     ap.add_argument("--cpu-n", type=int, default=2048, help="order of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--eig-driver", type=int, default=0, help="0 auto (module compression when dim(P) << n), 4 dense eigensolver forced")
+    ap.add_argument("--skip-roofline", action="store_true", help="only the timed steps (clean rocprofv3 kernel statistics)")
     args = ap.parse_args()
 
     import torch
@@ -92,7 +94,7 @@ def main():
     tP = torch.empty(n * n, dtype=torch.int32, device=dev)
     golden = torch.from_numpy(np.ascontiguousarray(Ls.ravel(order="F")).astype(np.int32)).to(dev)
     mode = {"i8": L.SQUARE_I8, "f32": L.SQUARE_F32, "f64": L.SQUARE_F64}[args.mode]
-    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode)
+    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode, eig_driver=args.eig_driver)
     lib = ctx._lib
     atol = 1.4901161193847656e-08
     blk_buf = {}
@@ -170,7 +172,7 @@ def main():
     kernels = {}
     roof = None
     cpu = None
-    if rank == 0:
+    if rank == 0 and not args.skip_roofline:
         flops = 2.0 * n ** 3
         for name, kind, peak, unit in (("square_i8", 0, I8_MFMA_PEAK_TOPS, "TOP/s"), ("square_f32", 1, FP32_MFMA_PEAK_TF, "TFLOP/s"),
                                        ("gemm_f64", 2, FP64_MFMA_PEAK_TF, "TFLOP/s")):
