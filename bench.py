@@ -105,10 +105,11 @@ def main():
         return C.c_void_p(t.data_ptr()) if t is not None else None
 
     def one_step(check=False):
-        nonlocal iters_total
+        nonlocal iters_total, ctx
         dd = C.c_int64(0)
         it = C.c_int32(0)
         ms = (C.c_double * L.T_COUNT)()
+        lib = ctx._lib
         ctx.check(lib.sdpsr_admissible_subspace(ctx._h, n, vp(tCL), vp(tX0), vp(tU), r, atol, vp(tP), C.byref(dd),
                                                 C.byref(it), C.cast(ms, C.c_void_p), L.MEM_DEVICE))
         iters_total += it.value
@@ -141,6 +142,7 @@ def main():
         return nb.value
 
     def fence():
+        nonlocal ctx
         ctx.synchronize()
         torch.cuda.synchronize()
         if world > 1:
@@ -162,6 +164,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     one_step(check=True)  # results still correct after the timed region
+    phase_timed = phase.copy()
+    iters_timed = iters_total
+
+    # the same reduction with the dense eigensolver forced (hand-written tridiagonalisation on the
+    # full n x n element): reported beside the default driver, never as `value`
+    variants = {}
+    if rank == 0 and not args.skip_roofline and args.eig_driver == 0:
+        ctx_d = pkg.Context(device=local, seed=2000, square_mode=mode, eig_driver=4)
+        saved = ctx
+        ctx = ctx_d
+        lib_d = ctx_d._lib  # noqa: F841
+        try:
+            one_step(check=True)
+            fence()
+            td = time.perf_counter()
+            for _ in range(3):
+                one_step()
+            fence()
+            dtd = (time.perf_counter() - td) / 3
+            variants["dense_eigensolver"] = {"value": round(1.0 / dtd, 4), "ms_per_step": round(dtd * 1e3, 3), "steps": 3,
+                                             "note": "eig_driver=4: diagonalize on the full n x n generic element"}
+        finally:
+            ctx = saved
+            ctx_d.close()
 
     # ---- roofline leg: per-launch duration of the hot kernels, HIP events on ctx's stream ----
     def prof(kind, nn, aux=0, reps=10):
@@ -204,10 +230,17 @@ def main():
             traffic = round(pj["traffic_bytes_per_launch"])
         except Exception:
             pass
-        roof = {"kernel": "sytrd_symv_kernel (tridiagonalisation column dots, n-1 launches per reduction)", "bound": "hbm",
-                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(avg_bytes),
-                "algorithmic": "8*(n-j-1)^2 bytes for column j; average 8*n*(2n-1)/6 bytes per launch"}
+        roof_dense = {"kernel": "sytrd_symv_kernel (dense driver: tridiagonalisation column dots, n-1 launches)", "bound": "hbm",
+                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                      "algorithmic_bytes_per_launch": round(avg_bytes)}
+        kernels["sytrd_symv"]["roofline_dense_driver"] = roof_dense
+        # default path: by the rocprofv3 kernel statistics (profiles/) the largest single kernel of a
+        # reduction is the int8 square (one launch, 4 channels): 2*N^3 integer ops per channel
+        ki8 = kernels["square_i8"]
+        roof = {"kernel": "gemm_tn_kernel<i8> (random squares, 4 channels per launch)", "bound": "mfma",
+                "achieved": ki8["achieved"], "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": ki8["frac"], "traffic": None,
+                "frac_of_fp32_mfma_peak": ki8["frac_of_fp32_mfma_peak"],
+                "algorithmic": "2*N^3 int8 multiply-adds (as ops) per channel; one launch = channels x 2*N^3"}
         if args.cpu_n > 0:
             cb = cpu_baseline(pr, args.cpu_n, seed=1)
             scale = (n / cb["n"]) ** 3
@@ -226,11 +259,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[3]: synthetic Jordan algebra N={n}, {d} basis matrices (circulant Z_32 (x) K_128 scheme, seeded permutation), "
                                    f"square_mode={args.mode}, 4 channels", "N": n, "dim": int(d), "restarts_per_step": world,
-                       "iterations_per_reduction": iters_total / max(1, args.steps)},
-            "phase_ms_per_step": {k: round(phase[i] / args.steps, 3) for k, i in
+                       "iterations_per_reduction": iters_timed / max(1, args.steps)},
+            "phase_ms_per_step": {k: round(phase_timed[i] / args.steps, 3) for k, i in
                                   (("project", L.T_PROJECT), ("square", L.T_SQUARE), ("refine", L.T_REFINE), ("eigen", L.T_EIGEN),
                                    ("iso_QtAQ", L.T_ISO), ("irreducible", L.T_IRRED), ("basis_image", L.T_IMAGE))},
-            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roof, "kernels": kernels, "variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     ctx.close()

@@ -1059,6 +1059,9 @@ void launch_lanczos_orth(hipStream_t s, int64_t n, int64_t ld, double* H, int64_
                          double* nin_out);
 void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B);
 void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
+size_t label_spmm_partial_doubles(int64_t n, int w);
+bool launch_label_spmm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, int64_t d, const double* W,
+                       int64_t ldw, int w, double* partials, double* Y, int64_t ldy);
 void launch_tall_times_small(hipStream_t s, int64_t n, int64_t ldi, const double* In, int kk, const double* S,
                              int lds_, int ncols, double alpha, double beta, double* out, int64_t ldo);
 void launch_lanczos_init(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const double* X,
@@ -1517,17 +1520,30 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     const int64_t wcap = round_up(wmax + 2, 128);
     uint32_t* flag = (uint32_t*)ctx_buf(c, "bd_flag", 64);
     double* W = (double*)ctx_buf(c, "cm_w", (size_t)ld * wcap * 8);
-    double* A = (double*)ctx_buf(c, "cm_a", (size_t)ld * ld * 8);
     double* T = (double*)ctx_buf(c, "cm_t", (size_t)ld * wcap * 8);
     double* zy = (double*)ctx_buf(c, "cm_zy", (size_t)ld * 2 * 8);
     double* dout = (double*)ctx_buf(c, "cm_out", 64);
-    if (!flag || !W || !A || !T || !zy || !dout) return SDPSR_OUT_OF_MEMORY;
+    if (!flag || !W || !T || !zy || !dout) return SDPSR_OUT_OF_MEMORY;
     launch_check_symmetric(s, n, L, flag);
     uint32_t* hflag = (uint32_t*)c->pinned;
     HIP_TRY(c, hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     if (hflag[0]) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
                                   "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
+    // Y <- A W for a fresh generic element A: fused label product when the shape allows it,
+    // gather + split-K MFMA GEMM otherwise.  Columns >= wcols of dst keep their old content.
+    auto apply_generic = [&](int wcols, double* dst) -> int {
+        const uint64_t key = next_key(c);
+        if (wcols <= 64 && d <= 4000) {
+            double* part = (double*)ctx_buf(c, "cm_part", label_spmm_partial_doubles(n, 64) * 8);
+            if (!part) return SDPSR_OUT_OF_MEMORY;
+            if (launch_label_spmm(s, n, L, key, d, W, ld, wcols, part, dst, ld)) return SDPSR_OK;
+        }
+        double* Afull = (double*)ctx_buf(c, "cm_a", (size_t)ld * ld * 8);
+        if (!Afull) return SDPSR_OUT_OF_MEMORY;
+        launch_gather_f64_padded(s, n, ld, L, key, Afull);
+        return gemm_tn_splitk(c, ld, round_up(wcols, 128), ld, Afull, ld, W, ld, dst, ld);
+    };
     dbg_mark("compressed: buffers + symmetric check done");
     tm.begin(SDPSR_T_EIGEN);
     HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)ld * wcap * 8, s));
@@ -1606,9 +1622,10 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         const int m = 2 * w;
         const int64_t mp = 2 * wpp;
         // candidates: Y[:, 0:w] = A_a W, Y[:, wpp : wpp + w] = A_b W
+        HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * mp * 8, s));
         for (int half = 0; half < 2; ++half) {
-            launch_gather_f64_padded(s, n, ld, L, next_key(c), A);
-            gemm_tn_splitk(c, ld, wpp, ld, A, ld, W, ld, Y + (size_t)half * wpp * ld, ld);
+            int e2 = apply_generic(w, Y + (size_t)half * wpp * ld);
+            if (e2) return e2;
         }
         // scale reference: the candidates before projection (after it, a complete module leaves
         // only rounding noise and a relative test would compare noise with noise)
@@ -1663,8 +1680,8 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     dbg_mark("compressed: module grown");
     ElemGen gen;
     gen.make = [&](double* dst) -> int {
-        launch_gather_f64_padded(s, n, ld, L, next_key(c), A);
-        gemm_tn_splitk(c, ld, wp, ld, A, ld, W, ld, T, ld);    // T = A W
+        HIP_TRY(c, hipMemsetAsync(T, 0, (size_t)ld * wp * 8, s));
+        { int e2 = apply_generic(w, T); if (e2) return e2; }   // T = A W
         gemm_tn_splitk(c, wp, wp, ld, W, ld, T, ld, dst, wp);  // B = W' T  (wp x wp)
         launch_symmetrize(s, w, wp, dst);
         return SDPSR_OK;
@@ -1845,6 +1862,31 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     double* out = out_dev(c, "bd_blks", blks, (size_t)d * S, mem, &st);
     if (st || !L || !Qhat || !Qrm) return st ? st : SDPSR_OUT_OF_MEMORY;
     launch_transpose_to_rowmajor(s, n, S1, Qhat, Qrm);
+    const double atol = 1e-12 * (double)n;  // basis_image default atol (src/diagonalize.jl:67)
+    if (basis_image_two_stage_fits(n, d, S1)) {
+        // two-stage form (row sums per class in LDS, then s_k x s_k dots): no sort needed
+        const int nb = (int)c->bd_sizes.size();
+        std::vector<int32_t> hcol(nb), hsz(nb);
+        std::vector<int64_t> hoff(nb);
+        int64_t colbase = 0, off = 0;
+        for (int k2 = 0; k2 < nb; ++k2) {
+            hcol[k2] = (int32_t)colbase;
+            hsz[k2] = c->bd_sizes[k2];
+            hoff[k2] = off;
+            colbase += hsz[k2];
+            off += (int64_t)hsz[k2] * hsz[k2];
+        }
+        int32_t* d_col = (int32_t*)ctx_buf(c, "bi_col", (size_t)nb * 4);
+        int32_t* d_sz = (int32_t*)ctx_buf(c, "bi_sz", (size_t)nb * 4);
+        int64_t* d_off = (int64_t*)ctx_buf(c, "bi_off", (size_t)nb * 8);
+        double* Tb = (double*)ctx_buf(c, "bi_T", (size_t)d * n * S1 * 8);
+        if (!d_col || !d_sz || !d_off || !Tb) return SDPSR_OUT_OF_MEMORY;
+        st = h2d_sync(c, d_col, hcol.data(), (size_t)nb * 4);
+        if (!st) st = h2d_sync(c, d_sz, hsz.data(), (size_t)nb * 4);
+        if (!st) st = h2d_sync(c, d_off, hoff.data(), (size_t)nb * 8);
+        if (st) return st;
+        launch_basis_image_two_stage(s, n, d, S1, S, nb, L, Qrm, Tb, d_col, d_sz, d_off, atol, out);
+    } else {
     // _constraints(P): entries grouped by class (src/diagonalize.jl:42-50)
     uint32_t* ent = nullptr;
     int64_t* class_ptr = nullptr;  // host, size d+2: class_ptr[l]..class_ptr[l+1] = label l
@@ -1892,9 +1934,9 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
         HIP_TRY(c, hipMemcpyAsync(d_dA, dA.data(), S * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemcpyAsync(d_dB, dB.data(), S * 4, hipMemcpyHostToDevice, s));
     }
-    const double atol = 1e-12 * (double)n;  // basis_image default atol (src/diagonalize.jl:67)
     launch_basis_image(s, n, d, S1, S, Qrm, ent, nullptr, d_dA, d_dB, d_chunk_ptr, nch, nullptr, d_cb, d_ce,
                        partial, out, atol);
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(s));  // host vectors above must outlive the copies
     st = out_finish(c, blks, out, (size_t)d * S, mem);

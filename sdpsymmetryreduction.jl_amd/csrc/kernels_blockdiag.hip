@@ -214,6 +214,106 @@ void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t
                                                                    out);
 }
 
+// ---------------------------------------------------------------------------
+// basis_image, two-stage form for symmetric partitions (the only ones diagonalize accepts):
+//   stage 1   T[i][r][:] = sum over c with L[c,r] == i of Qhat[c,:]      ( = (1[P==i] Qhat)[r,:] )
+//             one wave per row r: the wave walks column r of L (contiguous), lanes own the S1
+//             columns of Qhat, per-class accumulators live in LDS (d x S1 doubles, single
+//             wave => plain read-modify-write, fixed order, bitwise reproducible);
+//   stage 2   blks[i][k] = Q_k' T_i[:, cols_k]   (s_k x s_k dots over n).
+// Work n^2 S1 + d n sum s_k^2 instead of n^2 sum s_k^2 gathers.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, const double* __restrict__ Qrm,
+                        double* __restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [(d + 1)][S1]
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x;
+    const int tot = (d + 1) * S1;
+    for (int t = lane; t < tot; t += 64) s_acc[t] = 0.0;
+    __syncthreads();
+    const uint32_t* col = L + (int64_t)r * n;  // column r of L == row r (symmetric partition)
+    for (int j0 = 0; j0 < S1; j0 += 64) {      // column chunks of Qhat (S1 <= 64 in practice)
+        const int j = j0 + lane;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int cc = c0 + lane;
+            const uint32_t mylab = (cc < n) ? col[cc] : 0u;
+            const int lim = (n - c0 < 64) ? n - c0 : 64;
+            for (int u = 0; u < lim; u += 4) {
+                // four rows of Qhat in flight per lane
+                double q[4];
+                uint32_t lb[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int uu = (u + v < lim) ? u + v : lim - 1;
+                    lb[v] = __shfl(mylab, uu, 64);
+                    q[v] = (j < S1 && u + v < lim) ? Qrm[(int64_t)(c0 + uu) * S1 + j] : 0.0;
+                }
+                if (j < S1) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (u + v < lim) s_acc[lb[v] * S1 + j] += q[v];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // T[i][r][:], classes 1..d
+    for (int t = lane; t < d * S1; t += 64) {
+        const int i = t / S1, j = t - i * S1;
+        T[((int64_t)i * n + r) * S1 + j] = s_acc[(i + 1) * S1 + j];
+    }
+}
+
+// grid (d, nblocks): out[i][off_k + a + b*s] = sum_r Qrm[r][cb_k + a] * T[i][r][cb_k + b]
+__global__ void __launch_bounds__(256)
+basis_image_blocks_kernel(int n, int S1, int64_t S, const double* __restrict__ Qrm, const double* __restrict__ T,
+                          const int32_t* __restrict__ blk_col, const int32_t* __restrict__ blk_size,
+                          const int64_t* __restrict__ blk_off, double atol, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int i = blockIdx.x, k = blockIdx.y;
+    const int s = blk_size[k], cb = blk_col[k];
+    const int ss = s * s;
+    const double* Ti = T + (int64_t)i * n * S1;
+    // thread = (pair p of the s*s outputs handled in passes, row group g)
+    for (int p0 = 0; p0 < ss; p0 += 16) {
+        const int p = p0 + (threadIdx.x & 15);
+        const int g = threadIdx.x >> 4;  // 16 row groups
+        double acc = 0;
+        if (p < ss) {
+            const int a = p % s, b = p / s;
+            for (int r = g; r < n; r += 16) acc = fma(Qrm[(int64_t)r * S1 + cb + a], Ti[(int64_t)r * S1 + cb + b], acc);
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < 16 && p < ss) {
+            double v = 0;
+            for (int gg = 0; gg < 16; ++gg) v += red[gg * 16 + threadIdx.x];
+            out[(int64_t)i * S + blk_off[k] + p] = (fabs(v) < atol) ? 0.0 : v;
+        }
+        __syncthreads();
+    }
+}
+
+bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1) {
+    return (d + 1) * S1 * 8 <= 60 * 1024 && d * n * S1 * 8 <= ((int64_t)4 << 30);
+}
+
+void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks,
+                                  const uint32_t* L, const double* Qrm, double* T, const int32_t* blk_col,
+                                  const int32_t* blk_size, const int64_t* blk_off, double atol, double* out) {
+    const size_t lds = (size_t)(d + 1) * S1 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    basis_image_rows_kernel<<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T);
+    dim3 g((unsigned)d, (unsigned)nblocks);
+    basis_image_blocks_kernel<<<g, 256, 0, s>>>((int)n, (int)S1, S, Qrm, T, blk_col, blk_size, blk_off, atol, out);
+}
+
 // Qrm[r * S1 + k] = Qcm[r + k * n]
 __global__ void transpose_to_rowmajor_kernel(int64_t n, int64_t S1, const double* __restrict__ Qcm,
                                              double* __restrict__ Qrm) {

@@ -278,4 +278,130 @@ void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, con
     splitk_reduce_kernel<<<(unsigned)g, 256, 0, s>>>(len, Z, stride, P, C);
 }
 
+// ---------------------------------------------------------------------------
+// Fused randomize! + product:  Y = A W  with  A[r,c] = value(L[r,c])  never materialised
+// (src/abstract_part.jl:107-110 fused into the products of the module-compression driver).
+// Reads the 4-byte labels once (coalesced along r), the per-class values come from a
+// d+1 entry table built in LDS from the counter-based generator, W is staged through LDS in
+// 128-row chunks and broadcast to the lanes.  Workgroup = 64 rows x (4 waves splitting the
+// columns); grid.y splits the column range further, partial sums are reduced in fixed order.
+// ---------------------------------------------------------------------------
+template <int WMAX>
+__global__ void __launch_bounds__(256)
+label_spmm_kernel(int n, const uint32_t* __restrict__ L, uint64_t key, int d, const double* __restrict__ W,
+                  int64_t ldw, int w, int cols_per_block, double* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sW = smem;                 // [128][WMAX]
+    double* sV = smem + 128 * WMAX;    // [d + 1] class values
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x * 64 + lane;
+    const int c_begin = blockIdx.y * cols_per_block;
+    int c_end = c_begin + cols_per_block;
+    if (c_end > n) c_end = n;
+    for (int i = tid; i <= d; i += 256) sV[i] = i ? sdpsr_class_uniform(key, (uint32_t)i) : 0.0;
+    double acc[WMAX];
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j) acc[j] = 0.0;
+    for (int c0 = c_begin; c0 < c_end; c0 += 128) {
+        __syncthreads();
+        for (int idx = tid; idx < 128 * WMAX; idx += 256) {  // zero-filled beyond w: no predicates below
+            const int j = idx >> 7, cl = idx & 127;
+            const int c = c0 + cl;
+            sW[cl * WMAX + j] = (j < w && c < c_end) ? W[c + (int64_t)j * ldw] : 0.0;
+        }
+        __syncthreads();
+        // wave `wave` owns local columns wave*32 .. wave*32+31; labels are fetched 8 columns ahead
+        // so that eight independent global loads are in flight per lane
+        for (int g8 = 0; g8 < 32; g8 += 8) {
+            const int clb = wave * 32 + g8;
+            uint32_t lab[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + clb + u;
+                lab[u] = (r < n && c < c_end) ? L[r + (int64_t)c * n] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double v = sV[lab[u]];
+                const double2* wr = reinterpret_cast<const double2*>(sW + (clb + u) * WMAX);
+#pragma unroll
+                for (int j2 = 0; j2 < WMAX / 2; ++j2) {
+                    const double2 ww = wr[j2];
+                    acc[2 * j2] = fma(v, ww.x, acc[2 * j2]);
+                    acc[2 * j2 + 1] = fma(v, ww.y, acc[2 * j2 + 1]);
+                }
+            }
+        }
+    }
+    // sum the four waves (they own disjoint column subsets) through LDS, wave 0 writes
+    for (int wv = 1; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int j = 0; j < WMAX; ++j)
+                if (j < w) sW[lane * WMAX + j] = acc[j];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < WMAX; ++j)
+                if (j < w) acc[j] += sW[lane * WMAX + j];
+        }
+    }
+    if (wave == 0 && r < n) {
+        double* p = P + (int64_t)blockIdx.y * n * w;
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j)
+            if (j < w) p[r + (int64_t)j * n] = acc[j];
+    }
+}
+
+// Y[r + j*ldy] = sum_z P[z][r + j*n]
+__global__ void label_spmm_reduce_kernel(int n, int w, int Z, const double* __restrict__ P,
+                                         double* __restrict__ Y, int64_t ldy) {
+    const int64_t total = (int64_t)n * w;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+        const int64_t j = e / n, r = e - j * n;
+        double acc = 0;
+        for (int z = 0; z < Z; ++z) acc += P[(int64_t)z * total + e];
+        Y[r + j * ldy] = acc;
+    }
+}
+
+size_t label_spmm_partial_doubles(int64_t n, int w) {
+    int zg = (int)(768 / ((n + 63) / 64));
+    if (zg < 1) zg = 1;
+    if (zg > 32) zg = 32;
+    return (size_t)zg * n * w;
+}
+
+// returns false when the shape is not supported (w > 64 or the class table does not fit in LDS)
+bool launch_label_spmm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, int64_t d, const double* W,
+                       int64_t ldw, int w, double* partials, double* Y, int64_t ldy) {
+    if (w < 1 || w > 64 || d > 4000) return false;
+    const int rb = (int)((n + 63) / 64);
+    int zg = 768 / rb;
+    if (zg < 1) zg = 1;
+    if (zg > 32) zg = 32;
+    int cpb = (int)((n + zg - 1) / zg);
+    cpb = (cpb + 127) / 128 * 128;
+    zg = (int)((n + cpb - 1) / cpb);
+    dim3 g((unsigned)rb, (unsigned)zg);
+    auto go = [&](auto kern, int wmax) {
+        const size_t lds = ((size_t)128 * wmax + (size_t)d + 2) * sizeof(double);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        kern<<<g, 256, lds, s>>>((int)n, L, key, (int)d, W, ldw, w, cpb, partials);
+    };
+    if (w <= 8) go(label_spmm_kernel<8>, 8);
+    else if (w <= 16) go(label_spmm_kernel<16>, 16);
+    else if (w <= 32) go(label_spmm_kernel<32>, 32);
+    else if (w <= 48) go(label_spmm_kernel<48>, 48);
+    else go(label_spmm_kernel<64>, 64);
+    int64_t gr = ((int64_t)n * w + 255) / 256;
+    if (gr > 2048) gr = 2048;
+    label_spmm_reduce_kernel<<<(unsigned)gr, 256, 0, s>>>((int)n, w, zg, partials, Y, ldy);
+    return true;
+}
+
 }  // namespace sdpsr

@@ -167,6 +167,10 @@ void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t
                         int64_t nchunks_total, const int32_t* chunk_class,
                         const int64_t* chunk_begin, const int64_t* chunk_end, double* partial,
                         double* out, double atol);
+bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1);
+void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks,
+                                  const uint32_t* L, const double* Qrm, double* T, const int32_t* blk_col,
+                                  const int32_t* blk_size, const int64_t* blk_off, double atol, double* out);
 void launch_transpose_to_rowmajor(hipStream_t s, int64_t n, int64_t S1, const double* Qcm,
                                   double* Qrm);
 // stable sort of entries by label (label 0 dropped): ent sorted, hist[d+1]
