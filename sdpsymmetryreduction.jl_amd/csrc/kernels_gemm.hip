@@ -230,6 +230,192 @@ gemm_tn_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Variant with direct global->LDS loads (all three dtypes) (LDS-DMA, global_load_lds_dwordx4): no VGPR
+// staging and no ds_write pass.  K-tile = 128 bytes per operand row; one wave instruction
+// fills 8 rows x 128 B of the lane-linear LDS image, the XOR swizzle that makes the
+// ds_read_b128 fragment reads conflict-free is applied on the per-lane SOURCE address
+// (slot s of row r holds global chunk s ^ ((r >> 1) & 7)) and undone on the read.
+// Two LDS buffers (64 KiB): tile t+1 streams in while tile t feeds the MFMAs.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <int KIND>
+__global__ void __launch_bounds__(NT)
+gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag, int64_t lda,
+                   const typename GemmTraits<KIND>::in_t* __restrict__ Bg, int64_t ldb,
+                   typename GemmTraits<KIND>::out_t* __restrict__ Cg, int64_t ldc, int64_t strideA, int64_t strideB,
+                   int64_t strideC) {
+    typedef typename GemmTraits<KIND>::in_t in_t;
+    typedef typename GemmTraits<KIND>::out_t out_t;
+    constexpr int ES = sizeof(in_t);
+    constexpr int KB = 128;            // bytes of K per row per tile
+    constexpr int KE = KB / ES;
+    constexpr int OPB = BM * KB;       // 16 KiB per operand tile
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = wave >> 1;
+    const int64_t i0 = (int64_t)blockIdx.x * BM;
+    const int64_t j0 = (int64_t)blockIdx.y * BN;
+    const char* Ab = reinterpret_cast<const char*>(Ag + (int64_t)blockIdx.z * strideA + i0 * lda);
+    const char* Bb = reinterpret_cast<const char*>(Bg + (int64_t)blockIdx.z * strideB + j0 * ldb);
+    out_t* C = Cg + (int64_t)blockIdx.z * strideC;
+
+    // this wave issues instructions ii = wave*4 .. wave*4+3 of each operand tile
+    int64_t srcA[4], srcB[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int r = 8 * (wave * 4 + s) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        srcA[s] = (int64_t)r * lda * ES + c * 16;
+        srcB[s] = (int64_t)r * ldb * ES + c * 16;
+    }
+    auto issue = [&](int buf, int64_t kt) {
+        const int64_t kb = kt * KB;
+        char* base = smem + buf * 2 * OPB + (wave * 4) * 1024;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + srcA[s] + kb), (lds_void_t*)(base + s * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + srcB[s] + kb), (lds_void_t*)(base + OPB + s * 1024), 16, 0, 0);
+        }
+    };
+    const int64_t nk = k / KE;
+
+    if constexpr (KIND == KIND_I8 || KIND == KIND_F32) {
+        typedef typename std::conditional<KIND == KIND_I8, v16i, v16f>::type acc_t;
+        acc_t acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+        const int r32 = lane & 31, h = lane >> 5;
+        int rowA[2], rowB[2], swA[2], swB[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            rowA[t] = wi * 64 + t * 32 + r32;
+            rowB[t] = wj * 64 + t * 32 + r32;
+            swA[t] = (rowA[t] >> 1) & 7;
+            swB[t] = (rowB[t] >> 1) & 7;
+        }
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const int buf = (int)(kt & 1);
+            if (kt + 1 < nk) issue(buf ^ 1, kt + 1);
+            const char* tA = smem + buf * 2 * OPB;
+            const char* tB = tA + OPB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint4 fi[2], fj[2];
+                const int ch = 2 * q + h;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fi[t] = *reinterpret_cast<const uint4*>(tA + rowA[t] * KB + ((ch ^ swA[t]) << 4));
+                    fj[t] = *reinterpret_cast<const uint4*>(tB + rowB[t] * KB + ((ch ^ swB[t]) << 4));
+                }
+                if constexpr (KIND == KIND_I8) {
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti) {
+                            v4i a = {(int)fj[tj].x, (int)fj[tj].y, (int)fj[tj].z, (int)fj[tj].w};
+                            v4i b = {(int)fi[ti].x, (int)fi[ti].y, (int)fi[ti].z, (int)fi[ti].w};
+                            acc[tj][ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[tj][ti], 0, 0, 0);
+                        }
+                } else {
+                    const float* fjf0 = reinterpret_cast<const float*>(&fj[0]);
+                    const float* fjf1 = reinterpret_cast<const float*>(&fj[1]);
+                    const float* fif0 = reinterpret_cast<const float*>(&fi[0]);
+                    const float* fif1 = reinterpret_cast<const float*>(&fi[1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fjf0[e], fif0[e], acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fjf0[e], fif1[e], acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fjf1[e], fif0[e], acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fjf1[e], fif1[e], acc[1][1], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int64_t ii = i0 + wi * 64 + ti * 32 + r32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t jj = j0 + wj * 64 + tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    C[ii + jj * ldc] = acc[tj][ti][r];
+                }
+            }
+    } else {
+        v4d acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.0;
+        const int r16 = lane & 15, g = lane >> 4;
+        int rowA[4], rowB[4], swA[4], swB[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            rowA[t] = wi * 64 + t * 16 + r16;
+            rowB[t] = wj * 64 + t * 16 + r16;
+            swA[t] = (rowA[t] >> 1) & 7;
+            swB[t] = (rowB[t] >> 1) & 7;
+        }
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const int buf = (int)(kt & 1);
+            if (kt + 1 < nk) issue(buf ^ 1, kt + 1);
+            const char* tA = smem + buf * 2 * OPB;
+            const char* tB = tA + OPB;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                v2d fi[4], fj[4];
+                const int ch = 4 * q + g;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    fi[t] = *reinterpret_cast<const v2d*>(tA + rowA[t] * KB + ((ch ^ swA[t]) << 4));
+                    fj[t] = *reinterpret_cast<const v2d*>(tB + rowB[t] * KB + ((ch ^ swB[t]) << 4));
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                        for (int ti = 0; ti < 4; ++ti)
+                            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[tj][e], fi[ti][e], acc[tj][ti], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                const int64_t ii = i0 + wi * 64 + ti * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t jj = j0 + wj * 64 + tj * 16 + g + 4 * r;
+                    C[ii + jj * ldc] = acc[tj][ti][r];
+                }
+            }
+    }
+}
+
 template <int KIND>
 static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
                         const typename GemmTraits<KIND>::in_t* A, int64_t lda,
@@ -239,6 +425,20 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
     constexpr int KB = GemmTraits<KIND>::KB;
     constexpr size_t lds = 2 * 2 * BM * (KB + 16);
     dim3 grid((unsigned)(m / BM), (unsigned)(n / BN), (unsigned)batch);
+    constexpr int ESZ = sizeof(typename GemmTraits<KIND>::in_t);
+    if ((k * ESZ) % 128 == 0 && ((lda * ESZ) % 16) == 0 && ((ldb * ESZ) % 16) == 0 &&
+        ((strideA * ESZ) % 16) == 0 && ((strideB * ESZ) % 16) == 0 &&
+        (reinterpret_cast<uintptr_t>(A) % 16) == 0 && (reinterpret_cast<uintptr_t>(B) % 16) == 0) {
+        constexpr size_t lds_dma = 2 * 2 * BM * 128;  // 64 KiB
+        static bool dma_attr_set = false;
+        if (!dma_attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+            dma_attr_set = true;
+        }
+        gemm_tn_dma_kernel<KIND><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC);
+        return;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<KIND>),
