@@ -595,10 +595,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     // S = Part(CL); S = refine!(S, Part(X0L))   (:145-146)
     int64_t d = 0;
     tm.begin(SDPSR_T_REFINE);
-    launch_sig_f64(s, len, nullptr, dCL, sig);
-    st = refine_signatures(c, len, sig, L, &d);
-    if (st) return st;
-    launch_sig_f64(s, len, L, dX0, sig);
+    launch_sig_f64_pair(s, len, dCL, dX0, sig);  // both refinements in one canonical relabel
     st = refine_signatures(c, len, sig, L, &d);
     tm.end();
     if (st) return st;

@@ -302,6 +302,7 @@ label_spmm_kernel(int n, const uint32_t* __restrict__ L, uint64_t key, int d, co
     double acc[WMAX];
 #pragma unroll
     for (int j = 0; j < WMAX; ++j) acc[j] = 0.0;
+#pragma unroll 1
     for (int c0 = c_begin; c0 < c_end; c0 += 128) {
         __syncthreads();
         for (int idx = tid; idx < 128 * WMAX; idx += 256) {  // zero-filled beyond w: no predicates below
@@ -312,6 +313,7 @@ label_spmm_kernel(int n, const uint32_t* __restrict__ L, uint64_t key, int d, co
         __syncthreads();
         // wave `wave` owns local columns wave*32 .. wave*32+31; labels are fetched 8 columns ahead
         // so that eight independent global loads are in flight per lane
+#pragma unroll 1
         for (int g8 = 0; g8 < 32; g8 += 8) {
             const int clb = wave * 32 + g8;
             uint32_t lab[8];

@@ -321,6 +321,22 @@ void launch_sig_f64(hipStream_t s, int64_t len, const uint32_t* L, const double*
     sig_f64_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, v, sig);
 }
 
+// S = Part(a); S = refine!(S, Part(b)) in one pass: the canonical relabel of the value pairs
+// (src/partitions.jl:145-146); label 0 only where both values are +0.0
+__global__ void sig_f64_pair_kernel(int64_t len, const double* __restrict__ a, const double* __restrict__ b,
+                                    uint64_t* __restrict__ sig) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const uint64_t ka = (uint64_t)__double_as_longlong(a[e]);
+        const uint64_t kb = (uint64_t)__double_as_longlong(b[e]);
+        uint64_t h = sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb);
+        sig[e] = finish_sig(0u, ka == 0 && kb == 0, h);
+    }
+}
+void launch_sig_f64_pair(hipStream_t s, int64_t len, const double* a, const double* b, uint64_t* sig) {
+    sig_f64_pair_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, a, b, sig);
+}
+
 // v is a padded ld x ld matrix; output sig is dense n x n
 __global__ void sig_f64_rounded_kernel(int64_t n, int64_t ld, const uint32_t* __restrict__ L,
                                        const double* __restrict__ v, double atol, double scale,
@@ -425,6 +441,13 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned 
     return NO_SLOT;
 }
 
+// One workgroup dedups INSERT_CHUNK entries in an LDS table before touching the global one.
+// An entry whose LDS probe sequence gets long (many distinct signatures in the chunk) goes to
+// the global table directly instead.
+constexpr int INSERT_PER_THREAD = 16;
+constexpr int INSERT_CHUNK = REFINE_THREADS * INSERT_PER_THREAD;  // 4096 entries
+constexpr int LDS_MAX_PROBES = 24;
+
 __global__ void __launch_bounds__(REFINE_THREADS)
 refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
                      uint32_t* __restrict__ slot_out, unsigned long long* __restrict__ tab_sig,
@@ -432,40 +455,55 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
     __shared__ unsigned long long l_sig[LDS_SLOTS];
     __shared__ uint32_t l_min[LDS_SLOTS];
     __shared__ uint32_t l_gslot[LDS_SLOTS];
-    const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
-    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
+    for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x) {
         for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
             l_sig[i] = 0ull;
             l_min[i] = 0xFFFFFFFFu;
         }
         __syncthreads();
-        const int64_t base = blk * REFINE_BLOCK;
-        uint64_t my[REFINE_PER_THREAD];
-        int myslot[REFINE_PER_THREAD];
+        const int64_t base = blk * INSERT_CHUNK;
+        // >= 0: LDS slot; -1: zero signature; <= -2: already resolved global slot (-2 - g)
+        int myslot[INSERT_PER_THREAD];
 #pragma unroll
-        for (int q = 0; q < REFINE_PER_THREAD; ++q) {
-            // entry order inside the block does not matter for pass A
+        for (int q = 0; q < INSERT_PER_THREAD; ++q) {
             const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-            uint64_t sg = (e < len) ? sig[e] : 0ull;
-            my[q] = sg;
+            const uint64_t sg = (e < len) ? sig[e] : 0ull;
             myslot[q] = -1;
             if (sg) {
                 uint32_t idx = (uint32_t)(sg >> 40) & (LDS_SLOTS - 1);
-                while (true) {
+                int probes = 0;
+                bool placed = false;
+                while (probes < LDS_MAX_PROBES) {
                     unsigned long long cur = l_sig[idx];
-                    if (cur == sg) break;
+                    if (cur == sg) {
+                        placed = true;
+                        break;
+                    }
                     if (cur == 0ull) {
                         unsigned long long old = atomicCAS(&l_sig[idx], 0ull, (unsigned long long)sg);
-                        if (old == 0ull || old == sg) break;
+                        if (old == 0ull || old == sg) {
+                            placed = true;
+                            break;
+                        }
                     }
                     idx = (idx + 1) & (LDS_SLOTS - 1);
+                    ++probes;
                 }
-                atomicMin(&l_min[idx], (uint32_t)e);
-                myslot[q] = (int)idx;
+                if (placed) {
+                    atomicMin(&l_min[idx], (uint32_t)e);
+                    myslot[q] = (int)idx;
+                } else {
+                    const uint32_t g = global_find_or_insert(sg, tab_sig, mask, counters);
+                    if (g != NO_SLOT) {
+                        if (tab_min[g] > (uint32_t)e) atomicMin(&tab_min[g], (uint32_t)e);
+                        myslot[q] = -2 - (int)g;
+                    }
+                }
             }
         }
         __syncthreads();
-        // publish distinct signatures of this block
+        // publish distinct signatures of this chunk
         for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
             unsigned long long sg = l_sig[i];
             if (sg) {
@@ -482,9 +520,14 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < REFINE_PER_THREAD; ++q) {
+        for (int q = 0; q < INSERT_PER_THREAD; ++q) {
             const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-            if (e < len) slot_out[e] = (myslot[q] >= 0) ? l_gslot[myslot[q]] : NO_SLOT;
+            if (e < len) {
+                uint32_t out = NO_SLOT;
+                if (myslot[q] >= 0) out = l_gslot[myslot[q]];
+                else if (myslot[q] <= -2) out = (uint32_t)(-2 - myslot[q]);
+                slot_out[e] = out;
+            }
         }
         __syncthreads();
     }
@@ -608,7 +651,8 @@ void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* la
     hipMemsetAsync(ws.tab_min, 0xFF, cap * sizeof(uint32_t), s);
     hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint32_t), s);
     const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
-    const int g = (int)(nblk < 256 * 5 ? nblk : 256 * 5);
+    const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
+    const int g = (int)(nchunk < 256 * 5 ? nchunk : 256 * 5);
     refine_insert_kernel<<<g, REFINE_THREADS, 0, s>>>(len, sig, labels_out,
                                                       (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                       (uint32_t)(cap - 1), ws.counters);

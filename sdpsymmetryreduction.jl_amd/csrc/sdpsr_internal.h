@@ -94,6 +94,7 @@ void launch_proj_apply(hipStream_t s, int64_t len, int64_t r, const double* U, c
 
 // signatures.  sig = 0 <=> (L == 0 and key == 0).  L may be nullptr (all zero labels).
 void launch_sig_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* v, uint64_t* sig);
+void launch_sig_f64_pair(hipStream_t s, int64_t len, const double* a, const double* b, uint64_t* sig);
 void launch_sig_f64_rounded(hipStream_t s, int64_t n, int64_t ld, const uint32_t* L,
                             const double* v, double atol, double scale, uint64_t* sig);
 void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_t* k,
