@@ -166,6 +166,12 @@ int sdpsr_admissible_subspace_dense(sdpsr_ctx* ctx, int64_t n, int64_t m, const 
                                     uint32_t* P_out, int64_t* dim_out, int32_t* iters_out,
                                     double* phase_ms, int mem_out);
 
+/* ---- desymmetrize(P) / unSymmetrize, src/partitions.jl:197-223, src/compat.jl:70 -------------- */
+/* WL-type refinement with products X*Y of two independent random elements until the dimension
+   stalls: P (n x n labels) is refined in place, *dim updated, *iters (may be NULL) = rounds.
+   The products are evaluated exactly (int8 channels), like the squares of admissible_subspace. */
+int sdpsr_desymmetrize(sdpsr_ctx* ctx, int64_t n, uint32_t* P, int64_t* dim, int32_t* iters, int mem);
+
 /* ---- blockDiagonalize, src/compat.jl:46-68 ---------------------------------- */
 /* Phase 1 = diagonalize(Float64, P; atol=epsilon) (src/diagonalize.jl:25-40) +
    check_block_sizes (:1-11).  Keeps Q_hat on the device inside ctx.

@@ -294,6 +294,22 @@ def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, se
     return out
 
 
+def desymmetrize(P, ctx=None):
+    """``desymmetrize(P)`` (src/partitions.jl:197-223); returns a new Partition."""
+    ctx = _ctx(ctx)
+    n = P.shape[0]
+    lab = _f(P.matrix, np.uint32).copy()
+    d = C.c_int64(P.nparts)
+    it = C.c_int32(0)
+    ctx.check(ctx._lib.sdpsr_desymmetrize(ctx._h, n, _ptr(lab), C.byref(d), C.byref(it), L.MEM_HOST))
+    out = Partition(d.value, lab.reshape(P.shape, order="F"))
+    out.iterations = it.value
+    return out
+
+
+unSymmetrize = desymmetrize  # src/compat.jl:70
+
+
 # ---------------------------------------------------------------------------
 # blockDiagonalize
 # ---------------------------------------------------------------------------

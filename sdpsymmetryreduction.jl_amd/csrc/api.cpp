@@ -688,6 +688,45 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     return SDPSR_OK;
 }
 
+// desymmetrize, src/partitions.jl:197-223
+int sdpsr_desymmetrize(sdpsr_ctx* c, int64_t n, uint32_t* P, int64_t* dim, int32_t* iters, int mem) {
+    CHECK_CTX(c);
+    if (!P || !dim || n < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    uint32_t* L = (mem == SDPSR_MEM_DEVICE) ? P : (uint32_t*)in_dev(c, "adm_labels", (const uint32_t*)P, len, mem, &st);
+    if (st) return st;
+    const int T = c->opts.channels;
+    const int64_t ld = round_up(n, 128);
+    uint32_t* Lt = (uint32_t*)ctx_buf(c, "des_lt", len * 4);
+    int8_t* X = (int8_t*)ctx_buf(c, "adm_xi8", (size_t)T * ld * ld);
+    int8_t* Y = (int8_t*)ctx_buf(c, "des_yi8", (size_t)T * ld * ld);
+    int32_t* Cp = (int32_t*)ctx_buf(c, "adm_ci32", (size_t)T * ld * ld * 4);
+    uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+    if (!Lt || !X || !Y || !Cp || !sig) return SDPSR_OUT_OF_MEMORY;
+    int64_t current = *dim;
+    int it = 0;
+    for (;;) {  // :208-220
+        if (it >= c->opts.max_iters) return ctx_fail(c, SDPSR_NOT_CONVERGED, "max_iters reached");
+        ++it;
+        launch_transpose_labels(s, n, L, Lt);
+        launch_gather_i8(s, n, ld, T, Lt, next_key(c), X);  // X' as the K-contiguous operand
+        launch_gather_i8(s, n, ld, T, L, next_key(c), Y);
+        launch_gemm_tn_i8(s, ld, ld, ld, X, ld, Y, ld, Cp, ld, T, ld * ld, ld * ld, ld * ld);  // (X')' Y = X Y
+        launch_sig_i32(s, n, ld, T, L, Cp, sig);
+        int64_t d2 = 0;
+        st = refine_signatures(c, len, sig, L, &d2);
+        if (st) return st;
+        if (d2 == current) break;
+        current = d2;
+    }
+    *dim = current;
+    if (iters) *iters = it;
+    return out_finish(c, P, L, len, mem);
+}
+
 // Host setup stage for dense problems, src/partitions.jl:117-142.
 int sdpsr_admissible_subspace_dense(sdpsr_ctx* c, int64_t n, int64_t m, const double* C,
                                     const double* A, const double* b, double atol, uint32_t* P_out,

@@ -259,8 +259,25 @@ gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 1, wj = wave >> 1;
-    const int64_t i0 = (int64_t)blockIdx.x * BM;
-    const int64_t j0 = (int64_t)blockIdx.y * BN;
+    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so
+    // ids b and b+8 share an L2.  Give every XCD one contiguous range of the tile sequence and
+    // walk the tiles in 8-row groups, so the workgroups resident on an XCD at any time share
+    // operand rows through its L2.
+    int bi = blockIdx.x, bj = blockIdx.y;
+    {
+        const int gm = gridDim.x, gn = gridDim.y;
+        const int nwg = gm * gn;
+        if ((nwg & 7) == 0 && (gm & 7) == 0) {
+            const int lin = blockIdx.y * gm + blockIdx.x;
+            const int swz = (lin & 7) * (nwg >> 3) + (lin >> 3);
+            const int per_group = 8 * gn;
+            const int grp = swz / per_group, within = swz - grp * per_group;
+            bi = grp * 8 + (within & 7);
+            bj = within >> 3;
+        }
+    }
+    const int64_t i0 = (int64_t)bi * BM;
+    const int64_t j0 = (int64_t)bj * BN;
     const char* Ab = reinterpret_cast<const char*>(Ag + (int64_t)blockIdx.z * strideA + i0 * lda);
     const char* Bb = reinterpret_cast<const char*>(Bg + (int64_t)blockIdx.z * strideB + j0 * ldb);
     out_t* C = Cg + (int64_t)blockIdx.z * strideC;

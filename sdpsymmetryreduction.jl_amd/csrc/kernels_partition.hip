@@ -683,6 +683,27 @@ void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_
     check_symmetric_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, L, flag);
 }
 
+// Lt[k + i*n] = L[i + k*n]: 64 x 64 label tiles through LDS (both sides coalesced)
+__global__ void __launch_bounds__(256)
+transpose_labels_kernel(int n, const uint32_t* __restrict__ L, uint32_t* __restrict__ Lt) {
+    __shared__ uint32_t tile[64][65];
+    const int bi = blockIdx.x * 64, bk = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 rows of the tile per pass
+    for (int q = ty; q < 64; q += 4) {
+        const int i = bi + tx, kk = bk + q;
+        tile[q][tx] = (i < n && kk < n) ? L[i + (int64_t)kk * n] : 0u;
+    }
+    __syncthreads();
+    for (int q = ty; q < 64; q += 4) {
+        const int kk = bk + tx, i = bi + q;
+        if (kk < n && i < n) Lt[kk + (int64_t)i * n] = tile[tx][q];
+    }
+}
+void launch_transpose_labels(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* Lt) {
+    dim3 g((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
+    transpose_labels_kernel<<<g, 256, 0, s>>>((int)n, L, Lt);
+}
+
 // synthetic signatures with `nclasses` distinct non-zero values (measurement hook)
 __global__ void fill_test_sig_kernel(int64_t len, int64_t nclasses, uint64_t* __restrict__ sig) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -120,6 +120,7 @@ size_t refine_block_entries();
 void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out,
                    const RefineWs& ws);
 
+void launch_transpose_labels(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* Lt);
 // symmetric-labels check: flag[0] = 1 if some L[i,j] != L[j,i]
 void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag);
 

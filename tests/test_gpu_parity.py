@@ -230,6 +230,25 @@ def test_block_diagonalize_matches_pins(pkg, oracle, golden, gpu_ctx, name, eps)
             assert np.allclose(bd.blks[i][k], ref[i][k], atol=1e-10)
 
 
+def test_desymmetrize_triple_and_oracle(pkg, oracle, golden, gpu_ctx):
+    # test/runtests.jl:40: unSymmetrize(P1) == Partition(4, [1 3 3; 2 4 4; 2 4 4])
+    P1 = pkg.Partition.from_matrix(np.array([[1, 2, 2], [2, 3, 3], [2, 3, 3]]), ctx=gpu_ctx)
+    out = pkg.unSymmetrize(P1, ctx=gpu_ctx)
+    assert out.nparts == 4
+    assert np.array_equal(out.matrix, np.array([[1, 3, 3], [2, 4, 4], [2, 4, 4]]))
+    # the canonical result does not depend on the draws: compare with the oracle on real algebras
+    for name in ("petersen", "er3", "er5", "er7"):
+        L = golden[f"{name}_P"].astype(np.int64)
+        ref = oracle.desymmetrize(oracle.Partition(int(L.max()), L), rng=np.random.default_rng(1))
+        got = pkg.desymmetrize(pkg.Partition(int(L.max()), L.astype(np.uint32)), ctx=gpu_ctx)
+        assert got.nparts == ref.nparts, name
+        assert np.array_equal(got.matrix, ref.matrix), name
+    # a symmetric association scheme is already a coherent configuration: nothing to split
+    Lc = golden["circ256_P"].astype(np.int64)
+    got = pkg.desymmetrize(pkg.Partition(int(Lc.max()), Lc.astype(np.uint32)), ctx=gpu_ctx)
+    assert got.nparts == int(Lc.max()) and np.array_equal(got.matrix, Lc)
+
+
 def test_cyclic_c3_raises_invalid_field(pkg, gpu_ctx):
     # test/runtests.jl:50-56
     C3 = np.array([[1, 3, 2], [2, 1, 3], [3, 2, 1]])
