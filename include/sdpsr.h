@@ -172,6 +172,13 @@ int sdpsr_admissible_subspace_dense(sdpsr_ctx* ctx, int64_t n, int64_t m, const 
    The products are evaluated exactly (int8 channels), like the squares of admissible_subspace. */
 int sdpsr_desymmetrize(sdpsr_ctx* ctx, int64_t n, uint32_t* P, int64_t* dim, int32_t* iters, int mem);
 
+/* ---- reduced-SDP assembly, README.md:57-60, test/sd_problems.jl:32-37 ------------------------- */
+/* out = A * PMat with PMat = hcat(vec(P.matrix .== i) for i = 1:d): the columns of A summed per
+   class.  A: m x len column-major (dense), labels: len, out: m x d column-major.  C' * PMat is the
+   m = 1 case.  Sparse A stays with the caller (one sparse-times-indicator product). */
+int sdpsr_reduce_constraints(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, int64_t d, int64_t m,
+                             const double* A, double* out, int mem);
+
 /* ---- blockDiagonalize, src/compat.jl:46-68 ---------------------------------- */
 /* Phase 1 = diagonalize(Float64, P; atol=epsilon) (src/diagonalize.jl:25-40) +
    check_block_sizes (:1-11).  Keeps Q_hat on the device inside ctx.

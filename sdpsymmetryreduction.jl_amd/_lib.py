@@ -77,6 +77,7 @@ def load_library():
         "sdpsr_gemm_tn_f64": (C.c_int, [vp, i64, i64, i64, vp, i64, vp, i64, vp, i64, C.c_int]),
         "sdpsr_admissible_subspace": (C.c_int, [vp, i64, vp, vp, vp, i64, dbl, vp, pi64, pi32, vp, C.c_int]),
         "sdpsr_admissible_subspace_dense": (C.c_int, [vp, i64, i64, vp, vp, vp, dbl, vp, pi64, pi32, vp, C.c_int]),
+        "sdpsr_reduce_constraints": (C.c_int, [vp, i64, vp, i64, i64, vp, vp, C.c_int]),
         "sdpsr_desymmetrize": (C.c_int, [vp, i64, vp, pi64, pi32, C.c_int]),
         "sdpsr_block_diagonalize": (C.c_int, [vp, i64, vp, i64, dbl, pi32, pi64, pi64, vp, C.c_int]),
         "sdpsr_block_sizes": (C.c_int, [vp, vp]),

@@ -294,6 +294,22 @@ def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, se
     return out
 
 
+def reduce_constraints(P, A, ctx=None):
+    """``A * PMat`` with ``PMat = hcat([vec(P.matrix .== i) for i = 1:dim(P)]...)``
+    (README.md:57-60, test/sd_problems.jl:32-37); ``A`` dense m x n^2 (or a vector: C' * PMat)."""
+    ctx = _ctx(ctx)
+    A = np.asarray(_dense(A), dtype=np.float64)
+    vec = A.ndim == 1
+    A2 = A.reshape(1, -1) if vec else A
+    m, ln = A2.shape
+    lab = _f(P.matrix, np.uint32)
+    assert ln == lab.size
+    Af = np.asfortranarray(A2)
+    out = np.zeros((m, P.nparts), order="F")
+    ctx.check(ctx._lib.sdpsr_reduce_constraints(ctx._h, ln, _ptr(lab), P.nparts, m, _ptr(Af), _ptr(out), L.MEM_HOST))
+    return out[0] if vec else out
+
+
 def desymmetrize(P, ctx=None):
     """``desymmetrize(P)`` (src/partitions.jl:197-223); returns a new Partition."""
     ctx = _ctx(ctx)

@@ -727,6 +727,25 @@ int sdpsr_desymmetrize(sdpsr_ctx* c, int64_t n, uint32_t* P, int64_t* dim, int32
     return out_finish(c, P, L, len, mem);
 }
 
+// A * PMat (README.md:57-60)
+int sdpsr_reduce_constraints(sdpsr_ctx* c, int64_t len, const uint32_t* labels, int64_t d, int64_t m, const double* A,
+                             double* out, int mem) {
+    CHECK_CTX(c);
+    if (!labels || !A || !out || d < 1 || m < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = check_len(c, len);
+    if (st) return st;
+    const uint32_t* dL = in_dev(c, "prim_in_a", labels, len, mem, &st);
+    const double* dA = in_dev(c, "red_a", A, (size_t)len * m, mem, &st);
+    double* dO = out_dev(c, "red_out", out, (size_t)m * d, mem, &st);
+    const int64_t chunk = reduce_columns_chunk(len, m, d);
+    double* part = (double*)ctx_buf(c, "red_part", (size_t)((len + chunk - 1) / chunk) * d * m * 8);
+    if (st || !part) return st ? st : SDPSR_OUT_OF_MEMORY;
+    if (!launch_reduce_columns(c->stream, len, m, d, dL, dA, part, dO))
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "dim(P) * min(m, 64) too large for the LDS accumulators");
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, out, dO, (size_t)m * d, mem);
+}
+
 // Host setup stage for dense problems, src/partitions.jl:117-142.
 int sdpsr_admissible_subspace_dense(sdpsr_ctx* c, int64_t n, int64_t m, const double* C,
                                     const double* A, const double* b, double atol, uint32_t* P_out,

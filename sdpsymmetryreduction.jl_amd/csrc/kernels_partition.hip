@@ -704,6 +704,74 @@ void launch_transpose_labels(hipStream_t s, int64_t n, const uint32_t* L, uint32
     transpose_labels_kernel<<<g, 256, 0, s>>>((int)n, L, Lt);
 }
 
+// ---------------------------------------------------------------------------
+// Reduced-SDP assembly (README.md:57-60, test/sd_problems.jl:32-37): out = A * PMat with
+// PMat[e, i] = 1[L[e] == i], i.e. the columns of A (m x n^2, column-major) summed per class.
+// One wave per chunk of entries: lanes own the rows of A (m <= 64 per pass), the per-class
+// accumulators sit in LDS, entries are walked in order (fixed summation order); chunk partials
+// are added in chunk order by the second kernel.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+reduce_columns_kernel(int64_t len, int64_t chunk, int m, int d, const uint32_t* __restrict__ L,
+                      const double* __restrict__ A, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double s_bins[];  // [(d + 1)][mw]
+    const int lane = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * chunk;
+    int64_t e1 = e0 + chunk;
+    if (e1 > len) e1 = len;
+    for (int r0 = 0; r0 < m; r0 += 64) {
+        const int mw = (m - r0 < 64) ? m - r0 : 64;
+        for (int t = lane; t < (d + 1) * mw; t += 64) s_bins[t] = 0.0;
+        __syncthreads();
+        for (int64_t eb = e0; eb < e1; eb += 64) {
+            const uint32_t mylab = (eb + lane < e1) ? L[eb + lane] : 0u;
+            const int lim = (int)((e1 - eb < 64) ? e1 - eb : 64);
+            for (int u = 0; u < lim; ++u) {
+                const uint32_t lb = __shfl(mylab, u, 64);
+                if (lane < mw) s_bins[lb * mw + lane] += A[(int64_t)(eb + u) * m + r0 + lane];
+            }
+        }
+        __syncthreads();
+        for (int t = lane; t < d * mw; t += 64) {
+            const int i = t / mw, r = t - i * mw;
+            partial[((int64_t)blockIdx.x * d + i) * m + r0 + r] = s_bins[(i + 1) * mw + r];
+        }
+        __syncthreads();
+    }
+}
+__global__ void reduce_columns_final_kernel(int64_t nchunks, int m, int d, const double* __restrict__ partial,
+                                            double* __restrict__ out) {
+    const int64_t total = (int64_t)m * d;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t i = t / m, r = t - i * m;
+    double acc = 0;
+    for (int64_t ch = 0; ch < nchunks; ++ch) acc += partial[(ch * d + i) * m + r];
+    out[r + i * m] = acc;  // m x d column-major
+}
+int64_t reduce_columns_chunk(int64_t len, int64_t m, int64_t d) {
+    int64_t chunk = 4096;
+    while ((len + chunk - 1) / chunk * d * m * 8 > ((int64_t)64 << 20)) chunk *= 2;
+    return chunk;
+}
+bool launch_reduce_columns(hipStream_t s, int64_t len, int64_t m, int64_t d, const uint32_t* L, const double* A,
+                           double* partial, double* out) {
+    const int mw = (int)(m < 64 ? m : 64);
+    const size_t lds = (size_t)(d + 1) * mw * 8;
+    if (lds > 60 * 1024) return false;
+    const int64_t chunk = reduce_columns_chunk(len, m, d);
+    const int64_t nch = (len + chunk - 1) / chunk;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    reduce_columns_kernel<<<(unsigned)nch, 64, lds, s>>>(len, chunk, (int)m, (int)d, L, A, partial);
+    reduce_columns_final_kernel<<<(unsigned)((m * d + 255) / 256), 256, 0, s>>>(nch, (int)m, (int)d, partial, out);
+    return true;
+}
+
 // synthetic signatures with `nclasses` distinct non-zero values (measurement hook)
 __global__ void fill_test_sig_kernel(int64_t len, int64_t nclasses, uint64_t* __restrict__ sig) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

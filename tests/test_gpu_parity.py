@@ -249,6 +249,22 @@ def test_desymmetrize_triple_and_oracle(pkg, oracle, golden, gpu_ctx):
     assert got.nparts == int(Lc.max()) and np.array_equal(got.matrix, Lc)
 
 
+def test_reduce_constraints_matches_pmat_product(pkg, problems, golden, gpu_ctx):
+    # README.md:57-60 / test/sd_problems.jl:32-37: newA = A * PMat, newC = C' * PMat
+    for name in ("er5", "esc16j"):
+        Cv, A, b = _problem(problems, name)
+        L = golden[f"{name}_P"]
+        P = pkg.Partition(int(L.max()), L.copy())
+        flat = L.ravel(order="F")
+        PMat = np.zeros((flat.size, P.nparts))
+        PMat[np.nonzero(flat)[0], flat[flat > 0] - 1] = 1.0
+        Ad = np.asarray(A.todense()) if hasattr(A, "todense") else A
+        got = pkg.reduce_constraints(P, Ad, ctx=gpu_ctx)
+        assert np.allclose(got, Ad @ PMat, rtol=1e-13, atol=1e-12)
+        gc = pkg.reduce_constraints(P, np.asarray(Cv), ctx=gpu_ctx)
+        assert np.allclose(gc, np.asarray(Cv) @ PMat, rtol=1e-13, atol=1e-12)
+
+
 def test_cyclic_c3_raises_invalid_field(pkg, gpu_ctx):
     # test/runtests.jl:50-56
     C3 = np.array([[1, 3, 2], [2, 1, 3], [3, 2, 1]])
