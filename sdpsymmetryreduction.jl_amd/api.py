@@ -263,10 +263,43 @@ def admissible_setup(C_, A, b, atol=RTOL_DEFAULT):
     return n, np.ascontiguousarray(CL), np.ascontiguousarray(X0L), U
 
 
+def _admissible_subspace_device_setup(C_, A, b, atol, ctx, verbose):
+    """Whole ``admissible_subspace`` through ``sdpsr_admissible_subspace_dense``: the setup stage
+    (qr(A'), C_L, min-norm x0; src/partitions.jl:117-142) runs on the device as well."""
+    c = np.asarray(C_.todense()).reshape(-1) if hasattr(C_, "todense") else np.asarray(C_, dtype=np.float64).reshape(-1)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    n = math.isqrt(len(c))
+    if n * n != len(c):
+        raise ValueError("length(C) is not a perfect square")
+    Ad = np.asfortranarray(_dense(A), dtype=np.float64)
+    m = Ad.shape[0]
+    bb = np.ascontiguousarray(b, dtype=np.float64)
+    P = np.empty(n * n, dtype=np.uint32)
+    d = C.c_int64(0)
+    it = C.c_int32(0)
+    ms = (C.c_double * L.T_COUNT)()
+    ctx.check(ctx._lib.sdpsr_admissible_subspace_dense(ctx._h, n, m, _ptr(c), _ptr(Ad), _ptr(bb), float(atol), _ptr(P),
+                                                       C.byref(d), C.byref(it), C.cast(ms, C.c_void_p), L.MEM_HOST))
+    if verbose:
+        print(f"[sdpsr] admissible subspace (device setup): dim {d.value} after {it.value} iterations, loop {ms[L.T_TOTAL]:.3f} ms")
+    out = Partition(d.value, P.reshape(n, n, order="F"))
+    out.iterations = it.value
+    out.phase_ms = list(ms)
+    return out
+
+
 def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, setup=None,
-                        return_info=False):
-    """``admissible_subspace(C, A, b; verbose, atol)`` (src/partitions.jl:77-190)."""
+                        return_info=False, host_setup=False):
+    """``admissible_subspace(C, A, b; verbose, atol)`` (src/partitions.jl:77-190).
+
+    By default the setup stage runs on the device too (dense copy of ``A``, at most 4 GiB);
+    ``host_setup=True`` (or a precomputed ``setup``) uses the NumPy/SciPy setup, which is also the
+    path for very large sparse ``A``."""
     ctx = _ctx(ctx)
+    if setup is None and not host_setup and A is not None:
+        m_rows = A.shape[0]
+        if m_rows * int(np.prod(np.shape(C_))) * 8 <= (4 << 30):
+            return _admissible_subspace_device_setup(C_, A, b, atol, ctx, verbose)
     n, CL, X0L, U = setup if setup is not None else admissible_setup(C_, A, b, atol)
     on_dev = _is_torch(CL)
     r = U.shape[1]

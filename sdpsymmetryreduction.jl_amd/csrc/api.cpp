@@ -746,7 +746,11 @@ int sdpsr_reduce_constraints(sdpsr_ctx* c, int64_t len, const uint32_t* labels, 
     return out_finish(c, out, dO, (size_t)m * d, mem);
 }
 
-// Host setup stage for dense problems, src/partitions.jl:117-142.
+// Setup stage for dense problems on the device, src/partitions.jl:117-142:
+//   U    orthonormal basis of rowspace(A): modified Gram-Schmidt on the residual rows with
+//        pivoting by residual norm and one re-orthogonalisation pass (stands in for qr(A'));
+//   C_L  = symmetrize(round(c - U U'c));   X0_L = round(U U' symmetrize(x0)),  x0 = U R^-T b
+// All vectors of length n^2 stay in HBM; the host sees m-vectors of dot products only.
 int sdpsr_admissible_subspace_dense(sdpsr_ctx* c, int64_t n, int64_t m, const double* C,
                                     const double* A, const double* b, double atol, uint32_t* P_out,
                                     int64_t* dim_out, int32_t* iters_out, double* phase_ms,
@@ -754,111 +758,111 @@ int sdpsr_admissible_subspace_dense(sdpsr_ctx* c, int64_t n, int64_t m, const do
     CHECK_CTX(c);
     if (!C || !A || !b || n < 1 || m < 0 || !(atol > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
     const int64_t len = n * n;
-    // U = orthonormal basis of rowspace(A): modified Gram-Schmidt on the residual rows with
-    // pivoting by residual norm and one re-orthogonalisation pass (stands in for qr(A'), :124).
-    // coeffs[i][j] = <U_j, a_i>, so a_i = sum_j coeffs[i][j] U_j for every pivot row.
-    std::vector<double> U((size_t)len * std::max<int64_t>(m, 1));
-    std::vector<std::vector<double>> res(m, std::vector<double>(len));
-    std::vector<std::vector<double>> coeffs(m, std::vector<double>(m, 0.0));
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    const int64_t mm = std::max<int64_t>(m, 1);
+    const int nblk = 512;
+    double* dA = (double*)ctx_buf(c, "set_a", (size_t)len * mm * 8);   // m x len as given
+    double* R = (double*)ctx_buf(c, "set_r", (size_t)len * mm * 8);    // residual rows, len x m
+    double* U = (double*)ctx_buf(c, "adm_u", (size_t)len * mm * 8);    // basis, len x r
+    double* v1 = (double*)ctx_buf(c, "set_v1", (size_t)len * 8);
+    double* v2 = (double*)ctx_buf(c, "set_v2", (size_t)len * 8);
+    double* dCL = (double*)ctx_buf(c, "adm_cl", (size_t)len * 8);
+    double* dX0 = (double*)ctx_buf(c, "adm_x0", (size_t)len * 8);
+    double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)mm * nblk * 8);
+    double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)mm * 8);
+    if (!dA || !R || !U || !v1 || !v2 || !dCL || !dX0 || !partial || !coef) return SDPSR_OUT_OF_MEMORY;
+    if (m > 0) HIP_TRY(c, hipMemcpyAsync(dA, A, (size_t)len * m * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(v1, C, (size_t)len * 8, hipMemcpyHostToDevice, s));  // v1 = c
+    if (m > 0) launch_transpose_rows(s, len, m, dA, R);  // R[e + i*len] = A[i + e*m]
+    std::vector<std::vector<double>> coeffs(m, std::vector<double>(mm, 0.0));
     std::vector<int64_t> piv;
     std::vector<char> used(m, 0);
+    std::vector<double> hd(mm);
     double maxnorm = 0;
-    auto norm2 = [&](const std::vector<double>& w) {
-        double s2 = 0;
-        for (double t : w) s2 += t * t;
-        return std::sqrt(s2);
-    };
-    for (int64_t i = 0; i < m; ++i) {
-        for (int64_t e = 0; e < len; ++e) res[i][e] = A[i + e * m];
-        maxnorm = std::max(maxnorm, norm2(res[i]));
-    }
     int64_t r = 0;
     for (int64_t step = 0; step < m; ++step) {
+        launch_col_norms2(s, len, m, R, partial, nblk, coef);  // |R_i|^2 for every row
+        st = d2h_sync(c, hd.data(), coef, (size_t)m * 8);
+        if (st) return st;
+        if (step == 0)
+            for (int64_t i = 0; i < m; ++i) maxnorm = std::max(maxnorm, std::sqrt(hd[i]));
         int64_t best = -1;
         double bestn = -1;
-        for (int64_t i = 0; i < m; ++i) {
-            if (used[i]) continue;
-            double nn = norm2(res[i]);
-            if (nn > bestn) {
-                bestn = nn;
+        for (int64_t i = 0; i < m; ++i)
+            if (!used[i] && hd[i] > bestn) {
+                bestn = hd[i];
                 best = i;
             }
-        }
-        if (best < 0 || bestn <= 1e-12 * maxnorm) break;
-        std::vector<double>& v = res[best];
-        for (int64_t j = 0; j < r; ++j) {  // re-orthogonalise against the basis so far
-            const double* uj = &U[(size_t)j * len];
-            double dot = 0;
-            for (int64_t e = 0; e < len; ++e) dot += uj[e] * v[e];
-            for (int64_t e = 0; e < len; ++e) v[e] -= dot * uj[e];
-            coeffs[best][j] += dot;
-        }
-        bestn = norm2(v);
-        if (bestn <= 1e-12 * maxnorm) {
-            used[best] = 1;
-            continue;
-        }
+        if (best < 0 || std::sqrt(std::max(bestn, 0.0)) <= 1e-12 * maxnorm) break;
         used[best] = 1;
-        double* ur = &U[(size_t)r * len];
-        for (int64_t e = 0; e < len; ++e) ur[e] = v[e] / bestn;
-        coeffs[best][r] = bestn;
-        for (int64_t i = 0; i < m; ++i) {
-            if (used[i]) continue;
-            double dot = 0;
-            for (int64_t e = 0; e < len; ++e) dot += ur[e] * res[i][e];
-            for (int64_t e = 0; e < len; ++e) res[i][e] -= dot * ur[e];
-            coeffs[i][r] += dot;
+        double* v = R + (size_t)best * len;
+        if (r > 0) {  // re-orthogonalise against the basis so far
+            launch_proj_coef(s, len, r, U, nullptr, 0, v, partial, nblk, coef);
+            st = d2h_sync(c, hd.data(), coef, (size_t)r * 8);
+            if (st) return st;
+            for (int64_t j = 0; j < r; ++j) coeffs[best][j] += hd[j];
+            launch_proj_apply(s, len, r, U, nullptr, 0, v, coef, 0, 1, 0, v, nullptr);
         }
+        launch_col_norms2(s, len, 1, v, partial, nblk, coef);
+        double nn = 0;
+        st = d2h_sync(c, &nn, coef, 8);
+        if (st) return st;
+        nn = std::sqrt(std::max(nn, 0.0));
+        if (nn <= 1e-12 * maxnorm) continue;
+        double* ur = U + (size_t)r * len;
+        launch_scale_copy(s, len, v, 1.0 / nn, ur);
+        coeffs[best][r] = nn;
+        // remaining residual rows: R_i -= (u . R_i) u
+        launch_proj_coef(s, len, m, R, nullptr, 0, ur, partial, nblk, coef);  // dots of every row with u
+        st = d2h_sync(c, hd.data(), coef, (size_t)m * 8);
+        if (st) return st;
+        std::vector<double> dots(m, 0.0);
+        for (int64_t i = 0; i < m; ++i)
+            if (!used[i]) {
+                dots[i] = hd[i];
+                coeffs[i][r] += hd[i];
+            }
+        st = h2d_sync(c, coef, dots.data(), (size_t)m * 8);
+        if (st) return st;
+        launch_rank1_update(s, len, m, R, ur, coef);
         piv.push_back(best);
         ++r;
     }
     // min-norm solution x0 = U y with R' y = b(piv): forward substitution (Krylov.craig, :137)
-    std::vector<double> y(r, 0.0);
+    std::vector<double> y(std::max<int64_t>(r, 1), 0.0);
     for (int64_t k = 0; k < r; ++k) {
         double s2 = b[piv[k]];
         for (int64_t j = 0; j < k; ++j) s2 -= coeffs[piv[k]][j] * y[j];
         y[k] = s2 / coeffs[piv[k]][k];
     }
-    std::vector<double> x0(len, 0.0), CLv(len), X0(len);
-    for (int64_t k = 0; k < r; ++k)
-        for (int64_t e = 0; e < len; ++e) x0[e] += U[(size_t)k * len + e] * y[k];
-    auto project = [&](const std::vector<double>& in, std::vector<double>& out) {
-        std::fill(out.begin(), out.end(), 0.0);
-        for (int64_t k = 0; k < r; ++k) {
-            const double* uk = &U[(size_t)k * len];
-            double dot = 0;
-            for (int64_t e = 0; e < len; ++e) dot += uk[e] * in[e];
-            for (int64_t e = 0; e < len; ++e) out[e] += dot * uk[e];
-        }
-    };
-    auto symmetrize = [&](std::vector<double>& w) {  // src/utils.jl:71-81
-        for (int64_t j = 0; j < n; ++j)
-            for (int64_t i = j; i < n; ++i) {
-                double t = (w[i + j * n] + w[j + i * n]) / 2;
-                w[i + j * n] = w[j + i * n] = t;
-            }
-    };
     const double scale = std::pow(10.0, std::floor(-std::log10(atol)));
-    std::vector<double> tmp(len);
-    // CL (:129-134)
-    std::vector<double> cv(C, C + len);
-    project(cv, tmp);
-    for (int64_t e = 0; e < len; ++e) CLv[e] = sdpsr_clamp_round(cv[e] - tmp[e], atol, scale);
-    symmetrize(CLv);
-    // X0L (:137-142)
-    symmetrize(x0);
-    project(x0, tmp);
-    for (int64_t e = 0; e < len; ++e) X0[e] = sdpsr_clamp_round(tmp[e], atol, scale);
-    // run the loop with host inputs; the output may be wanted on the device
-    if (mem_out == SDPSR_MEM_HOST)
-        return sdpsr_admissible_subspace(c, n, CLv.data(), X0.data(), U.data(), r, atol, P_out, dim_out,
-                                         iters_out, phase_ms, SDPSR_MEM_HOST);
-    std::vector<uint32_t> hostP(len);
-    int st = sdpsr_admissible_subspace(c, n, CLv.data(), X0.data(), U.data(), r, atol, hostP.data(),
-                                       dim_out, iters_out, phase_ms, SDPSR_MEM_HOST);
-    if (st) return st;
-    HIP_TRY(c, hipMemcpy(P_out, hostP.data(), len * 4, hipMemcpyHostToDevice));
-    return SDPSR_OK;
+    // C_L (:129-134): v1 = c;  C_L = symmetrize(round(c - U U'c))
+    launch_proj_coef(s, len, r, U, nullptr, 0, v1, partial, nblk, coef);
+    launch_proj_apply(s, len, r, U, nullptr, 0, v1, coef, atol, scale, 1, dCL, nullptr);
+    launch_symmetrize(s, n, n, dCL);
+    // X0_L (:137-142): x0 = U y -> symmetrize -> U U' x0 -> round
+    if (r > 0) {
+        st = h2d_sync(c, coef, y.data(), (size_t)r * 8);
+        if (st) return st;
+        launch_tall_times_small(s, len, len, U, (int)r, coef, (int)r, 1, 1.0, 0.0, v2, len);
+    } else {
+        HIP_TRY(c, hipMemsetAsync(v2, 0, (size_t)len * 8, s));
+    }
+    launch_symmetrize(s, n, n, v2);
+    launch_proj_coef(s, len, r, U, nullptr, 0, v2, partial, nblk, coef);
+    launch_proj_apply(s, len, r, U, nullptr, 0, v2, coef, 0, 1, 0, v1, nullptr);  // v1 = x0 - U U'x0
+    launch_sub_round(s, len, v2, v1, atol, scale, dX0);                           // X0_L = round(x0 - v1)
+    HIP_TRY(c, hipGetLastError());
+    // the loop, device-resident inputs
+    uint32_t* dP = (mem_out == SDPSR_MEM_DEVICE) ? P_out : (uint32_t*)ctx_buf(c, "adm_labels", (size_t)len * 4);
+    if (!dP) return SDPSR_OUT_OF_MEMORY;
+    st = sdpsr_admissible_subspace(c, n, dCL, dX0, U, r, atol, dP, dim_out, iters_out, phase_ms, SDPSR_MEM_DEVICE);
+    if (st && st != SDPSR_NOT_CONVERGED) return st;
+    const int st_loop = st;
+    st = out_finish(c, P_out, dP, len, mem_out);
+    return st ? st : st_loop;
 }
 
 }  // extern "C"
@@ -1119,6 +1123,11 @@ bool launch_label_spmm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key
                        int64_t ldw, int w, double* partials, double* Y, int64_t ldy);
 void launch_tall_times_small(hipStream_t s, int64_t n, int64_t ldi, const double* In, int kk, const double* S,
                              int lds_, int ncols, double alpha, double beta, double* out, int64_t ldo);
+void launch_transpose_rows(hipStream_t s, int64_t len, int64_t m, const double* A, double* R);
+void launch_col_norms2(hipStream_t s, int64_t len, int64_t k, const double* V, double* partial, int nblk, double* out);
+void launch_scale_copy(hipStream_t s, int64_t len, const double* v, double alpha, double* out);
+void launch_rank1_update(hipStream_t s, int64_t len, int64_t m, double* R, const double* u, const double* dots);
+void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double* b, double atol, double scale, double* out);
 void launch_lanczos_init(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const double* X,
                          int64_t ldx, int nruns, double* norm0);
 void launch_lanczos_pack(hipStream_t s, int64_t n, int64_t ld, const double* H, int64_t hstride, const int* tcur,

@@ -772,6 +772,67 @@ bool launch_reduce_columns(hipStream_t s, int64_t len, int64_t m, int64_t d, con
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// small vector kernels of the device setup stage (src/partitions.jl:117-142)
+// ---------------------------------------------------------------------------
+// R[e + i*len] = A[i + e*m]
+__global__ void transpose_rows_kernel(int64_t len, int m, const double* __restrict__ A, double* __restrict__ R) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride)
+        for (int i = 0; i < m; ++i) R[e + (int64_t)i * len] = A[i + e * m];
+}
+void launch_transpose_rows(hipStream_t s, int64_t len, int64_t m, const double* A, double* R) {
+    transpose_rows_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, (int)m, A, R);
+}
+// out[k] = |V[:,k]|^2 ; grid (nblk, k)
+__global__ void col_norms2_kernel(int64_t len, const double* __restrict__ V, double* __restrict__ partial) {
+    __shared__ double sh[8];
+    const double* v = V + (int64_t)blockIdx.y * len;
+    double acc = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) acc = fma(v[e], v[e], acc);
+    double r = block_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+void launch_col_norms2(hipStream_t s, int64_t len, int64_t k, const double* V, double* partial, int nblk, double* out) {
+    if (k <= 0) return;
+    dim3 g(nblk, (unsigned)k);
+    col_norms2_kernel<<<g, 256, 0, s>>>(len, V, partial);
+    proj_coef_final_kernel<<<(unsigned)k, 256, 0, s>>>(nblk, partial, out);
+}
+__global__ void scale_copy_kernel(int64_t len, const double* __restrict__ v, double alpha, double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) out[e] = v[e] * alpha;
+}
+void launch_scale_copy(hipStream_t s, int64_t len, const double* v, double alpha, double* out) {
+    scale_copy_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, v, alpha, out);
+}
+// R[:, i] -= dots[i] * u   for every i (dots[i] = 0 leaves the row alone)
+__global__ void rank1_update_kernel(int64_t len, int m, double* __restrict__ R, const double* __restrict__ u,
+                                    const double* __restrict__ dots) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const double ue = u[e];
+        for (int i = 0; i < m; ++i) {
+            const double dd = dots[i];
+            if (dd != 0.0) R[e + (int64_t)i * len] = fma(-dd, ue, R[e + (int64_t)i * len]);
+        }
+    }
+}
+void launch_rank1_update(hipStream_t s, int64_t len, int64_t m, double* R, const double* u, const double* dots) {
+    rank1_update_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, (int)m, R, u, dots);
+}
+// out = clamp_round(a - b)
+__global__ void sub_round_kernel(int64_t len, const double* __restrict__ a, const double* __restrict__ b, double atol,
+                                 double scale, double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride)
+        out[e] = sdpsr_clamp_round(a[e] - b[e], atol, scale);
+}
+void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double* b, double atol, double scale, double* out) {
+    sub_round_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, a, b, atol, scale, out);
+}
+
 // synthetic signatures with `nclasses` distinct non-zero values (measurement hook)
 __global__ void fill_test_sig_kernel(int64_t len, int64_t nclasses, uint64_t* __restrict__ sig) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

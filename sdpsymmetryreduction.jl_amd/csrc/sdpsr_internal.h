@@ -124,6 +124,16 @@ void launch_transpose_labels(hipStream_t s, int64_t n, const uint32_t* L, uint32
 int64_t reduce_columns_chunk(int64_t len, int64_t m, int64_t d);
 bool launch_reduce_columns(hipStream_t s, int64_t len, int64_t m, int64_t d, const uint32_t* L, const double* A,
                            double* partial, double* out);
+// kernels_krylov.hip / setup-stage helpers used across api.cpp
+void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B);
+void launch_tall_times_small(hipStream_t s, int64_t n, int64_t ldi, const double* In, int kk, const double* S,
+                             int lds_, int ncols, double alpha, double beta, double* out, int64_t ldo);
+void launch_transpose_rows(hipStream_t s, int64_t len, int64_t m, const double* A, double* R);
+void launch_col_norms2(hipStream_t s, int64_t len, int64_t k, const double* V, double* partial, int nblk, double* out);
+void launch_scale_copy(hipStream_t s, int64_t len, const double* v, double alpha, double* out);
+void launch_rank1_update(hipStream_t s, int64_t len, int64_t m, double* R, const double* u, const double* dots);
+void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double* b, double atol, double scale, double* out);
+
 // symmetric-labels check: flag[0] = 1 if some L[i,j] != L[j,i]
 void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag);
 

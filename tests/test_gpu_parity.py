@@ -282,6 +282,19 @@ def test_numerical_issues_never_throws(pkg, golden, gpu_ctx):
         assert nc == 2
 
 
+def test_device_setup_equals_host_setup(pkg, problems, golden):
+    """Setup stage on the device (sdpsr_admissible_subspace_dense) vs the NumPy setup: same
+    canonical partition, including the sparse-A QAP with a 33 x 65536 constraint matrix."""
+    for name in ("petersen", "er7", "esc16j"):
+        Cv, A, b = _problem(problems, name)
+        with pkg.Context(seed=11) as ctx:
+            Pd = pkg.admissible_subspace(Cv, A, b, ctx=ctx)
+            Ph = pkg.admissible_subspace(Cv, A, b, ctx=ctx, host_setup=True)
+        assert Pd.nparts == Ph.nparts == int(golden[f"{name}_P"].max())
+        assert np.array_equal(Pd.matrix, golden[f"{name}_P"])
+        assert np.array_equal(Ph.matrix, golden[f"{name}_P"])
+
+
 def test_generic_graph_reaches_maximal_dimension(pkg, problems, oracle):
     # BASELINE.json configs[1] at a size the oracle finishes in seconds: trivial symmetry
     n = 96
