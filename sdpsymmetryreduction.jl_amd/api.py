@@ -374,11 +374,21 @@ def _labels_arg(P):
     return _f(m, np.uint32), L.MEM_HOST
 
 
-def blockDiagonalize(P, verbose=False, epsilon=RTOL_DEFAULT, complex=False, ctx=None):
-    """``blockDiagonalize(P, verbose; epsilon, complex)`` (src/compat.jl:26-68), real path."""
+def blockDiagonalize(P, verbose=False, epsilon=RTOL_DEFAULT, complex=False, ctx=None, retries=0):
+    """``blockDiagonalize(P, verbose; epsilon, complex)`` (src/compat.jl:26-68), real path.
+
+    ``retries`` > 0 re-runs the randomized decomposition with fresh generic elements when it ends
+    in ``NumericalInconsistency`` / ``DimensionMismatch`` -- what the reference's error texts ask
+    the caller to do ("try again"); the default 0 is the reference's behaviour."""
     if complex:
         raise NotImplementedError("complex path (desymmetrize + ComplexF64 eigen) is outside the HIP hot path; see DESIGN.md")
     ctx = _ctx(ctx)
+    for attempt in range(int(retries)):
+        try:
+            return blockDiagonalize(P, verbose=verbose, epsilon=epsilon, ctx=ctx, retries=0)
+        except (NumericalInconsistency, DimensionMismatch) as e:
+            if verbose:
+                print(f"[sdpsr] blockDiagonalize attempt {attempt + 1} failed ({type(e).__name__}); retrying")
     n = P.shape[0]
     lab, mem = _labels_arg(P)
     nb = C.c_int32(0)

@@ -1681,29 +1681,36 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             for (int i = 0; i <= cc; ++i) coef[(size_t)perm[i] + (size_t)cc * m] = X[(size_t)i + (size_t)cc * r];
         return r;
     };
+    double ref = 0;  // squared scale of a candidate column before projection (first round)
     for (int round = 0; round < 40; ++round) {
         const int64_t wpp = round_up(w, 128);
-        const int m = 2 * w;
-        const int64_t mp = 2 * wpp;
-        // candidates: Y[:, 0:w] = A_a W, Y[:, wpp : wpp + w] = A_b W
+        const bool fused = (w <= 64 && d <= 4000);
+        int G = (fused && w <= 16) ? 4 : 2;            // generic elements per round
+        const int64_t cstride = fused ? w : wpp;        // fused products pack their columns densely
+        while (G > 2 && (int64_t)G * cstride > ycap) --G;
+        const int m = G * w;
+        const int64_t mp = round_up((int64_t)(G - 1) * cstride + (fused ? w : wpp), 128);
+        // candidates: Y[:, g*cstride + (0:w)] = A_g W for fresh generic elements A_g
         HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * mp * 8, s));
-        for (int half = 0; half < 2; ++half) {
-            int e2 = apply_generic(w, Y + (size_t)half * wpp * ld);
+        for (int gidx = 0; gidx < G; ++gidx) {
+            int e2 = apply_generic(w, Y + (size_t)gidx * cstride * ld);
             if (e2) return e2;
         }
-        // scale reference: the candidates before projection (after it, a complete module leaves
-        // only rounding noise and a relative test would compare noise with noise)
-        gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);
-        hG.resize((size_t)mp * mp);
-        { int e2 = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8); if (e2) return e2; }
-        double ref = 0;
-        for (int64_t i = 0; i < mp; ++i) ref = std::max(ref, hG[(size_t)i + (size_t)i * mp]);
+        if (round == 0) {
+            // scale reference: the candidates before projection (after it, a complete module
+            // leaves only rounding noise and a relative test would compare noise with noise)
+            gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);
+            hG.resize((size_t)mp * mp);
+            { int e2 = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8); if (e2) return e2; }
+            for (int64_t i = 0; i < mp; ++i) ref = std::max(ref, hG[(size_t)i + (size_t)i * mp]);
+        }
         project_off_W(Y, mp, (int)mp);
         gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);  // Gram
+        hG.resize((size_t)mp * mp);
         { int e2 = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8); if (e2) return e2; }
-        // compact the two halves (columns w..wpp-1 of each half are zero)
+        // compact the G groups (columns between the groups are zero)
         std::vector<double> Gc((size_t)m * m);
-        auto src = [&](int i) { return (i < w) ? (int64_t)i : (int64_t)(wpp + (i - w)); };
+        auto src = [&](int i) { return (int64_t)(i / w) * cstride + (i % w); };
         for (int j = 0; j < m; ++j)
             for (int i = 0; i < m; ++i) Gc[(size_t)i + (size_t)j * m] = hG[(size_t)src(i) + (size_t)src(j) * mp];
         std::vector<double> coefc;
