@@ -14,6 +14,7 @@ namespace sdpsr {
 size_t sytrd_workspace_doubles(int64_t n, int64_t ld);
 void launch_sytrd(hipStream_t s, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau,
                   double* ws);
+bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double* w, double* Vtmp, int* info);
 
 static int ensure_handle(sdpsr_ctx* c) {
     if (!c->rocblas) {
@@ -43,7 +44,12 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w) {
     rocblas_int* info = (rocblas_int*)ctx_buf(c, "eig_info", 64);
     if (!E || !tau || !info) return SDPSR_OUT_OF_MEMORY;
     rocblas_status rs;
-    if (c->opts.eig_driver == 1) {
+    if (n <= 128 && (c->opts.eig_driver == 0 || c->opts.eig_driver >= 4)) {
+        // one-workgroup Jacobi (kernels_sytrd.hip): the blocked path is pure launch latency here
+        double* Vt = (double*)ctx_buf(c, "eig_Z", (size_t)n * n * sizeof(double));
+        if (!Vt) return SDPSR_OUT_OF_MEMORY;
+        launch_small_syev(c->stream, n, A, lda, w, Vt, (int*)info);
+    } else if (c->opts.eig_driver == 1) {
         rs = rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, (rocblas_int)n, A,
                               (rocblas_int)lda, w, E, info);
         if (rs != rocblas_status_success)

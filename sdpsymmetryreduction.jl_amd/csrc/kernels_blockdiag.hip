@@ -226,42 +226,72 @@ void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t
 __global__ void __launch_bounds__(64)
 basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, const double* __restrict__ Qrm,
                         double* __restrict__ T) {
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [(d + 1)][S1]
+    // One wave per row r.  The n labels of column r of L (== row r, symmetric partition) are
+    // first sorted by class with a STABLE counting sort in LDS (ranks inside a 64-entry chunk
+    // come from ballots over the distinct labels of the chunk), then every class segment is
+    // summed in index order with independent loads: no read-modify-write chains, fixed order.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int* s_off = reinterpret_cast<int*>(smem_raw);                       // [d + 2] running offsets
+    int* s_start = s_off + (d + 2);                                      // [d + 2] segment starts
+    unsigned short* s_pos = reinterpret_cast<unsigned short*>(s_start + (d + 2));  // [n] sorted entries
     const int lane = threadIdx.x;
     const int r = blockIdx.x;
-    const int tot = (d + 1) * S1;
-    for (int t = lane; t < tot; t += 64) s_acc[t] = 0.0;
+    const uint32_t* col = L + (int64_t)r * n;
+    for (int t = lane; t < d + 2; t += 64) s_off[t] = 0;
     __syncthreads();
-    const uint32_t* col = L + (int64_t)r * n;  // column r of L == row r (symmetric partition)
-    for (int j0 = 0; j0 < S1; j0 += 64) {      // column chunks of Qhat (S1 <= 64 in practice)
-        const int j = j0 + lane;
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const int cc = c0 + lane;
-            const uint32_t mylab = (cc < n) ? col[cc] : 0u;
-            const int lim = (n - c0 < 64) ? n - c0 : 64;
-            for (int u = 0; u < lim; u += 4) {
-                // four rows of Qhat in flight per lane
-                double q[4];
-                uint32_t lb[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int uu = (u + v < lim) ? u + v : lim - 1;
-                    lb[v] = __shfl(mylab, uu, 64);
-                    q[v] = (j < S1 && u + v < lim) ? Qrm[(int64_t)(c0 + uu) * S1 + j] : 0.0;
-                }
-                if (j < S1) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (u + v < lim) s_acc[lb[v] * S1 + j] += q[v];
-                }
+    for (int c = lane; c < n; c += 64) atomicAdd(&s_off[col[c] + 1], 1);  // histogram, shifted by one
+    __syncthreads();
+    if (lane == 0) {  // exclusive scan (d + 1 classes incl. the zero class)
+        int run = 0;
+        for (int i = 0; i <= d; ++i) {
+            const int cnt = s_off[i + 1];
+            s_start[i] = run;
+            run += cnt;
+        }
+        s_start[d + 1] = run;
+    }
+    __syncthreads();
+    for (int t = lane; t < d + 2; t += 64) s_off[t] = s_start[t];
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int c = c0 + lane;
+        const bool valid = c < n;
+        const uint32_t l = valid ? col[c] : 0xFFFFFFFFu;
+        unsigned long long remaining = __ballot(valid);
+        while (remaining) {
+            const int leader = __ffsll((long long)remaining) - 1;
+            const uint32_t ll = __shfl(l, leader, 64);
+            const unsigned long long mask = __ballot(valid && l == ll);
+            if (valid && l == ll) {
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                s_pos[s_off[ll] + rank] = (unsigned short)c;
             }
+            // all lanes read s_off[ll] above before the leader bumps it: same wave, in-order LDS
+            if (lane == leader) s_off[ll] += __popcll(mask);
+            remaining &= ~mask;
         }
     }
     __syncthreads();
-    // T[i][r][:], classes 1..d
-    for (int t = lane; t < d * S1; t += 64) {
-        const int i = t / S1, j = t - i * S1;
-        T[((int64_t)i * n + r) * S1 + j] = s_acc[(i + 1) * S1 + j];
+    for (int j0 = 0; j0 < S1; j0 += 64) {
+        const int j = j0 + lane;
+        for (int i = 1; i <= d; ++i) {
+            const int p0 = s_start[i], p1 = s_start[i + 1];
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int p = p0;
+            if (j < S1) {
+                for (; p + 3 < p1; p += 4) {
+                    const int c0 = s_pos[p], c1 = s_pos[p + 1], c2 = s_pos[p + 2], c3 = s_pos[p + 3];
+                    const double q0 = Qrm[(int64_t)c0 * S1 + j], q1 = Qrm[(int64_t)c1 * S1 + j];
+                    const double q2 = Qrm[(int64_t)c2 * S1 + j], q3 = Qrm[(int64_t)c3 * S1 + j];
+                    a0 += q0;
+                    a1 += q1;
+                    a2 += q2;
+                    a3 += q3;
+                }
+                for (; p < p1; ++p) a0 += Qrm[(int64_t)s_pos[p] * S1 + j];
+                T[((int64_t)(i - 1) * n + r) * S1 + j] = (a0 + a1) + (a2 + a3);
+            }
+        }
     }
 }
 
@@ -296,13 +326,13 @@ basis_image_blocks_kernel(int n, int S1, int64_t S, const double* __restrict__ Q
 }
 
 bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1) {
-    return (d + 1) * S1 * 8 <= 60 * 1024 && d * n * S1 * 8 <= ((int64_t)4 << 30);
+    return n <= 65535 && (2 * (d + 2) * 4 + n * 2) <= 60 * 1024 && d * n * S1 * 8 <= ((int64_t)4 << 30);
 }
 
 void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks,
                                   const uint32_t* L, const double* Qrm, double* T, const int32_t* blk_col,
                                   const int32_t* blk_size, const int64_t* blk_off, double atol, double* out) {
-    const size_t lds = (size_t)(d + 1) * S1 * 8;
+    const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel),

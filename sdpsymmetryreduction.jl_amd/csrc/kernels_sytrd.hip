@@ -508,3 +508,166 @@ void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, 
 }
 
 }  // namespace sdpsr
+
+// ---------------------------------------------------------------------------
+// Small symmetric eigenproblems (n <= 128) in ONE workgroup: parallel cyclic Jacobi with the
+// matrix resident in LDS.  The compressed problems of the module-compression driver (w x w,
+// w < 2 dim P) and the reference's small test algebras are this size; the blocked
+// tridiagonalisation path costs ~5 launches per column there, i.e. pure launch latency.
+// Round-robin ordering: n/2 disjoint rotations per step, n-1 steps per sweep; every step is
+// (angles) -> barrier -> (column rotations of A and V) -> barrier -> (row rotations of A).
+// ---------------------------------------------------------------------------
+namespace sdpsr {
+
+constexpr int JAC_THREADS = 1024;
+constexpr int JAC_MAXN = 128;
+
+__global__ void __launch_bounds__(JAC_THREADS)
+small_syev_jacobi_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __restrict__ wout,
+                         double* __restrict__ Vtmp, int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sA[];  // n x n, leading dimension ldl
+    __shared__ double s_c[JAC_MAXN / 2], s_s[JAC_MAXN / 2];
+    __shared__ int s_p[JAC_MAXN / 2], s_q[JAC_MAXN / 2];
+    __shared__ double s_red[JAC_THREADS / 64];
+    __shared__ double s_off, s_diag;
+    __shared__ int s_rank[JAC_MAXN];
+    const int tid = threadIdx.x;
+    const int ldl = n | 1;  // odd leading dimension: column walks hit distinct banks
+    const int m = (n + 1) & ~1;  // players of the tournament (a dummy one when n is odd)
+    const int half = m >> 1;
+    // load A (symmetric part from the lower triangle, like LAPACK with uplo = 'L') and V = I
+    for (int e = tid; e < n * n; e += JAC_THREADS) {
+        const int j = e / n, i = e - j * n;
+        const int ii = i > j ? i : j, jj = i > j ? j : i;
+        sA[i + j * ldl] = Ag[ii + (int64_t)jj * lda];
+        Vtmp[i + (int64_t)j * n] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    int sweep = 0;
+    for (; sweep < 40; ++sweep) {
+        // off-diagonal and diagonal norms
+        double off = 0, dg = 0;
+        for (int e = tid; e < n * n; e += JAC_THREADS) {
+            const int j = e / n, i = e - j * n;
+            const double v = sA[i + j * ldl];
+            if (i == j) dg = fma(v, v, dg);
+            else off = fma(v, v, off);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            off += __shfl_down(off, o, 64);
+            dg += __shfl_down(dg, o, 64);
+        }
+        if ((tid & 63) == 0) s_red[tid >> 6] = off;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0;
+            for (int k = 0; k < JAC_THREADS / 64; ++k) t += s_red[k];
+            s_off = t;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = dg;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0;
+            for (int k = 0; k < JAC_THREADS / 64; ++k) t += s_red[k];
+            s_diag = t;
+        }
+        __syncthreads();
+        if (s_off <= 1e-30 * (s_diag + s_off) || s_off == 0.0) break;
+        for (int step = 0; step < m - 1; ++step) {
+            if (tid < half) {
+                int p, q;
+                if (tid == 0) {
+                    p = m - 1;
+                    q = step;
+                } else {
+                    p = (step + tid) % (m - 1);
+                    q = (step - tid + (m - 1)) % (m - 1);
+                }
+                if (p > q) {
+                    const int t = p;
+                    p = q;
+                    q = t;
+                }
+                double c = 1.0, s = 0.0;
+                if (q < n) {
+                    const double apq = sA[p + q * ldl];
+                    if (apq != 0.0) {
+                        const double app = sA[p + p * ldl], aqq = sA[q + q * ldl];
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0);
+                        s = t * c;
+                    }
+                }
+                s_c[tid] = c;
+                s_s[tid] = s;
+                s_p[tid] = p;
+                s_q[tid] = (q < n) ? q : -1;
+            }
+            __syncthreads();
+            // column rotations: A <- A J, V <- V J
+            for (int e = tid; e < half * n; e += JAC_THREADS) {
+                const int k = e / n, i = e - k * n;
+                const int q = s_q[k];
+                if (q < 0) continue;
+                const int p = s_p[k];
+                const double c = s_c[k], s = s_s[k];
+                if (s == 0.0) continue;
+                const double x = sA[i + p * ldl], y = sA[i + q * ldl];
+                sA[i + p * ldl] = c * x - s * y;
+                sA[i + q * ldl] = s * x + c * y;
+                const double vx = Vtmp[i + (int64_t)p * n], vy = Vtmp[i + (int64_t)q * n];
+                Vtmp[i + (int64_t)p * n] = c * vx - s * vy;
+                Vtmp[i + (int64_t)q * n] = s * vx + c * vy;
+            }
+            __syncthreads();
+            // row rotations: A <- J' A
+            for (int e = tid; e < half * n; e += JAC_THREADS) {
+                const int k = e / n, j = e - k * n;
+                const int q = s_q[k];
+                if (q < 0) continue;
+                const int p = s_p[k];
+                const double c = s_c[k], s = s_s[k];
+                if (s == 0.0) continue;
+                const double x = sA[p + j * ldl], y = sA[q + j * ldl];
+                sA[p + j * ldl] = c * x - s * y;
+                sA[q + j * ldl] = s * x + c * y;
+            }
+            __syncthreads();
+        }
+    }
+    // ascending order: rank of every diagonal entry (ties broken by index)
+    for (int i = tid; i < n; i += JAC_THREADS) {
+        const double li = sA[i + i * ldl];
+        int rk = 0;
+        for (int j = 0; j < n; ++j) {
+            const double lj = sA[j + j * ldl];
+            rk += (lj < li) || (lj == li && j < i);
+        }
+        s_rank[i] = rk;
+        wout[rk] = li;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += JAC_THREADS) {
+        const int j = e / n, i = e - j * n;
+        Ag[i + (int64_t)s_rank[j] * lda] = Vtmp[i + (int64_t)j * n];
+    }
+    if (tid == 0) info[0] = (sweep >= 40) ? 1 : 0;
+}
+
+bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double* w, double* Vtmp, int* info) {
+    if (n < 1 || n > JAC_MAXN) return false;
+    const size_t lds = (size_t)((n | 1) * n + 8) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    small_syev_jacobi_kernel<<<1, JAC_THREADS, lds, s>>>((int)n, A, lda, w, Vtmp, info);
+    return true;
+}
+
+}  // namespace sdpsr

@@ -65,3 +65,42 @@ def test_hash_header_compiles_for_host_and_matches_python():
     b2 = (bits >> 16) & 0xFF
     assert int(out[3]) == (b2 - 256 if b2 >= 128 else b2)
     assert float(out[4]) == 0.0625
+
+
+def test_product_path_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under the package (or bench.py outside its
+    cpu_baseline leg, or the C sources) may import, link or execute it."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "sdpsymmetryreduction.jl_amd")
+    offenders = []
+    for base, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".jl")) or f == "Makefile":
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"sdpsr_oracle|oracle/|import oracle|from oracle", txt):
+                    offenders.append(os.path.join(base, f))
+    assert offenders == []
+    bench = open(os.path.join(root, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"sdpsr_oracle", bench)]
+    body = bench[bench.index("def cpu_baseline"):bench.index("def main")]
+    assert len(uses) == body.count("sdpsr_oracle")  # only inside cpu_baseline()
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    import pytest
+    monkeypatch.setattr(pkg._lib, "_lib", None)
+    monkeypatch.setattr(pkg._lib, "LIB_PATH", "/nonexistent/libsdpsr_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg._lib.load_library()
+
+
+def test_no_gpu_means_an_error_not_a_fallback(pkg):
+    """Without a GPU the context cannot be created; nothing silently computes on the CPU."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.SdpsrError):
+        pkg.Context()

@@ -1,0 +1,41 @@
+"""Wall times of the BASELINE.json configs on the GPU (device-resident labels where possible)."""
+import sys, os, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+pkg = load_package(); pr = pkg.problems
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "golden_partitions.npz"))
+def timeit(f, reps=3):
+    best = 1e9
+    for _ in range(reps):
+        t = time.perf_counter(); r = f(); best = min(best, time.perf_counter() - t)
+    return best * 1e3, r
+with pkg.Context(seed=1) as ctx:
+    # config 1: G(1024, 0.5)
+    Cv, A, b = pr.theta_prime_problem(pr.gnp_adjacency(1024, 0.5, seed=11))
+    setup = pkg.admissible_setup(Cv, A, b)
+    ms, P = timeit(lambda: pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup))
+    print("config1 G(1024,.5): admissible %.1f ms (host arrays), dim %d, iters %d, phases %s" % (ms, P.nparts, P.iterations, ["%.2f" % x for x in P.phase_ms[:4]]))
+    ms, r = timeit(lambda: pkg.eigen_decomposition(P, atol=1.5e-8, ctx=ctx), reps=2)
+    print("         eigen_decomposition (dense, 1024 eigenspaces): %.1f ms -> %s" % (ms, r))
+    # config 2: QAP grid 30
+    flow, dist = pr.grid_qap_instance(5, 6, seed=4)
+    Cv, A, b = pr.qap_problem(flow, dist)
+    setup = pkg.admissible_setup(Cv, A, b)
+    ms, P = timeit(lambda: pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup))
+    print("config2 QAP N=900 m=61: admissible %.1f ms, dim %d, iters %d, phases %s" % (ms, P.nparts, P.iterations, ["%.2f" % x for x in P.phase_ms[:4]]))
+    try:
+        ms, bd = timeit(lambda: pkg.blockDiagonalize(P, ctx=ctx), reps=2)
+        print("         blockDiagonalize %.1f ms blocks %s" % (ms, sorted(bd.blkSizes)))
+    except Exception as e:
+        print("         blockDiagonalize:", type(e).__name__, str(e)[:120])
+    # config 3: non-commutative 4104
+    L, d = pr.kron_with_complete(g["er7_P"].astype(np.int64), 72, seed=5)
+    P = pkg.Partition(d, L.astype(np.uint32))
+    ms, bd = timeit(lambda: pkg.blockDiagonalize(P, ctx=ctx))
+    print("config3 ER7xK72 N=4104: blockDiagonalize %.1f ms (host I/O included) blocks %s phases %s" % (ms, sorted(bd.blkSizes), ["%.2f" % x for x in bd.phase_ms[4:8]]))
+    # esc16j end to end
+    fa, fb = pr.read_qapdata(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "esc16j.dat"))
+    Cv, A, b = pr.qap_problem(fa, fb)
+    ms, P = timeit(lambda: pkg.admissible_subspace(Cv, A, b, ctx=ctx))
+    ms2, bd = timeit(lambda: pkg.blockDiagonalize(P, ctx=ctx))
+    print("esc16j N=256: admissible (device setup) %.1f ms dim %d; blockDiagonalize %.1f ms blocks %s" % (ms, P.nparts, ms2, sorted(bd.blkSizes)))
