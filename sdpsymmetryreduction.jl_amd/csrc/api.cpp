@@ -1604,9 +1604,14 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             if (launch_label_spmm(s, n, L, key, d, W, ld, wcols, part, dst, ld)) return SDPSR_OK;
         }
         double* Afull = (double*)ctx_buf(c, "cm_a", (size_t)ld * ld * 8);
-        if (!Afull) return SDPSR_OUT_OF_MEMORY;
+        const int64_t wcp = round_up(wcols, 128);
+        double* tmpo = (double*)ctx_buf(c, "cm_tmpo", (size_t)ld * wcp * 8);
+        if (!Afull || !tmpo) return SDPSR_OUT_OF_MEMORY;
         launch_gather_f64_padded(s, n, ld, L, key, Afull);
-        return gemm_tn_splitk(c, ld, round_up(wcols, 128), ld, Afull, ld, W, ld, dst, ld);
+        int e3 = gemm_tn_splitk(c, ld, wcp, ld, Afull, ld, W, ld, tmpo, ld);
+        if (e3) return e3;
+        HIP_TRY(c, hipMemcpyAsync(dst, tmpo, (size_t)ld * wcols * 8, hipMemcpyDeviceToDevice, s));
+        return SDPSR_OK;
     };
     dbg_mark("compressed: buffers + symmetric check done");
     tm.begin(SDPSR_T_EIGEN);
@@ -1681,65 +1686,89 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             for (int i = 0; i <= cc; ++i) coef[(size_t)perm[i] + (size_t)cc * m] = X[(size_t)i + (size_t)cc * r];
         return r;
     };
-    double ref = 0;  // squared scale of a candidate column before projection (first round)
-    for (int round = 0; round < 40; ++round) {
-        const int64_t wpp = round_up(w, 128);
-        const bool fused = (w <= 64 && d <= 4000);
-        int G = (fused && w <= 16) ? 4 : 2;            // generic elements per round
-        const int64_t cstride = fused ? w : wpp;        // fused products pack their columns densely
-        while (G > 2 && (int64_t)G * cstride > ycap) --G;
-        const int m = G * w;
-        const int64_t mp = round_up((int64_t)(G - 1) * cstride + (fused ? w : wpp), 128);
-        // candidates: Y[:, g*cstride + (0:w)] = A_g W for fresh generic elements A_g
-        HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * mp * 8, s));
-        for (int gidx = 0; gidx < G; ++gidx) {
-            int e2 = apply_generic(w, Y + (size_t)gidx * cstride * ld);
-            if (e2) return e2;
-        }
-        if (round == 0) {
+    double ref = 0;  // squared scale of a candidate column before projection (first batch)
+    // absorb m densely packed candidate columns Y[:, 0:m) into W; returns the number of new
+    // basis vectors (0 = nothing left the span), < 0 on error (status in `abs_err`)
+    int abs_err = SDPSR_OK;
+    auto absorb = [&](int m) -> int {
+        const int64_t mp = round_up(m, 128);
+        if (ref == 0) {
             // scale reference: the candidates before projection (after it, a complete module
             // leaves only rounding noise and a relative test would compare noise with noise)
             gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);
             hG.resize((size_t)mp * mp);
-            { int e2 = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8); if (e2) return e2; }
-            for (int64_t i = 0; i < mp; ++i) ref = std::max(ref, hG[(size_t)i + (size_t)i * mp]);
+            abs_err = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8);
+            if (abs_err) return -1;
+            for (int64_t i = 0; i < m; ++i) ref = std::max(ref, hG[(size_t)i + (size_t)i * mp]);
         }
-        project_off_W(Y, mp, (int)mp);
+        project_off_W(Y, mp, m);
         gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);  // Gram
         hG.resize((size_t)mp * mp);
-        { int e2 = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8); if (e2) return e2; }
-        // compact the G groups (columns between the groups are zero)
-        std::vector<double> Gc((size_t)m * m);
-        auto src = [&](int i) { return (int64_t)(i / w) * cstride + (i % w); };
-        for (int j = 0; j < m; ++j)
-            for (int i = 0; i < m; ++i) Gc[(size_t)i + (size_t)j * m] = hG[(size_t)src(i) + (size_t)src(j) * mp];
+        abs_err = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8);
+        if (abs_err) return -1;
         std::vector<double> coefc;
-        const int r_new = gram_select(Gc, m, m, 1e-12 * ref, coefc);
-        if (r_new == 0) break;
+        const int r_new = gram_select(hG, mp, m, 1e-12 * ref, coefc);
+        if (r_new == 0) return 0;
         if (w + r_new >= wmax) {
-            tm.end();
-            tm.collect();
-            return krylov_fallback(c, "module dimension exceeds " + std::to_string(wmax));
+            abs_err = krylov_fallback(c, "module dimension exceeds " + std::to_string(wmax));
+            return -1;
         }
-        // Q1 = Y * coef (expand the compact coefficients to the padded row layout)
-        hS.assign((size_t)mp * r_new, 0.0);
-        for (int cc = 0; cc < r_new; ++cc)
-            for (int i = 0; i < m; ++i) hS[(size_t)src(i) + (size_t)cc * mp] = coefc[(size_t)i + (size_t)cc * m];
-        { int e2 = h2d_sync(c, dSm, hS.data(), (size_t)mp * r_new * 8); if (e2) return e2; }
+        // Q1 = Y * coef
+        abs_err = h2d_sync(c, dSm, coefc.data(), (size_t)m * r_new * 8);
+        if (abs_err) return -1;
         const int64_t rp = round_up(r_new, 128);
-        HIP_TRY(c, hipMemsetAsync(Q1, 0, (size_t)ld * rp * 8, s));
-        launch_tall_times_small(s, n, ld, Y, (int)mp, dSm, (int)mp, r_new, 1.0, 0.0, Q1, ld);
+        if (hipMemsetAsync(Q1, 0, (size_t)ld * rp * 8, s) != hipSuccess) {
+            abs_err = ctx_fail(c, SDPSR_HIP_ERROR, "memset");
+            return -1;
+        }
+        launch_tall_times_small(s, n, ld, Y, m, dSm, m, r_new, 1.0, 0.0, Q1, ld);
         // second orthonormalisation pass (CholQR2): off W again, then Gram + Cholesky of Q1 itself
         project_off_W(Q1, rp, r_new);
         gemm_tn_splitk(c, rp, rp, ld, Q1, ld, Q1, ld, Cc, rp);
         hG.resize((size_t)rp * rp);
-        { int e2 = d2h_sync(c, hG.data(), Cc, (size_t)rp * rp * 8); if (e2) return e2; }
+        abs_err = d2h_sync(c, hG.data(), Cc, (size_t)rp * rp * 8);
+        if (abs_err) return -1;
         std::vector<double> coef2;
         const int r2 = gram_select(hG, rp, r_new, 1e-6, coef2);  // Q1 columns have unit scale
-        if (r2 <= 0) break;
-        { int e2 = h2d_sync(c, dSm, coef2.data(), (size_t)r_new * r2 * 8); if (e2) return e2; }
+        if (r2 <= 0) return 0;
+        abs_err = h2d_sync(c, dSm, coef2.data(), (size_t)r_new * r2 * 8);
+        if (abs_err) return -1;
         launch_tall_times_small(s, n, ld, Q1, r_new, dSm, r_new, r2, 1.0, 0.0, W + (size_t)w * ld, ld);
         w += r2;
+        return r2;
+    };
+    // level 1: S x = span{P_i x}: all d class sums of x in ONE pass over the labels (the
+    // row-sum kernel of basis_image with a single column).  For a commutative algebra this
+    // already is the whole module.
+    if (ld == n && basis_image_two_stage_fits(n, d, 1) && d <= ycap && d + 1 < wmax) {
+        HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * round_up(d, 128) * 8, s));
+        launch_class_sums(s, n, d, L, W, Y);  // Y[:, i] = P_{i+1} x
+        const int got = absorb((int)d);
+        if (got < 0) {
+            tm.end();
+            tm.collect();
+            return abs_err;
+        }
+    }
+    for (int round = 0; round < 40; ++round) {
+        const bool fused = (w <= 64 && d <= 4000);
+        int G = (fused && w <= 16) ? 4 : 2;  // generic elements per round
+        while (G > 2 && (int64_t)G * w > ycap) --G;
+        if ((int64_t)G * w > ycap) G = 1;
+        const int m = G * w;
+        // candidates: Y[:, g*w + (0:w)] = A_g W for fresh generic elements A_g
+        HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * round_up(m, 128) * 8, s));
+        for (int gidx = 0; gidx < G; ++gidx) {
+            int e2 = apply_generic(w, Y + (size_t)gidx * w * ld);
+            if (e2) return e2;
+        }
+        const int got = absorb(m);
+        if (got < 0) {
+            tm.end();
+            tm.collect();
+            return abs_err;
+        }
+        if (got == 0) break;
     }
     // columns >= w must be zero for the padded products below
     const int64_t wp = round_up(w, 128);

@@ -329,6 +329,13 @@ bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1) {
     return n <= 65535 && (2 * (d + 2) * 4 + n * 2) <= 60 * 1024 && d * n * S1 * 8 <= ((int64_t)4 << 30);
 }
 
+void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out) {
+    const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    basis_image_rows_kernel<<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, 1, L, x, out);
+}
+
 void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks,
                                   const uint32_t* L, const double* Qrm, double* T, const int32_t* blk_col,
                                   const int32_t* blk_size, const int64_t* blk_off, double atol, double* out) {
