@@ -335,3 +335,52 @@ def test_dense_convenience_entry(pkg, problems, golden, gpu_ctx):
                                                       C.byref(d), C.byref(it), None, 0))
     assert d.value == 15
     assert np.array_equal(P.reshape(n, n, order="F"), golden["er5_P"])
+
+
+# ------------------------------------------------------------------ edge cases
+def test_tiny_and_degenerate_inputs(pkg, oracle, gpu_ctx):
+    # 1 x 1
+    P = pkg.Partition.from_matrix(np.array([[1]]), ctx=gpu_ctx)
+    bd = pkg.blockDiagonalize(P, ctx=gpu_ctx)
+    assert bd.blkSizes == [1] and abs(bd.blks[0][0][0, 0] - 1.0) < 1e-12
+    # 2 x 2 full symmetric algebra: one block of size 2.  The Otsu threshold of the reference
+    # (src/eigen_decomposition.jl:112-139) needs a gap between zero and non-zero couplings, which a
+    # full matrix algebra does not have: the oracle itself ends in DimensionMismatch on ~60 % of the
+    # draws here, so retry like the error text asks ("try again").
+    P = pkg.Partition.from_matrix(np.array([[1, 2], [2, 3]]), ctx=gpu_ctx)
+    bd = pkg.blockDiagonalize(P, ctx=gpu_ctx, retries=200)
+    assert bd.blkSizes == [2]
+    # identity-only partition (diagonal class, zeros elsewhere): n blocks?  dim = 1, generic
+    # element = x*I has ONE eigenspace -> one block of size 1: 1*2/2 == dim(P)
+    P = pkg.Partition.from_matrix(np.eye(5), ctx=gpu_ctx)
+    assert P.nparts == 1
+    bd = pkg.blockDiagonalize(P, ctx=gpu_ctx)
+    assert bd.blkSizes == [1]
+    # all-zero partition: dim 0, the decomposition cannot match -> DimensionMismatch, no crash
+    Z = pkg.Partition(0, np.zeros((4, 4), dtype=np.uint32))
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.blockDiagonalize(Z, ctx=gpu_ctx)
+
+
+def test_admissible_without_constraints_and_bad_arguments(pkg, problems, oracle, gpu_ctx):
+    # m = 0 constraints: L is the whole space, x0 = 0, the loop only squares
+    n = 12
+    rng = np.random.default_rng(0)
+    M = rng.integers(1, 4, size=(n, n))
+    M = np.triu(M) + np.triu(M, 1).T
+    Cv = M.astype(np.float64).ravel(order="F")
+    A = np.zeros((0, n * n))
+    b = np.zeros(0)
+    ref = oracle.admissible_subspace(Cv, A, b, rng=np.random.default_rng(1))
+    P = pkg.admissible_subspace(Cv, A, b, ctx=gpu_ctx, host_setup=True)
+    assert P.nparts == ref.nparts and np.array_equal(P.matrix, ref.matrix)
+    Pd = pkg.admissible_subspace(Cv, A, b, ctx=gpu_ctx)  # device setup with m = 0
+    assert np.array_equal(Pd.matrix, ref.matrix)
+    # @assert n^2 == length(C) (src/partitions.jl:118)
+    with pytest.raises(ValueError):
+        pkg.admissible_subspace(np.ones(10), np.zeros((1, 10)), np.zeros(1), ctx=gpu_ctx)
+    # null pointers / bad sizes come back as BAD_ARGUMENT, never as a fault
+    lib = pkg.load_library()
+    d = C.c_int64(0)
+    assert lib.sdpsr_partition_from_f64(gpu_ctx._h, 0, None, None, C.byref(d), 0) == 5
+    assert lib.sdpsr_block_diagonalize(gpu_ctx._h, 0, None, 0, 1e-8, None, None, None, None, 0) == 5
