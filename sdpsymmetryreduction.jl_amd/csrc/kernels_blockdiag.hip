@@ -225,7 +225,7 @@ void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, const double* __restrict__ Qrm,
-                        double* __restrict__ T) {
+                        double* __restrict__ T, int lower) {
     // One wave per row r.  The n labels of column r of L (== row r, symmetric partition) are
     // first sorted by class with a STABLE counting sort in LDS (ranks inside a 64-entry chunk
     // come from ballots over the distinct labels of the chunk), then every class segment is
@@ -235,8 +235,13 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
     int* s_start = s_off + (d + 2);                                      // [d + 2] segment starts
     unsigned short* s_pos = reinterpret_cast<unsigned short*>(s_start + (d + 2));  // [n] sorted entries
     const int lane = threadIdx.x;
-    const int r = blockIdx.x;
+    // lower != 0: only the strictly lower part of the row (entries c < r); the caller adds the
+    // mirrored half and the diagonal (the partition and every 1[P==i] are symmetric).  Rows are
+    // walked from the longest to the shortest so that the tail of the grid is short work.
+    const int r = lower ? (n - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const uint32_t* col = L + (int64_t)r * n;
+    const int nn = n;
+    n = lower ? r : n;  // entries considered
     for (int t = lane; t < d + 2; t += 64) s_off[t] = 0;
     __syncthreads();
     for (int c = lane; c < n; c += 64) atomicAdd(&s_off[col[c] + 1], 1);  // histogram, shifted by one
@@ -289,7 +294,7 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
                     a3 += q3;
                 }
                 for (; p < p1; ++p) a0 += Qrm[(int64_t)s_pos[p] * S1 + j];
-                T[((int64_t)(i - 1) * n + r) * S1 + j] = (a0 + a1) + (a2 + a3);
+                T[((int64_t)(i - 1) * nn + r) * S1 + j] = (a0 + a1) + (a2 + a3);
             }
         }
     }
@@ -299,7 +304,8 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
 __global__ void __launch_bounds__(256)
 basis_image_blocks_kernel(int n, int S1, int64_t S, const double* __restrict__ Qrm, const double* __restrict__ T,
                           const int32_t* __restrict__ blk_col, const int32_t* __restrict__ blk_size,
-                          const int64_t* __restrict__ blk_off, double atol, double* __restrict__ out) {
+                          const int64_t* __restrict__ blk_off, double atol, double* __restrict__ out,
+                          const uint32_t* __restrict__ L, int lower) {
     __shared__ double red[256];
     const int i = blockIdx.x, k = blockIdx.y;
     const int s = blk_size[k], cb = blk_col[k];
@@ -312,7 +318,17 @@ basis_image_blocks_kernel(int n, int S1, int64_t S, const double* __restrict__ Q
         double acc = 0;
         if (p < ss) {
             const int a = p % s, b = p / s;
-            for (int r = g; r < n; r += 16) acc = fma(Qrm[(int64_t)r * S1 + cb + a], Ti[(int64_t)r * S1 + cb + b], acc);
+            if (!lower) {
+                for (int r = g; r < n; r += 16) acc = fma(Qrm[(int64_t)r * S1 + cb + a], Ti[(int64_t)r * S1 + cb + b], acc);
+            } else {
+                // U[a,b] + U[b,a] + diagonal entries of the class
+                for (int r = g; r < n; r += 16) {
+                    const double qa = Qrm[(int64_t)r * S1 + cb + a], qb = Qrm[(int64_t)r * S1 + cb + b];
+                    acc = fma(qa, Ti[(int64_t)r * S1 + cb + b], acc);
+                    acc = fma(qb, Ti[(int64_t)r * S1 + cb + a], acc);
+                    if (L[(int64_t)r * n + r] == (uint32_t)(i + 1)) acc = fma(qa, qb, acc);
+                }
+            }
         }
         red[threadIdx.x] = acc;
         __syncthreads();
@@ -333,7 +349,7 @@ void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, c
     const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    basis_image_rows_kernel<<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, 1, L, x, out);
+    basis_image_rows_kernel<<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, 1, L, x, out, 0);
 }
 
 void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks,
@@ -346,9 +362,9 @@ void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S
                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_set = true;
     }
-    basis_image_rows_kernel<<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T);
+    basis_image_rows_kernel<<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T, 1);
     dim3 g((unsigned)d, (unsigned)nblocks);
-    basis_image_blocks_kernel<<<g, 256, 0, s>>>((int)n, (int)S1, S, Qrm, T, blk_col, blk_size, blk_off, atol, out);
+    basis_image_blocks_kernel<<<g, 256, 0, s>>>((int)n, (int)S1, S, Qrm, T, blk_col, blk_size, blk_off, atol, out, L, 1);
 }
 
 // Qrm[r * S1 + k] = Qcm[r + k * n]
