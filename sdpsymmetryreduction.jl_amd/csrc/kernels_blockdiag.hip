@@ -1,6 +1,7 @@
 // Kernels of the block-diagonalisation stage (src/eigen_decomposition.jl:177-219,295-348,
 // src/diagonalize.jl:42-89): eigenspace block norms, the small products of
 // irreducible_decomposition, and basis_image as a segmented outer-product reduction.
+#include <type_traits>
 #include "sdpsr_internal.h"
 
 #include <hipcub/hipcub.hpp>
@@ -223,6 +224,7 @@ void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t
 //   stage 2   blks[i][k] = Q_k' T_i[:, cols_k]   (s_k x s_k dots over n).
 // Work n^2 S1 + d n sum s_k^2 instead of n^2 sum s_k^2 gathers.
 // ---------------------------------------------------------------------------
+template <int VEC>
 __global__ void __launch_bounds__(64)
 basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, const double* __restrict__ Qrm,
                         double* __restrict__ T, int lower) {
@@ -244,7 +246,22 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
     n = lower ? r : n;  // entries considered
     for (int t = lane; t < d + 2; t += 64) s_off[t] = 0;
     __syncthreads();
-    for (int c = lane; c < n; c += 64) atomicAdd(&s_off[col[c] + 1], 1);  // histogram, shifted by one
+    // peers(l) = lanes of the chunk that hold the same label, from one ballot per label bit (no
+    // loop over the distinct labels); the lowest peer is the leader that updates the counters.
+    const int nbits = 32 - __clz(d);  // labels 0..d
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int c0 = 0; c0 < n; c0 += 64) {  // histogram, shifted by one
+        const int c = c0 + lane;
+        const bool valid = c < n;
+        const uint32_t l = valid ? col[c] : 0u;
+        unsigned long long m = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            const bool bit = (l >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        if (valid && (m & lt_mask) == 0ull) s_off[l + 1] += __popcll(m);
+    }
     __syncthreads();
     if (lane == 0) {  // exclusive scan (d + 1 classes incl. the zero class)
         int run = 0;
@@ -258,43 +275,66 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
     __syncthreads();
     for (int t = lane; t < d + 2; t += 64) s_off[t] = s_start[t];
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 64) {
+    for (int c0 = 0; c0 < n; c0 += 64) {  // stable scatter of the entry indices
         const int c = c0 + lane;
         const bool valid = c < n;
-        const uint32_t l = valid ? col[c] : 0xFFFFFFFFu;
-        unsigned long long remaining = __ballot(valid);
-        while (remaining) {
-            const int leader = __ffsll((long long)remaining) - 1;
-            const uint32_t ll = __shfl(l, leader, 64);
-            const unsigned long long mask = __ballot(valid && l == ll);
-            if (valid && l == ll) {
-                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                s_pos[s_off[ll] + rank] = (unsigned short)c;
-            }
-            // all lanes read s_off[ll] above before the leader bumps it: same wave, in-order LDS
-            if (lane == leader) s_off[ll] += __popcll(mask);
-            remaining &= ~mask;
+        const uint32_t l = valid ? col[c] : 0u;
+        unsigned long long m = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            const bool bit = (l >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        if (valid) {
+            const int base = s_off[l];  // read by every peer before the leader bumps it (in-order LDS)
+            const int rank = __popcll(m & lt_mask);
+            s_pos[base + rank] = (unsigned short)c;
+            if (rank == 0) s_off[l] = base + __popcll(m);
         }
     }
     __syncthreads();
-    for (int j0 = 0; j0 < S1; j0 += 64) {
-        const int j = j0 + lane;
+    // Segment sums.  A lane owns VEC adjacent columns of Qhat (16-byte loads when VEC == 2); when
+    // fewer than 64 lanes are needed for the S1 columns the wave splits into `groups` lane groups
+    // that stride the segment, and a fixed xor-tree adds the groups: fixed order, reproducible.
+    typedef typename std::conditional<VEC == 2, double2, double>::type vec_t;
+    const int cols = S1 / VEC;
+    int sub = 1;
+    while (sub < cols && sub < 64) sub <<= 1;
+    const int groups = 64 / sub;
+    const int jl = lane & (sub - 1), g = lane / sub;
+    const vec_t* __restrict__ Qv = reinterpret_cast<const vec_t*>(Qrm);
+    for (int j0 = 0; j0 < cols; j0 += sub) {
+        const int j = j0 + jl;
+        const bool act = j < cols;
         for (int i = 1; i <= d; ++i) {
             const int p0 = s_start[i], p1 = s_start[i + 1];
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            int p = p0;
-            if (j < S1) {
-                for (; p + 3 < p1; p += 4) {
-                    const int c0 = s_pos[p], c1 = s_pos[p + 1], c2 = s_pos[p + 2], c3 = s_pos[p + 3];
-                    const double q0 = Qrm[(int64_t)c0 * S1 + j], q1 = Qrm[(int64_t)c1 * S1 + j];
-                    const double q2 = Qrm[(int64_t)c2 * S1 + j], q3 = Qrm[(int64_t)c3 * S1 + j];
-                    a0 += q0;
-                    a1 += q1;
-                    a2 += q2;
-                    a3 += q3;
+            double a[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) a[u][v] = 0.0;
+            if (act) {
+                int p = p0 + g;
+                for (; p + 7 * groups < p1; p += 8 * groups) {
+                    vec_t q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) q[u] = Qv[(int64_t)s_pos[p + u * groups] * cols + j];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) a[u][v] += reinterpret_cast<const double*>(&q[u])[v];
                 }
-                for (; p < p1; ++p) a0 += Qrm[(int64_t)s_pos[p] * S1 + j];
-                T[((int64_t)(i - 1) * nn + r) * S1 + j] = (a0 + a1) + (a2 + a3);
+                for (; p < p1; p += groups) {
+                    const vec_t q = Qv[(int64_t)s_pos[p] * cols + j];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) a[0][v] += reinterpret_cast<const double*>(&q)[v];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                double t = ((a[0][v] + a[1][v]) + (a[2][v] + a[3][v])) + ((a[4][v] + a[5][v]) + (a[6][v] + a[7][v]));
+                for (int off = sub; off < 64; off <<= 1) t += __shfl_xor(t, off, 64);
+                if (act && g == 0) T[((int64_t)(i - 1) * nn + r) * S1 + (int64_t)j * VEC + v] = t;
             }
         }
     }
@@ -347,9 +387,9 @@ bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1) {
 
 void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out) {
     const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    basis_image_rows_kernel<<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, 1, L, x, out, 0);
+    basis_image_rows_kernel<1><<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, 1, L, x, out, 0);
 }
 
 void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks,
@@ -358,11 +398,16 @@ void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S
     const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_set = true;
     }
-    basis_image_rows_kernel<<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T, 1);
+    if (S1 % 2 == 0)  // rows of Qrm are 16-byte aligned
+        basis_image_rows_kernel<2><<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T, 1);
+    else
+        basis_image_rows_kernel<1><<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T, 1);
     dim3 g((unsigned)d, (unsigned)nblocks);
     basis_image_blocks_kernel<<<g, 256, 0, s>>>((int)n, (int)S1, S, Qrm, T, blk_col, blk_size, blk_off, atol, out, L, 1);
 }
