@@ -515,32 +515,36 @@ void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, 
 // w < 2 dim P) and the reference's small test algebras are this size; the blocked
 // tridiagonalisation path costs ~5 launches per column there, i.e. pure launch latency.
 // Round-robin ordering: n/2 disjoint rotations per step, n-1 steps per sweep; every step is
-// (angles) -> barrier -> (column rotations of A and V) -> barrier -> (row rotations of A).
+// (angles) -> barrier -> (two-sided 2 x 2 block updates of A, column rotations of V) -> barrier.
 // ---------------------------------------------------------------------------
 namespace sdpsr {
 
-constexpr int JAC_THREADS = 1024;
+constexpr int JAC_MAXTHREADS = 1024;
 constexpr int JAC_MAXN = 128;
 
-__global__ void __launch_bounds__(JAC_THREADS)
+__global__ void __launch_bounds__(JAC_MAXTHREADS)
 small_syev_jacobi_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __restrict__ wout,
-                         double* __restrict__ Vtmp, int* __restrict__ info) {
+                         double* __restrict__ Vglob, int* __restrict__ info, int v_in_lds) {
     extern __shared__ __attribute__((aligned(16))) double sA[];  // n x n, leading dimension ldl
     __shared__ double s_c[JAC_MAXN / 2], s_s[JAC_MAXN / 2];
     __shared__ int s_p[JAC_MAXN / 2], s_q[JAC_MAXN / 2];
-    __shared__ double s_red[JAC_THREADS / 64];
+    __shared__ double s_red[JAC_MAXTHREADS / 64];
     __shared__ double s_off, s_diag;
     __shared__ int s_rank[JAC_MAXN];
     const int tid = threadIdx.x;
+    const int JAC_THREADS = blockDim.x;
     const int ldl = n | 1;  // odd leading dimension: column walks hit distinct banks
     const int m = (n + 1) & ~1;  // players of the tournament (a dummy one when n is odd)
     const int half = m >> 1;
+    // the eigenvector accumulator lives in LDS next to A when both fit (n <= 96), else in global
+    double* __restrict__ Vtmp = v_in_lds ? (sA + (size_t)ldl * n + 8) : Vglob;
+    const int ldv = v_in_lds ? ldl : n;
     // load A (symmetric part from the lower triangle, like LAPACK with uplo = 'L') and V = I
     for (int e = tid; e < n * n; e += JAC_THREADS) {
         const int j = e / n, i = e - j * n;
         const int ii = i > j ? i : j, jj = i > j ? j : i;
         sA[i + j * ldl] = Ag[ii + (int64_t)jj * lda];
-        Vtmp[i + (int64_t)j * n] = (i == j) ? 1.0 : 0.0;
+        Vtmp[i + j * ldv] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
     int sweep = 0;
@@ -574,7 +578,10 @@ small_syev_jacobi_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __
             s_diag = t;
         }
         __syncthreads();
-        if (s_off <= 1e-30 * (s_diag + s_off) || s_off == 0.0) break;
+        // stop at the backward-error level of a LAPACK solver: ||off(A)||_F <= n eps ||A||_F (the
+        // rounding floor of the sweeps themselves is ~ sqrt(n) eps, a tighter bound only spins)
+        const double tolr = (double)n * 2.220446049250313e-16;
+        if (s_off <= tolr * tolr * (s_diag + s_off) || s_off == 0.0) break;
         for (int step = 0; step < m - 1; ++step) {
             if (tid < half) {
                 int p, q;
@@ -594,11 +601,34 @@ small_syev_jacobi_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __
                 if (q < n) {
                     const double apq = sA[p + q * ldl];
                     if (apq != 0.0) {
-                        const double app = sA[p + p * ldl], aqq = sA[q + q * ldl];
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(t * t + 1.0);
+                        // t = tan of the rotation angle (smaller root), c = 1/sqrt(1+t^2), s = t c.
+                        // Hardware reciprocal / reciprocal-square-root seeds plus Newton steps in
+                        // FMAs instead of the IEEE division and sqrt sequences (which dominated the
+                        // step): only c needs full precision (c^2 + s^2 = 1 keeps V orthogonal), an
+                        // error in t merely leaves a residual a_pq for the next sweep.
+                        const double dd = sA[q + q * ldl] - sA[p + p * ldl], bb = 2.0 * apq;
+                        const double h2 = fma(dd, dd, bb * bb);
+                        if (!(h2 > 1e-280 && h2 < 1e280)) {  // out of the seeds' range: IEEE sequences
+                            const double theta = dd / bb;
+                            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                            c = 1.0 / sqrt(t * t + 1.0);
+                            s = t * c;
+                        } else {
+                        double y = __builtin_amdgcn_rsq(h2);
+                        y = y * fma(-0.5 * h2 * y, y, 1.5);
+                        const double r = h2 * y;  // hypot(dd, bb)
+                        const double den = fabs(dd) + r;
+                        double ri = __builtin_amdgcn_rcp(den);
+                        ri = ri * fma(-den, ri, 2.0);
+                        ri = ri * fma(-den, ri, 2.0);
+                        const double t = (dd >= 0 ? bb : -bb) * ri;
+                        const double u = fma(t, t, 1.0);
+                        double z = __builtin_amdgcn_rsq(u);
+                        z = z * fma(-0.5 * u * z, z, 1.5);
+                        z = z * fma(-0.5 * u * z, z, 1.5);
+                        c = z;
                         s = t * c;
+                        }
                     }
                 }
                 s_c[tid] = c;
@@ -607,7 +637,25 @@ small_syev_jacobi_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __
                 s_q[tid] = (q < n) ? q : -1;
             }
             __syncthreads();
-            // column rotations: A <- A J, V <- V J
+            // A <- J' A J on the 2 x 2 blocks (row pair k1, column pair k2): one thread owns a block,
+            // so the two-sided update needs no barrier in between; V <- V J alongside
+            for (int e = tid; e < half * half; e += JAC_THREADS) {
+                const int k1 = e / half, k2 = e - k1 * half;
+                const int r0 = s_p[k1], r1 = s_q[k1], c0 = s_p[k2], c1 = s_q[k2];
+                const double cr = s_c[k1], sr = s_s[k1], cc = s_c[k2], sc = s_s[k2];
+                if (sr == 0.0 && sc == 0.0) continue;
+                const bool vr = r1 >= 0, vc = c1 >= 0;
+                const double x00 = sA[r0 + c0 * ldl];
+                const double x01 = vc ? sA[r0 + c1 * ldl] : 0.0;
+                const double x10 = vr ? sA[r1 + c0 * ldl] : 0.0;
+                const double x11 = (vr && vc) ? sA[r1 + c1 * ldl] : 0.0;
+                const double y00 = cr * x00 - sr * x10, y10 = sr * x00 + cr * x10;
+                const double y01 = cr * x01 - sr * x11, y11 = sr * x01 + cr * x11;
+                sA[r0 + c0 * ldl] = cc * y00 - sc * y01;
+                if (vc) sA[r0 + c1 * ldl] = sc * y00 + cc * y01;
+                if (vr) sA[r1 + c0 * ldl] = cc * y10 - sc * y11;
+                if (vr && vc) sA[r1 + c1 * ldl] = sc * y10 + cc * y11;
+            }
             for (int e = tid; e < half * n; e += JAC_THREADS) {
                 const int k = e / n, i = e - k * n;
                 const int q = s_q[k];
@@ -615,25 +663,9 @@ small_syev_jacobi_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __
                 const int p = s_p[k];
                 const double c = s_c[k], s = s_s[k];
                 if (s == 0.0) continue;
-                const double x = sA[i + p * ldl], y = sA[i + q * ldl];
-                sA[i + p * ldl] = c * x - s * y;
-                sA[i + q * ldl] = s * x + c * y;
-                const double vx = Vtmp[i + (int64_t)p * n], vy = Vtmp[i + (int64_t)q * n];
-                Vtmp[i + (int64_t)p * n] = c * vx - s * vy;
-                Vtmp[i + (int64_t)q * n] = s * vx + c * vy;
-            }
-            __syncthreads();
-            // row rotations: A <- J' A
-            for (int e = tid; e < half * n; e += JAC_THREADS) {
-                const int k = e / n, j = e - k * n;
-                const int q = s_q[k];
-                if (q < 0) continue;
-                const int p = s_p[k];
-                const double c = s_c[k], s = s_s[k];
-                if (s == 0.0) continue;
-                const double x = sA[p + j * ldl], y = sA[q + j * ldl];
-                sA[p + j * ldl] = c * x - s * y;
-                sA[q + j * ldl] = s * x + c * y;
+                const double vx = Vtmp[i + p * ldv], vy = Vtmp[i + q * ldv];
+                Vtmp[i + p * ldv] = c * vx - s * vy;
+                Vtmp[i + q * ldv] = s * vx + c * vy;
             }
             __syncthreads();
         }
@@ -652,21 +684,27 @@ small_syev_jacobi_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __
     __syncthreads();
     for (int e = tid; e < n * n; e += JAC_THREADS) {
         const int j = e / n, i = e - j * n;
-        Ag[i + (int64_t)s_rank[j] * lda] = Vtmp[i + (int64_t)j * n];
+        Ag[i + (int64_t)s_rank[j] * lda] = Vtmp[i + j * ldv];
     }
     if (tid == 0) info[0] = (sweep >= 40) ? 1 : 0;
 }
 
 bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double* w, double* Vtmp, int* info) {
     if (n < 1 || n > JAC_MAXN) return false;
-    const size_t lds = (size_t)((n | 1) * n + 8) * sizeof(double);
+    size_t lds = (size_t)((n | 1) * n + 8) * sizeof(double);
+    const int v_in_lds = (2 * lds <= 150 * 1024) ? 1 : 0;
+    if (v_in_lds) lds *= 2;
+    // one thread per element of the n/2 rotated column pairs, whole waves, at most 1024
+    int threads = (int)(((n + 1) / 2) * n + 63) / 64 * 64;
+    if (threads > JAC_MAXTHREADS) threads = JAC_MAXTHREADS;
+    if (threads < 64) threads = 64;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    small_syev_jacobi_kernel<<<1, JAC_THREADS, lds, s>>>((int)n, A, lda, w, Vtmp, info);
+    small_syev_jacobi_kernel<<<1, threads, lds, s>>>((int)n, A, lda, w, Vtmp, info, v_in_lds);
     return true;
 }
 
