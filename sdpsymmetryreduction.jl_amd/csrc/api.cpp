@@ -142,7 +142,26 @@ int d2h_sync(sdpsr_ctx* c, void* host, const void* dev, size_t bytes) {
     memcpy(host, p, bytes);
     return SDPSR_OK;
 }
+// Upload of a small host array.  Up to H2D_SLOT bytes go through a ring of pinned slots and stay
+// stream-ordered (the caller's buffer is free on return, no host wait); the stream is only
+// synchronised when the ring wraps, so a slot is never rewritten while its copy is in flight.
+constexpr size_t H2D_SLOT = 32 * 1024;
+constexpr int H2D_SLOTS = 16;
 int h2d_sync(sdpsr_ctx* c, void* dev, const void* host, size_t bytes) {
+    if (bytes <= H2D_SLOT) {
+        if (!c->h2d_ring && hipHostMalloc(&c->h2d_ring, H2D_SLOT * H2D_SLOTS, hipHostMallocDefault) != hipSuccess) {
+            c->h2d_ring = nullptr;
+            return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned upload ring");
+        }
+        if (c->h2d_ring_next == H2D_SLOTS) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->h2d_ring_next = 0;
+        }
+        void* slot = (char*)c->h2d_ring + (size_t)c->h2d_ring_next++ * H2D_SLOT;
+        memcpy(slot, host, bytes);
+        HIP_TRY(c, hipMemcpyAsync(dev, slot, bytes, hipMemcpyHostToDevice, c->stream));
+        return SDPSR_OK;
+    }
     void* p = ctx_pinned(c, bytes);
     if (!p) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
     memcpy(p, host, bytes);
@@ -327,6 +346,7 @@ void sdpsr_destroy(sdpsr_ctx* c) {
     for (auto& kv : c->bufs)
         if (kv.second.p) hipFree(kv.second.p);
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->h2d_ring) hipHostFree(c->h2d_ring);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1514,11 +1534,13 @@ int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen*
     double* inv = (double*)ctx_buf(c, "bd_inv", 64);
     if (!wv || !cv || !inv) return SDPSR_OUT_OF_MEMORY;
     int64_t col = 0;
+    std::vector<int32_t> cp_src, cp_dst;  // first members, copied in one launch after the loop
     for (size_t p = 0; p < roots.size(); ++p) {
         const int i = roots[p];
         const int64_t mi = info.ptrs[i + 1] - info.ptrs[i];
         // first member: P1 = I -> first eigenvector of Ei (:311-313, :326)
-        launch_copy_col(s, n, Q + (size_t)info.ptrs[i] * ld, Qhat + (size_t)col * n);
+        cp_src.push_back((int32_t)info.ptrs[i]);
+        cp_dst.push_back((int32_t)col);
         ++col;
         for (size_t q = 1; q < members[p].size(); ++q) {
             const int j = members[p][q];
@@ -1533,6 +1555,7 @@ int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen*
             ++col;
         }
     }
+    launch_copy_cols(s, n, (int64_t)cp_src.size(), cp_src.data(), cp_dst.data(), Q, ld, Qhat, n);
     launch_clamptol(s, n * S1, Qhat, atol);  // src/diagonalize.jl:39
     tm.end();
     HIP_TRY(c, hipGetLastError());
@@ -1628,9 +1651,10 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     const int64_t ycap = 2 * wcap;
     double* Y = (double*)ctx_buf(c, "cm_y", (size_t)ld * ycap * 8);
     double* Cc = (double*)ctx_buf(c, "cm_c", (size_t)ycap * ycap * 8);
-    double* dSm = (double*)ctx_buf(c, "cm_sm", (size_t)ycap * ycap * 8);
+    double* dSm = (double*)ctx_buf(c, "cm_sm", (size_t)(ycap * ycap + ycap) * 8);
+    double* nrm_part = (double*)ctx_buf(c, "cm_nrm_part", (size_t)ycap * 64 * 8);
     double* Q1 = (double*)ctx_buf(c, "cm_q1", (size_t)ld * ycap * 8);
-    if (!Y || !Cc || !dSm || !Q1) return SDPSR_OUT_OF_MEMORY;
+    if (!Y || !Cc || !dSm || !Q1 || !nrm_part) return SDPSR_OUT_OF_MEMORY;
     std::vector<double> hG, hS;
     auto project_off_W = [&](double* Yb, int64_t ncolp, int ncol) {  // Yb -= W (W' Yb), twice
         const int64_t wpp = round_up(w, 128);
@@ -1692,20 +1716,18 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     int abs_err = SDPSR_OK;
     auto absorb = [&](int m) -> int {
         const int64_t mp = round_up(m, 128);
-        if (ref == 0) {
-            // scale reference: the candidates before projection (after it, a complete module
-            // leaves only rounding noise and a relative test would compare noise with noise)
-            gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);
-            hG.resize((size_t)mp * mp);
-            abs_err = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8);
-            if (abs_err) return -1;
-            for (int64_t i = 0; i < m; ++i) ref = std::max(ref, hG[(size_t)i + (size_t)i * mp]);
-        }
+        const bool need_ref = (ref == 0);
+        // scale reference: squared column norms of the candidates BEFORE projection (after it, a
+        // complete module leaves only rounding noise and a relative test would compare noise with
+        // noise); they ride behind the Gram matrix in the same read-back
+        if (need_ref) launch_col_norms2(s, ld, m, Y, nrm_part, 64, dSm + (size_t)mp * mp);
         project_off_W(Y, mp, m);
         gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);  // Gram
-        hG.resize((size_t)mp * mp);
-        abs_err = d2h_sync(c, hG.data(), dSm, (size_t)mp * mp * 8);
+        hG.resize((size_t)mp * mp + (size_t)m);
+        abs_err = d2h_sync(c, hG.data(), dSm, ((size_t)mp * mp + (need_ref ? (size_t)m : 0)) * 8);
         if (abs_err) return -1;
+        if (need_ref)
+            for (int64_t i = 0; i < m; ++i) ref = std::max(ref, hG[(size_t)mp * mp + (size_t)i]);
         std::vector<double> coefc;
         const int r_new = gram_select(hG, mp, m, 1e-12 * ref, coefc);
         if (r_new == 0) return 0;
@@ -1754,7 +1776,10 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         const bool fused = (w <= 64 && d <= 4000);
         int G = (fused && w <= 16) ? 4 : 2;  // generic elements per round
         while (G > 2 && (int64_t)G * w > ycap) --G;
-        if ((int64_t)G * w > ycap) G = 1;
+        // dim <S> x <= dim S = d: once w has reached d the round is (almost surely) only the
+        // invariance check, for which ONE generic element suffices (the elements that map the
+        // module into itself form a subspace of S; it contains a generic point iff it is S)
+        if ((int64_t)G * w > ycap || w >= d) G = 1;
         const int m = G * w;
         // candidates: Y[:, g*w + (0:w)] = A_g W for fresh generic elements A_g
         HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * round_up(m, 128) * 8, s));

@@ -101,6 +101,34 @@ void launch_copy_col(hipStream_t s, int64_t n, const double* src, double* dst) {
     copy_col_kernel<<<grid_for(n, 256), 256, 0, s>>>(n, src, dst);
 }
 
+// many column copies in one launch: the (source, destination) column pairs travel by value in
+// the kernel arguments, so no index upload and no per-column launch
+struct ColPairs {
+    int32_t src[128];
+    int32_t dst[128];
+};
+__global__ void copy_cols_kernel(int64_t n, ColPairs cp, const double* __restrict__ src, int64_t lds_,
+                                 double* __restrict__ dst, int64_t ldd) {
+    const int k = blockIdx.y;
+    const double* a = src + (int64_t)cp.src[k] * lds_;
+    double* b = dst + (int64_t)cp.dst[k] * ldd;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) b[i] = a[i];
+}
+void launch_copy_cols(hipStream_t s, int64_t n, int64_t count, const int32_t* src_cols, const int32_t* dst_cols,
+                      const double* src, int64_t ld_src, double* dst, int64_t ld_dst) {
+    for (int64_t k0 = 0; k0 < count; k0 += 128) {
+        ColPairs cp;
+        const int m = (int)((count - k0 < 128) ? (count - k0) : 128);
+        for (int k = 0; k < m; ++k) {
+            cp.src[k] = src_cols[k0 + k];
+            cp.dst[k] = dst_cols[k0 + k];
+        }
+        dim3 g((unsigned)grid_for(n, 256), (unsigned)m);
+        copy_cols_kernel<<<g, 256, 0, s>>>(n, cp, src, ld_src, dst, ld_dst);
+    }
+}
+
 __global__ void clamptol_kernel(int64_t len, double* __restrict__ a, double atol) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {

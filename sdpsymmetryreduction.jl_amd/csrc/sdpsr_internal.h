@@ -33,6 +33,8 @@ struct sdpsr_ctx {
     std::map<std::string, DevBuf> bufs;
     void* pinned = nullptr;  // small pinned host scratch for scalar read-backs
     size_t pinned_bytes = 0;
+    void* h2d_ring = nullptr;  // pinned ring for small stream-ordered uploads (no sync per upload)
+    int h2d_ring_next = 0;
     void* rocblas = nullptr;  // rocblas_handle, created lazily
     // --- block-diagonalisation state kept between phase 1 and phase 2 ---
     int64_t bd_n = 0, bd_d = 0;
@@ -170,6 +172,8 @@ void launch_gemv_n_scaled(hipStream_t s, int64_t n, int64_t ld, const double* Q,
                           int64_t m, const double* w, const double* inv_norm, double* dst);
 // copy column / clamp
 void launch_copy_col(hipStream_t s, int64_t n, const double* src, double* dst);
+void launch_copy_cols(hipStream_t s, int64_t n, int64_t count, const int32_t* src_cols, const int32_t* dst_cols,
+                      const double* src, int64_t ld_src, double* dst, int64_t ld_dst);
 void launch_clamptol(hipStream_t s, int64_t len, double* a, double atol);
 // norm2 of a vector -> out[0] = 1/||v||
 void launch_inv_norm(hipStream_t s, int64_t m, const double* v, double* out);
