@@ -246,7 +246,7 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
         ws.tab_min = (uint32_t*)ctx_buf(c, "ref_tab_min", cap * 4);
         ws.tab_lab = (uint32_t*)ctx_buf(c, "ref_tab_lab", cap * 4);
         ws.blk_cnt = (uint32_t*)ctx_buf(c, "ref_blk_cnt", (nblk + 1) * 4);
-        ws.counters = (uint32_t*)ctx_buf(c, "ref_counters", 64);
+        ws.counters = (uint32_t*)ctx_buf(c, "ref_counters", refine_counters_bytes());
         if (!ws.tab_sig || !ws.tab_min || !ws.tab_lab || !ws.blk_cnt || !ws.counters)
             return SDPSR_OUT_OF_MEMORY;
         ws.log2cap = log2cap;

@@ -417,8 +417,14 @@ constexpr int REFINE_BLOCK = REFINE_THREADS * REFINE_PER_THREAD;  // 1024 entrie
 constexpr int LDS_SLOTS = 2048;
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 constexpr int MAX_PROBES = 4096;
+// Few-classes fast path: the first SMALL_K distinct signatures also append their global slot to
+// a list (counters[LIST_OFF + i]); when the whole partition has <= SMALL_K classes one workgroup
+// ranks those slots by first index and the three entry-level ranking passes exit at once.
+constexpr uint32_t SMALL_K = 1024;
+constexpr int LIST_OFF = 16;
 
 size_t refine_block_entries() { return REFINE_BLOCK; }
+size_t refine_counters_bytes() { return (size_t)(LIST_OFF + SMALL_K) * sizeof(uint32_t); }
 
 __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned long long* tab,
                                                           uint32_t mask, uint32_t* counters) {
@@ -430,6 +436,7 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned 
             unsigned long long old = atomicCAS(&tab[idx], 0ull, (unsigned long long)sg);
             if (old == 0ull) {
                 uint32_t cnt = atomicAdd(&counters[0], 1u);
+                if (cnt < SMALL_K) counters[LIST_OFF + cnt] = idx;
                 if (cnt + 1 > (mask >> 1) + (mask >> 2)) counters[1] = 1u;  // > 75% full
                 return idx;
             }
@@ -491,7 +498,10 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
                     ++probes;
                 }
                 if (placed) {
-                    atomicMin(&l_min[idx], (uint32_t)e);
+                    // l_min only decreases: a plain read that is already <= e makes the atomic a
+                    // no-op (true for every entry after the first of its class in this thread's
+                    // increasing index order, i.e. almost always when classes are few)
+                    if (l_min[idx] > (uint32_t)e) atomicMin(&l_min[idx], (uint32_t)e);
                     myslot[q] = (int)idx;
                 } else {
                     const uint32_t g = global_find_or_insert(sg, tab_sig, mask, counters);
@@ -555,8 +565,10 @@ __device__ __forceinline__ int first_flags(int64_t len, int64_t base,
 
 __global__ void __launch_bounds__(REFINE_THREADS)
 refine_count_kernel(int64_t len, const uint32_t* __restrict__ slot,
-                    const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ blk_cnt) {
+                    const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ blk_cnt,
+                    const uint32_t* __restrict__ counters) {
     __shared__ int sh[REFINE_THREADS / 64];
+    if (counters[0] <= SMALL_K) return;  // ranked by refine_small_rank_kernel
     const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         int flags[REFINE_PER_THREAD];
@@ -580,6 +592,7 @@ __global__ void __launch_bounds__(1024)
 refine_scan_kernel(int64_t nblk, uint32_t* __restrict__ blk_cnt, uint32_t* counters) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
+    if (counters[0] <= SMALL_K) return;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -608,8 +621,9 @@ refine_scan_kernel(int64_t nblk, uint32_t* __restrict__ blk_cnt, uint32_t* count
 __global__ void __launch_bounds__(REFINE_THREADS)
 refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
                    const uint32_t* __restrict__ tab_min, const uint32_t* __restrict__ blk_off,
-                   uint32_t* __restrict__ tab_lab) {
+                   uint32_t* __restrict__ tab_lab, const uint32_t* __restrict__ counters) {
     __shared__ int wsum[REFINE_THREADS / 64];
+    if (counters[0] <= SMALL_K) return;
     const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -635,6 +649,41 @@ refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
     }
 }
 
+// <= SMALL_K classes: label of a class = 1 + number of classes with a smaller first index
+__global__ void __launch_bounds__(1024)
+refine_small_rank_kernel(const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ tab_lab,
+                         uint32_t* __restrict__ counters) {
+    __shared__ uint32_t s_min[SMALL_K];
+    const uint32_t K = counters[0];
+    if (K > SMALL_K) return;
+    const uint32_t i = threadIdx.x;
+    uint32_t slot = 0, mine = 0;
+    if (i < K) {
+        slot = counters[LIST_OFF + i];
+        mine = tab_min[slot];
+        s_min[i] = mine;
+    }
+    __syncthreads();
+    if (i < K) {
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < K; ++j) rank += (s_min[j] < mine);
+        tab_lab[slot] = rank + 1;
+    }
+    if (i == 0) counters[2] = K;
+}
+
+// tab_sig = 0, tab_min = 0xFFFFFFFF, counters[0..16) = 0 in one launch
+__global__ void refine_clear_kernel(int64_t cap, unsigned long long* __restrict__ tab_sig,
+                                    uint32_t* __restrict__ tab_min, uint32_t* __restrict__ counters) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < cap; i += stride) {
+        tab_sig[i] = 0ull;
+        tab_min[i] = 0xFFFFFFFFu;
+    }
+    if (t0 < LIST_OFF) counters[t0] = 0u;
+}
+
 __global__ void refine_label_kernel(int64_t len, uint32_t* __restrict__ slot_inout,
                                     const uint32_t* __restrict__ tab_lab) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -647,9 +696,8 @@ __global__ void refine_label_kernel(int64_t len, uint32_t* __restrict__ slot_ino
 void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out,
                    const RefineWs& ws) {
     const size_t cap = (size_t)1 << ws.log2cap;
-    hipMemsetAsync(ws.tab_sig, 0, cap * sizeof(uint64_t), s);
-    hipMemsetAsync(ws.tab_min, 0xFF, cap * sizeof(uint32_t), s);
-    hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint32_t), s);
+    refine_clear_kernel<<<grid_for((int64_t)cap, 256), 256, 0, s>>>((int64_t)cap, (unsigned long long*)ws.tab_sig,
+                                                                   ws.tab_min, ws.counters);
     const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
     const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
     const int g = (int)(nchunk < 256 * 5 ? nchunk : 256 * 5);
@@ -657,10 +705,11 @@ void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* la
                                                       (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                       (uint32_t)(cap - 1), ws.counters);
     const int g2 = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
-    refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt);
+    refine_small_rank_kernel<<<1, 1024, 0, s>>>(ws.tab_min, ws.tab_lab, ws.counters);
+    refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt, ws.counters);
     refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
     refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt,
-                                                     ws.tab_lab);
+                                                     ws.tab_lab, ws.counters);
     refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, labels_out, ws.tab_lab);
 }
 
