@@ -481,7 +481,7 @@ int sdpsr_project_out(sdpsr_ctx* c, int64_t len, double* x, const double* U, int
     if (st) return st;
     double* dX = (mem == SDPSR_MEM_DEVICE) ? x : (double*)in_dev(c, "prim_in_a", (const double*)x, len, mem, &st);
     const double* dU = in_dev(c, "prim_in_b", U, (size_t)len * std::max<int64_t>(r, 1), mem, &st);
-    const int nblk = 512;
+    const int nblk = 2048;
     double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * nblk * 8);
     double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
     if (st || !partial || !coef) return st ? st : SDPSR_OUT_OF_MEMORY;
@@ -578,7 +578,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     const double* dU = in_dev(c, "adm_u", U, (size_t)len * std::max<int64_t>(r, 1), mem, &st);
     uint32_t* L = out_dev(c, "adm_labels", P_out, len, mem, &st);
     uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
-    const int nblk = 512;
+    const int nblk = 2048;
     double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * nblk * 8);
     double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
     if (st || !sig || !partial || !coef) return st ? st : SDPSR_OUT_OF_MEMORY;
@@ -782,7 +782,7 @@ int sdpsr_admissible_subspace_dense(sdpsr_ctx* c, int64_t n, int64_t m, const do
     if (st) return st;
     hipStream_t s = c->stream;
     const int64_t mm = std::max<int64_t>(m, 1);
-    const int nblk = 512;
+    const int nblk = 2048;
     double* dA = (double*)ctx_buf(c, "set_a", (size_t)len * mm * 8);   // m x len as given
     double* R = (double*)ctx_buf(c, "set_r", (size_t)len * mm * 8);    // residual rows, len x m
     double* U = (double*)ctx_buf(c, "adm_u", (size_t)len * mm * 8);    // basis, len x r
@@ -2172,14 +2172,14 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
         uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)len * 4);
         double* U = (double*)ctx_buf(c, "prof_u", (size_t)len * std::max<int64_t>(r, 1) * 8);
-        double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * 512 * 8);
+        double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * 2048 * 8);
         double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
         if (!sig || !Lb || !U || !partial || !coef) return SDPSR_OUT_OF_MEMORY;
         HIP_TRY(c, hipMemsetAsync(Lb, 0, (size_t)len * 4, s));
         launch_fill_test_sig(s, len / 2, 1000, (uint64_t*)Lb);
         HIP_TRY(c, hipMemsetAsync(U, 0, (size_t)len * std::max<int64_t>(r, 1) * 8, s));
         auto run = [&]() {
-            launch_proj_coef(s, len, r, U, Lb, 777, nullptr, partial, 512, coef);
+            launch_proj_coef(s, len, r, U, Lb, 777, nullptr, partial, 2048, coef);
             launch_proj_apply(s, len, r, U, Lb, 777, nullptr, coef, 1.5e-8, 1e7, 1, nullptr, sig);
         };
         run();

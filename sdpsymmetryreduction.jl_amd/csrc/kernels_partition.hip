@@ -228,18 +228,26 @@ __global__ void proj_coef_kernel(int64_t len, const double* __restrict__ U,
     __shared__ double sh[8];
     const int k = blockIdx.y;
     const double* Uk = U + (int64_t)k * len;
-    double acc = 0;
+    // four independent strided streams per thread: the loads of one round are all in flight
+    // before the first FMA (the kernel is bound by memory latency, not by the hash)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
-        double x;
-        if (xin) {
-            x = xin[e];
-        } else {
-            uint32_t l = L[e];
-            x = l ? sdpsr_class_uniform(key, l) : 0.0;
-        }
-        acc = fma(Uk[e], x, acc);
+    auto value = [&](int64_t e) -> double {
+        if (xin) return xin[e];
+        const uint32_t l = L[e];
+        return l ? sdpsr_class_uniform(key, l) : 0.0;
+    };
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; e + 3 * stride < len; e += 4 * stride) {
+        const double u0 = Uk[e], u1 = Uk[e + stride], u2 = Uk[e + 2 * stride], u3 = Uk[e + 3 * stride];
+        const double x0 = value(e), x1 = value(e + stride), x2 = value(e + 2 * stride), x3 = value(e + 3 * stride);
+        a0 = fma(u0, x0, a0);
+        a1 = fma(u1, x1, a1);
+        a2 = fma(u2, x2, a2);
+        a3 = fma(u3, x3, a3);
     }
+    for (; e < len; e += stride) a0 = fma(Uk[e], value(e), a0);
+    const double acc = (a0 + a1) + (a2 + a3);
     double r = block_reduce_sum(acc, sh);
     if (threadIdx.x == 0) partial[(int64_t)k * gridDim.x + blockIdx.x] = r;
 }
@@ -268,6 +276,7 @@ __global__ void proj_apply_kernel(int64_t len, int r, const double* __restrict__
                                   double atol, double scale, int do_round,
                                   double* __restrict__ yout, uint64_t* __restrict__ sig) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+#pragma unroll 4
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
         uint32_t l = L ? L[e] : 0u;
         double x;
@@ -370,32 +379,43 @@ void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_
     sig_u32_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, k, sig);
 }
 
+// grid (row chunks, columns): no 64-bit division per entry
 template <typename CT>
 __global__ void sig_channels_kernel(int64_t n, int64_t ld, int T, const uint32_t* __restrict__ L,
                                     const CT* __restrict__ C, uint64_t* __restrict__ sig) {
-    const int64_t len = n * n;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
-        const int64_t j = e / n, i = e - j * n;
-        uint32_t l = L[e];
-        uint64_t h = sdpsr_sig_start(l);
-        bool allz = true;
-        for (int t = 0; t < T; ++t) {
-            CT c = C[(int64_t)t * ld * ld + i + j * ld];
-            int32_t ci = (int32_t)c;  // exact: f32 channels hold integers < 2^24
-            allz = allz && (ci == 0);
-            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)ci);
+    const int64_t istride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+        const uint32_t* Lj = L + j * n;
+        uint64_t* sj = sig + j * n;
+        const CT* Cj = C + j * ld;
+#pragma unroll 2
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += istride) {
+            const uint32_t l = Lj[i];
+            uint64_t h = sdpsr_sig_start(l);
+            bool allz = true;
+            for (int t = 0; t < T; t += 2) {  // two 32-bit channel values per 64-bit mixing step
+                const int32_t c0 = (int32_t)Cj[(int64_t)t * ld * ld + i];  // exact: f32 channels hold integers < 2^24
+                const int32_t c1 = (t + 1 < T) ? (int32_t)Cj[(int64_t)(t + 1) * ld * ld + i] : 0;
+                allz = allz && (c0 == 0) && (c1 == 0);
+                h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c0 | ((uint64_t)(uint32_t)c1 << 32));
+            }
+            sj[i] = finish_sig(l, allz, h);
         }
-        sig[e] = finish_sig(l, allz, h);
     }
+}
+static inline dim3 column_grid(int64_t n) {
+    int64_t gx = (n + 1023) / 1024;  // ~4 rows per thread
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    return dim3((unsigned)gx, (unsigned)(n < 65535 ? n : 65535));
 }
 void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
                     const int32_t* C, uint64_t* sig) {
-    sig_channels_kernel<int32_t><<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, T, L, C, sig);
+    sig_channels_kernel<int32_t><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig);
 }
 void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
                     const float* C, uint64_t* sig) {
-    sig_channels_kernel<float><<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, T, L, C, sig);
+    sig_channels_kernel<float><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig);
 }
 
 // ---------------------------------------------------------------------------
@@ -716,20 +736,29 @@ void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* la
 // ---------------------------------------------------------------------------
 // symmetric label check
 // ---------------------------------------------------------------------------
-__global__ void check_symmetric_kernel(int64_t n, const uint32_t* __restrict__ L,
-                                       uint32_t* flag) {
-    const int64_t len = n * n;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// 64 x 64 tiles through LDS: both the tile and its mirror image are read along columns
+__global__ void __launch_bounds__(256)
+check_symmetric_kernel(int64_t n, const uint32_t* __restrict__ L, uint32_t* flag) {
+    __shared__ uint32_t tile[64][65];
+    const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+    if (i0 < j0) return;  // lower triangle of tiles only
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    for (int c = ty; c < 64; c += 4) {  // mirror tile: rows j0.., columns i0..
+        const int64_t r = j0 + tx, cc = i0 + c;
+        tile[c][tx] = (r < n && cc < n) ? L[r + cc * n] : 0u;
+    }
+    __syncthreads();
     bool bad = false;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
-        const int64_t j = e / n, i = e - j * n;
-        if (i > j && L[e] != L[j + i * n]) bad = true;
+    for (int c = ty; c < 64; c += 4) {  // tile: rows i0.., columns j0..
+        const int64_t r = i0 + tx, cc = j0 + c;
+        if (r < n && cc < n && L[r + cc * n] != tile[tx][c]) bad = true;  // L[r,cc] vs L[cc,r]
     }
     if (bad) flag[0] = 1u;
 }
 void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag) {
     hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
-    check_symmetric_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, L, flag);
+    const unsigned t = (unsigned)((n + 63) / 64);
+    check_symmetric_kernel<<<dim3(t, t), 256, 0, s>>>(n, L, flag);
 }
 
 // Lt[k + i*n] = L[i + k*n]: 64 x 64 label tiles through LDS (both sides coalesced)

@@ -44,9 +44,12 @@ SDPSR_HD uint64_t sdpsr_sig_mix(uint64_t h, uint64_t v) {
     return sdpsr_fmix64(h + 0x9E3779B97F4A7C15ULL + v * 0xD6E8FEB86659FD93ULL);
 }
 
-// start of a signature chain from the old label
+// start of a signature chain from the old label.  Not mixed by itself: every chain goes through
+// at least one sdpsr_sig_mix, whose finaliser does the mixing (one 64 x 32 multiply here instead
+// of two 64 x 64 ones; 32/64-bit integer multiplies are quarter rate on CDNA and the signature
+// kernels are bound by them, not by HBM).
 SDPSR_HD uint64_t sdpsr_sig_start(uint32_t label) {
-    return sdpsr_fmix64(0x51ED270B0F3A4C27ULL ^ (uint64_t)label);
+    return 0x51ED270B0F3A4C27ULL + (uint64_t)label * 0xC2B2AE3D27D4EB4FULL;
 }
 
 // round-to-nearest restatement of _clamp_round!/unsafe_round (src/utils.jl:34-53):
