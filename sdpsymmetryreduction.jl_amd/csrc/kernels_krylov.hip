@@ -4,6 +4,7 @@
 // exactly k steps and its Ritz pairs are the k eigenvalues and one generic unit vector of every
 // eigenspace -- everything src/eigen_decomposition.jl:236-348 uses of eigen(A).  All passes
 // are HBM-bound reads of the n x n element (sym_gemv) or small tall-skinny updates.
+#include <algorithm>
 #include "sdpsr_internal.h"
 
 namespace sdpsr {
@@ -281,80 +282,74 @@ void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, con
 // ---------------------------------------------------------------------------
 // Fused randomize! + product:  Y = A W  with  A[r,c] = value(L[r,c])  never materialised
 // (src/abstract_part.jl:107-110 fused into the products of the module-compression driver).
-// Reads the 4-byte labels once (coalesced along r), the per-class values come from a
-// d+1 entry table built in LDS from the counter-based generator, W is staged through LDS in
-// 128-row chunks and broadcast to the lanes.  Workgroup = 64 rows x (4 waves splitting the
-// columns); grid.y splits the column range further, partial sums are reduced in fixed order.
+// Reads the 4-byte labels coalesced along r, the per-class values come from a d+1 entry table
+// built in LDS from the counter-based generator.  Workgroup = 64 rows; grid.y splits the column
+// range, partial sums are reduced in fixed order.
 // ---------------------------------------------------------------------------
+// W is read through the SCALAR data path.  (A first version staged W through LDS and broadcast it
+// to the lanes: one 1 KiB LDS read per two FMAs per wave, bound by the LDS pipe at 128 B/clk/CU
+// instead of the FP64 rate: 102 us at N = 4096, w = 34 against 57 us for this one.)  The four waves of a workgroup split the w output columns (JW = WMAX/4 each)
+// and every wave walks ALL matrix columns c of its 64 rows: the column index is wave-uniform, so
+// W'[wave][c][0..JW) (a transposed, zero-padded copy) arrives by s_load in SGPRs and is fed to
+// the FMAs as a scalar operand; JW accumulators per lane keep the occupancy high, which hides the
+// scalar-load latency.  Labels are read once per wave (4x through L1, coalesced).
+__global__ void transpose_pad_w_kernel(int n, int npad, int w, int jw, const double* __restrict__ W, int64_t ldw,
+                                       double* __restrict__ Wt) {
+    const int64_t per_wave = (int64_t)npad * jw;
+    const int64_t total = 4 * per_wave;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+        const int wv = (int)(e / per_wave);
+        const int64_t rem = e - (int64_t)wv * per_wave;
+        const int c = (int)(rem / jw), j = (int)(rem - (int64_t)c * jw);
+        const int jj = wv * jw + j;
+        Wt[e] = (jj < w && c < n) ? W[c + (int64_t)jj * ldw] : 0.0;
+    }
+}
+
 template <int WMAX>
 __global__ void __launch_bounds__(256)
-label_spmm_kernel(int n, const uint32_t* __restrict__ L, uint64_t key, int d, const double* __restrict__ W,
-                  int64_t ldw, int w, int cols_per_block, double* __restrict__ P) {
+label_spmm_sload_kernel(int n, int npad, const uint32_t* __restrict__ L, uint64_t key, int d,
+                        const double* __restrict__ Wt, int w, int cols_per_block, double* __restrict__ P) {
+    constexpr int JW = WMAX / 4;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sW = smem;                 // [128][WMAX]
-    double* sV = smem + 128 * WMAX;    // [d + 1] class values
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* sV = smem;  // [d + 1] class values
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = blockIdx.x * 64 + lane;
     const int c_begin = blockIdx.y * cols_per_block;
     int c_end = c_begin + cols_per_block;
     if (c_end > n) c_end = n;
     for (int i = tid; i <= d; i += 256) sV[i] = i ? sdpsr_class_uniform(key, (uint32_t)i) : 0.0;
-    double acc[WMAX];
+    __syncthreads();
+    double acc[JW];
 #pragma unroll
-    for (int j = 0; j < WMAX; ++j) acc[j] = 0.0;
+    for (int j = 0; j < JW; ++j) acc[j] = 0.0;
+    const double* __restrict__ Ww = Wt + (int64_t)wave * npad * JW;
+    const bool row_ok = r < n;
 #pragma unroll 1
-    for (int c0 = c_begin; c0 < c_end; c0 += 128) {
-        __syncthreads();
-        for (int idx = tid; idx < 128 * WMAX; idx += 256) {  // zero-filled beyond w: no predicates below
-            const int j = idx >> 7, cl = idx & 127;
-            const int c = c0 + cl;
-            sW[cl * WMAX + j] = (j < w && c < c_end) ? W[c + (int64_t)j * ldw] : 0.0;
+    for (int cb = c_begin; cb < c_end; cb += 8) {
+        uint32_t lab[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = cb + u;
+            lab[u] = (row_ok && c < c_end) ? L[r + (int64_t)c * n] : 0u;  // label 0 -> value 0
         }
-        __syncthreads();
-        // wave `wave` owns local columns wave*32 .. wave*32+31; labels are fetched 8 columns ahead
-        // so that eight independent global loads are in flight per lane
-#pragma unroll 1
-        for (int g8 = 0; g8 < 32; g8 += 8) {
-            const int clb = wave * 32 + g8;
-            uint32_t lab[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + clb + u;
-                lab[u] = (r < n && c < c_end) ? L[r + (int64_t)c * n] : 0u;
-            }
+        for (int u = 0; u < 8; ++u) {
+            const double v = sV[lab[u]];
+            const double* __restrict__ wr = Ww + (int64_t)(cb + u) * JW;  // uniform address (rows >= n are zero)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const double v = sV[lab[u]];
-                const double2* wr = reinterpret_cast<const double2*>(sW + (clb + u) * WMAX);
-#pragma unroll
-                for (int j2 = 0; j2 < WMAX / 2; ++j2) {
-                    const double2 ww = wr[j2];
-                    acc[2 * j2] = fma(v, ww.x, acc[2 * j2]);
-                    acc[2 * j2 + 1] = fma(v, ww.y, acc[2 * j2 + 1]);
-                }
-            }
+            for (int j = 0; j < JW; ++j) acc[j] = fma(v, wr[j], acc[j]);
         }
     }
-    // sum the four waves (they own disjoint column subsets) through LDS, wave 0 writes
-    for (int wv = 1; wv < 4; ++wv) {
-        __syncthreads();
-        if (wave == wv) {
-#pragma unroll
-            for (int j = 0; j < WMAX; ++j)
-                if (j < w) sW[lane * WMAX + j] = acc[j];
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int j = 0; j < WMAX; ++j)
-                if (j < w) acc[j] += sW[lane * WMAX + j];
-        }
-    }
-    if (wave == 0 && r < n) {
+    if (row_ok) {
         double* p = P + (int64_t)blockIdx.y * n * w;
 #pragma unroll
-        for (int j = 0; j < WMAX; ++j)
-            if (j < w) p[r + (int64_t)j * n] = acc[j];
+        for (int j = 0; j < JW; ++j) {
+            const int jj = wave * JW + j;
+            if (jj < w) p[r + (int64_t)jj * n] = acc[j];
+        }
     }
 }
 
@@ -372,10 +367,11 @@ __global__ void label_spmm_reduce_kernel(int n, int w, int Z, const double* __re
 }
 
 size_t label_spmm_partial_doubles(int64_t n, int w) {
-    int zg = (int)(768 / ((n + 63) / 64));
+    int zg = (int)(2048 / ((n + 63) / 64));
     if (zg < 1) zg = 1;
     if (zg > 32) zg = 32;
-    return (size_t)zg * n * w;
+    (void)w;
+    return (size_t)zg * n * 64 + (size_t)(n + 8) * 64;  // partial sums + transposed copy of W
 }
 
 // returns false when the shape is not supported (w > 64 or the class table does not fit in LDS)
@@ -383,23 +379,28 @@ bool launch_label_spmm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key
                        int64_t ldw, int w, double* partials, double* Y, int64_t ldy) {
     if (w < 1 || w > 64 || d > 4000) return false;
     const int rb = (int)((n + 63) / 64);
-    int zg = 768 / rb;
+    int zg = 2048 / rb;
     if (zg < 1) zg = 1;
     if (zg > 32) zg = 32;
+    const int zg_cap = zg;
     int cpb = (int)((n + zg - 1) / zg);
     cpb = (cpb + 127) / 128 * 128;
     zg = (int)((n + cpb - 1) / cpb);
     dim3 g((unsigned)rb, (unsigned)zg);
+    // transposed zero-padded copy of W behind the partial sums (label_spmm_partial_doubles leaves room)
+    double* Wt = partials + (size_t)zg_cap * n * 64;
+    const int npad = (int)n + 8;
     auto go = [&](auto kern, int wmax) {
-        const size_t lds = ((size_t)128 * wmax + (size_t)d + 2) * sizeof(double);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        kern<<<g, 256, lds, s>>>((int)n, L, key, (int)d, W, ldw, w, cpb, partials);
+        transpose_pad_w_kernel<<<(unsigned)std::min<int64_t>(((int64_t)npad * wmax + 255) / 256, 2048), 256, 0, s>>>(
+            (int)n, npad, w, wmax / 4, W, ldw, Wt);
+        const size_t lds = ((size_t)d + 2) * sizeof(double);
+        kern<<<g, 256, lds, s>>>((int)n, npad, L, key, (int)d, Wt, w, cpb, partials);
     };
-    if (w <= 8) go(label_spmm_kernel<8>, 8);
-    else if (w <= 16) go(label_spmm_kernel<16>, 16);
-    else if (w <= 32) go(label_spmm_kernel<32>, 32);
-    else if (w <= 48) go(label_spmm_kernel<48>, 48);
-    else go(label_spmm_kernel<64>, 64);
+    if (w <= 8) go(label_spmm_sload_kernel<8>, 8);
+    else if (w <= 16) go(label_spmm_sload_kernel<16>, 16);
+    else if (w <= 32) go(label_spmm_sload_kernel<32>, 32);
+    else if (w <= 48) go(label_spmm_sload_kernel<48>, 48);
+    else go(label_spmm_sload_kernel<64>, 64);
     int64_t gr = ((int64_t)n * w + 255) / 256;
     if (gr > 2048) gr = 2048;
     label_spmm_reduce_kernel<<<(unsigned)gr, 256, 0, s>>>((int)n, w, zg, partials, Y, ldy);
