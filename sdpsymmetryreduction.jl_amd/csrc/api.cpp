@@ -1989,28 +1989,27 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     launch_transpose_to_rowmajor(s, n, S1, Qhat, Qrm);
     const double atol = 1e-12 * (double)n;  // basis_image default atol (src/diagonalize.jl:67)
     if (basis_image_two_stage_fits(n, d, S1)) {
-        // two-stage form (row sums per class in LDS, then s_k x s_k dots): no sort needed
-        const int nb = (int)c->bd_sizes.size();
-        std::vector<int32_t> hcol(nb), hsz(nb);
-        std::vector<int64_t> hoff(nb);
-        int64_t colbase = 0, off = 0;
-        for (int k2 = 0; k2 < nb; ++k2) {
-            hcol[k2] = (int32_t)colbase;
-            hsz[k2] = c->bd_sizes[k2];
-            hoff[k2] = off;
-            colbase += hsz[k2];
-            off += (int64_t)hsz[k2] * hsz[k2];
+        // two-stage form (class sums per row, then the s_k x s_k dots): descriptor = the two
+        // columns of Q_hat every output multiplies, blocks side by side, column-major inside
+        std::vector<int32_t> hdesc(2 * (size_t)S);
+        {
+            int64_t o = 0, colbase = 0;
+            for (int32_t sz : c->bd_sizes) {
+                for (int b2 = 0; b2 < sz; ++b2)
+                    for (int a2 = 0; a2 < sz; ++a2) {
+                        hdesc[o] = (int32_t)(colbase + a2);
+                        hdesc[S + o] = (int32_t)(colbase + b2);
+                        ++o;
+                    }
+                colbase += sz;
+            }
         }
-        int32_t* d_col = (int32_t*)ctx_buf(c, "bi_col", (size_t)nb * 4);
-        int32_t* d_sz = (int32_t*)ctx_buf(c, "bi_sz", (size_t)nb * 4);
-        int64_t* d_off = (int64_t*)ctx_buf(c, "bi_off", (size_t)nb * 8);
+        int32_t* d_desc = (int32_t*)ctx_buf(c, "bi_desc", (size_t)2 * S * 4);
         double* Tb = (double*)ctx_buf(c, "bi_T", (size_t)d * n * S1 * 8);
-        if (!d_col || !d_sz || !d_off || !Tb) return SDPSR_OUT_OF_MEMORY;
-        st = h2d_sync(c, d_col, hcol.data(), (size_t)nb * 4);
-        if (!st) st = h2d_sync(c, d_sz, hsz.data(), (size_t)nb * 4);
-        if (!st) st = h2d_sync(c, d_off, hoff.data(), (size_t)nb * 8);
+        if (!d_desc || !Tb) return SDPSR_OUT_OF_MEMORY;
+        st = h2d_sync(c, d_desc, hdesc.data(), (size_t)2 * S * 4);
         if (st) return st;
-        launch_basis_image_two_stage(s, n, d, S1, S, nb, L, Qrm, Tb, d_col, d_sz, d_off, atol, out);
+        launch_basis_image_two_stage(s, n, d, S1, S, L, Qrm, Tb, d_desc, d_desc + S, atol, out);
     } else {
     // _constraints(P): entries grouped by class (src/diagonalize.jl:42-50)
     uint32_t* ent = nullptr;

@@ -278,17 +278,26 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
     // loop over the distinct labels); the lowest peer is the leader that updates the counters.
     const int nbits = 32 - __clz(d);  // labels 0..d
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int c0 = 0; c0 < n; c0 += 64) {  // histogram, shifted by one
-        const int c = c0 + lane;
-        const bool valid = c < n;
-        const uint32_t l = valid ? col[c] : 0u;
-        unsigned long long m = __ballot(valid);
-        for (int b = 0; b < nbits; ++b) {
-            const bool bit = (l >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+    // (four chunks per round: their label loads are issued together, the ballots follow)
+    for (int c0 = 0; c0 < n; c0 += 256) {  // histogram, shifted by one
+        uint32_t lq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q * 64 + lane;
+            lq[q] = (c < n) ? col[c] : 0u;
         }
-        if (valid && (m & lt_mask) == 0ull) s_off[l + 1] += __popcll(m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool valid = (c0 + q * 64 + lane) < n;
+            const uint32_t l = lq[q];
+            unsigned long long m = __ballot(valid);
+            for (int b = 0; b < nbits; ++b) {
+                const bool bit = (l >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            if (valid && (m & lt_mask) == 0ull) s_off[l + 1] += __popcll(m);
+        }
     }
     __syncthreads();
     if (lane == 0) {  // exclusive scan (d + 1 classes incl. the zero class)
@@ -303,21 +312,30 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
     __syncthreads();
     for (int t = lane; t < d + 2; t += 64) s_off[t] = s_start[t];
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 64) {  // stable scatter of the entry indices
-        const int c = c0 + lane;
-        const bool valid = c < n;
-        const uint32_t l = valid ? col[c] : 0u;
-        unsigned long long m = __ballot(valid);
-        for (int b = 0; b < nbits; ++b) {
-            const bool bit = (l >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+    for (int c0 = 0; c0 < n; c0 += 256) {  // stable scatter of the entry indices
+        uint32_t lq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q * 64 + lane;
+            lq[q] = (c < n) ? col[c] : 0u;
         }
-        if (valid) {
-            const int base = s_off[l];  // read by every peer before the leader bumps it (in-order LDS)
-            const int rank = __popcll(m & lt_mask);
-            s_pos[base + rank] = (unsigned short)c;
-            if (rank == 0) s_off[l] = base + __popcll(m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q * 64 + lane;
+            const bool valid = c < n;
+            const uint32_t l = lq[q];
+            unsigned long long m = __ballot(valid);
+            for (int b = 0; b < nbits; ++b) {
+                const bool bit = (l >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            if (valid) {
+                const int base = s_off[l];  // read by every peer before the leader bumps it (in-order LDS)
+                const int rank = __popcll(m & lt_mask);
+                s_pos[base + rank] = (unsigned short)c;
+                if (rank == 0) s_off[l] = base + __popcll(m);
+            }
         }
     }
     __syncthreads();
@@ -331,6 +349,7 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
     const int groups = 64 / sub;
     const int jl = lane & (sub - 1), g = lane / sub;
     const vec_t* __restrict__ Qv = reinterpret_cast<const vec_t*>(Qrm);
+    const uint32_t diag = lower ? col[r] : 0u;
     for (int j0 = 0; j0 < cols; j0 += sub) {
         const int j = j0 + jl;
         const bool act = j < cols;
@@ -362,50 +381,54 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
             for (int v = 0; v < VEC; ++v) {
                 double t = ((a[0][v] + a[1][v]) + (a[2][v] + a[3][v])) + ((a[4][v] + a[5][v]) + (a[6][v] + a[7][v]));
                 for (int off = sub; off < 64; off <<= 1) t += __shfl_xor(t, off, 64);
-                if (act && g == 0) T[((int64_t)(i - 1) * nn + r) * S1 + (int64_t)j * VEC + v] = t;
+                if (act && g == 0) {
+                    // the diagonal entry enters with weight 1/2: the caller forms U + U' (below)
+                    if (lower && diag == (uint32_t)i) t = fma(0.5, Qrm[(int64_t)r * S1 + (int64_t)j * VEC + v], t);
+                    T[((int64_t)(i - 1) * nn + r) * S1 + (int64_t)j * VEC + v] = t;
+                }
             }
         }
     }
 }
 
-// grid (d, nblocks): out[i][off_k + a + b*s] = sum_r Qrm[r][cb_k + a] * T[i][r][cb_k + b]
+// out[i][o] = sum_r Q[r][ca_o] T_i[r][cb_o] + Q[r][cb_o] T_i[r][ca_o]   (= U + U', see the rows kernel)
+// for the S = sum s_k^2 outputs o of every class i; (ca_o, cb_o) come from a descriptor table.
+// grid (d, ceil(S / 4)): a workgroup owns 4 outputs x 64 row groups, so 1 x 1 blocks (commutative
+// algebras) use the whole workgroup just like large blocks do.
 __global__ void __launch_bounds__(256)
 basis_image_blocks_kernel(int n, int S1, int64_t S, const double* __restrict__ Qrm, const double* __restrict__ T,
-                          const int32_t* __restrict__ blk_col, const int32_t* __restrict__ blk_size,
-                          const int64_t* __restrict__ blk_off, double atol, double* __restrict__ out,
-                          const uint32_t* __restrict__ L, int lower) {
+                          const int32_t* __restrict__ colA, const int32_t* __restrict__ colB, double atol,
+                          double* __restrict__ out) {
     __shared__ double red[256];
-    const int i = blockIdx.x, k = blockIdx.y;
-    const int s = blk_size[k], cb = blk_col[k];
-    const int ss = s * s;
+    const int i = blockIdx.x;
+    const int64_t o = (int64_t)blockIdx.y * 4 + (threadIdx.x & 3);
+    const int g = threadIdx.x >> 2;  // 64 row groups
     const double* Ti = T + (int64_t)i * n * S1;
-    // thread = (pair p of the s*s outputs handled in passes, row group g)
-    for (int p0 = 0; p0 < ss; p0 += 16) {
-        const int p = p0 + (threadIdx.x & 15);
-        const int g = threadIdx.x >> 4;  // 16 row groups
-        double acc = 0;
-        if (p < ss) {
-            const int a = p % s, b = p / s;
-            if (!lower) {
-                for (int r = g; r < n; r += 16) acc = fma(Qrm[(int64_t)r * S1 + cb + a], Ti[(int64_t)r * S1 + cb + b], acc);
-            } else {
-                // U[a,b] + U[b,a] + diagonal entries of the class
-                for (int r = g; r < n; r += 16) {
-                    const double qa = Qrm[(int64_t)r * S1 + cb + a], qb = Qrm[(int64_t)r * S1 + cb + b];
-                    acc = fma(qa, Ti[(int64_t)r * S1 + cb + b], acc);
-                    acc = fma(qb, Ti[(int64_t)r * S1 + cb + a], acc);
-                    if (L[(int64_t)r * n + r] == (uint32_t)(i + 1)) acc = fma(qa, qb, acc);
-                }
-            }
+    double a0 = 0, a1 = 0;
+    if (o < S) {
+        const int ca = colA[o], cb = colB[o];
+        int r = g;
+        for (; r + 64 < n; r += 128) {
+            const double qa0 = Qrm[(int64_t)r * S1 + ca], qb0 = Qrm[(int64_t)r * S1 + cb];
+            const double ta0 = Ti[(int64_t)r * S1 + ca], tb0 = Ti[(int64_t)r * S1 + cb];
+            const double qa1 = Qrm[(int64_t)(r + 64) * S1 + ca], qb1 = Qrm[(int64_t)(r + 64) * S1 + cb];
+            const double ta1 = Ti[(int64_t)(r + 64) * S1 + ca], tb1 = Ti[(int64_t)(r + 64) * S1 + cb];
+            a0 = fma(qa0, tb0, a0);
+            a0 = fma(qb0, ta0, a0);
+            a1 = fma(qa1, tb1, a1);
+            a1 = fma(qb1, ta1, a1);
         }
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (threadIdx.x < 16 && p < ss) {
-            double v = 0;
-            for (int gg = 0; gg < 16; ++gg) v += red[gg * 16 + threadIdx.x];
-            out[(int64_t)i * S + blk_off[k] + p] = (fabs(v) < atol) ? 0.0 : v;
+        for (; r < n; r += 64) {
+            a0 = fma(Qrm[(int64_t)r * S1 + ca], Ti[(int64_t)r * S1 + cb], a0);
+            a0 = fma(Qrm[(int64_t)r * S1 + cb], Ti[(int64_t)r * S1 + ca], a0);
         }
-        __syncthreads();
+    }
+    red[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < 4 && o < S) {
+        double v = 0;
+        for (int gg = 0; gg < 64; ++gg) v += red[gg * 4 + threadIdx.x];
+        out[(int64_t)i * S + o] = (fabs(v) < atol) ? 0.0 : v;
     }
 }
 
@@ -413,16 +436,76 @@ bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1) {
     return n <= 65535 && (2 * (d + 2) * 4 + n * 2) <= 60 * 1024 && d * n * S1 * 8 <= ((int64_t)4 << 30);
 }
 
+// Class sums of ONE vector, few classes: out[(i-1) n + r] = sum over c with L[c,r] == i of x[c].
+// x sits in LDS, every lane adds into its private (d+1)-entry table in LDS (no sort, no atomics),
+// then lane i adds the 64 tables of class i in lane order: fixed order, reproducible.
+// Workgroup = 4 waves = 4 rows at a time, sharing x.
+__global__ void __launch_bounds__(256)
+class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict__ L, const double* __restrict__ x,
+                          double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double cs_smem[];
+    double* sx = cs_smem;                                  // [n]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* acc = cs_smem + n + (size_t)wave * 64 * tstride;  // [64][tstride], tstride odd >= d + 1
+    double* mine = acc + (size_t)lane * tstride;
+    for (int c = threadIdx.x; c < n; c += 256) sx[c] = x[c];
+    __syncthreads();
+    const int rows_per_round = gridDim.x * 4;
+    for (int r0 = blockIdx.x * 4; r0 < n; r0 += rows_per_round) {
+        const int r = r0 + wave;
+        const bool row_ok = r < n;
+        for (int i = 0; i <= d; ++i) mine[i] = 0.0;
+        if (row_ok) {
+            const uint32_t* col = L + (int64_t)r * n;
+            for (int c0 = 0; c0 < n; c0 += 512) {
+                uint32_t lab[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u * 64 + lane;
+                    lab[u] = (c < n) ? col[c] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u * 64 + lane;
+                    if (c < n) mine[lab[u]] += sx[c];
+                }
+            }
+        }
+        __syncthreads();
+        if (row_ok)
+            for (int i = 1 + lane; i <= d; i += 64) {
+                double t = 0;
+                for (int l2 = 0; l2 < 64; ++l2) t += acc[(size_t)l2 * tstride + i];
+                out[(int64_t)(i - 1) * n + r] = t;
+            }
+        __syncthreads();
+    }
+}
+
 void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out) {
+    const int tstride = (int)((d + 1) | 1);
+    const size_t lds_small = ((size_t)n + (size_t)4 * 64 * tstride) * sizeof(double);
+    if (lds_small <= 150 * 1024) {
+        static bool attr_small = false;
+        if (!attr_small) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_small = true;
+        }
+        int g = (int)((n + 3) / 4);
+        if (g > 256) g = 256;  // one resident workgroup per CU, rows in rounds
+        class_sums_small_d_kernel<<<g, 256, lds_small, s>>>((int)n, (int)d, tstride, L, x, out);
+        return;
+    }
     const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     basis_image_rows_kernel<1><<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, 1, L, x, out, 0);
 }
 
-void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks,
-                                  const uint32_t* L, const double* Qrm, double* T, const int32_t* blk_col,
-                                  const int32_t* blk_size, const int64_t* blk_off, double atol, double* out) {
+void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S,
+                                  const uint32_t* L, const double* Qrm, double* T, const int32_t* colA,
+                                  const int32_t* colB, double atol, double* out) {
     const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
     static bool attr_set = false;
     if (!attr_set) {
@@ -436,8 +519,8 @@ void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S
         basis_image_rows_kernel<2><<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T, 1);
     else
         basis_image_rows_kernel<1><<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T, 1);
-    dim3 g((unsigned)d, (unsigned)nblocks);
-    basis_image_blocks_kernel<<<g, 256, 0, s>>>((int)n, (int)S1, S, Qrm, T, blk_col, blk_size, blk_off, atol, out, L, 1);
+    dim3 g((unsigned)d, (unsigned)((S + 3) / 4));
+    basis_image_blocks_kernel<<<g, 256, 0, s>>>((int)n, (int)S1, S, Qrm, T, colA, colB, atol, out);
 }
 
 // Qrm[r * S1 + k] = Qcm[r + k * n]

@@ -190,9 +190,9 @@ void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t
 bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1);
 // out[r + i*n] = sum over c with L[c + r*n] == i+1 of x[c]   (class sums of a vector, i < d)
 void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out);
-void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks,
-                                  const uint32_t* L, const double* Qrm, double* T, const int32_t* blk_col,
-                                  const int32_t* blk_size, const int64_t* blk_off, double atol, double* out);
+void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S,
+                                  const uint32_t* L, const double* Qrm, double* T, const int32_t* colA,
+                                  const int32_t* colB, double atol, double* out);
 void launch_transpose_to_rowmajor(hipStream_t s, int64_t n, int64_t S1, const double* Qcm,
                                   double* Qrm);
 // stable sort of entries by label (label 0 dropped): ent sorted, hist[d+1]
