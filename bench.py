@@ -200,12 +200,14 @@ def main():
     cpu = None
     if rank == 0 and not args.skip_roofline:
         flops = 2.0 * n ** 3
-        for name, kind, peak, unit in (("square_i8", 0, I8_MFMA_PEAK_TOPS, "TOP/s"), ("square_f32", 1, FP32_MFMA_PEAK_TF, "TFLOP/s"),
-                                       ("gemm_f64", 2, FP64_MFMA_PEAK_TF, "TFLOP/s")):
-            ms = prof(kind, n)
-            ach = flops / (ms * 1e-3) / 1e12
-            kernels[name] = {"ms": round(ms, 4), "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                             "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4)}
+        # the int8 square is launched exactly as the product path launches it: all 4 channels in
+        # one launch (so that the HIP-event duration agrees with rocprofv3's average for the kernel)
+        for name, kind, peak, unit, batch in (("square_i8", 0, I8_MFMA_PEAK_TOPS, "TOP/s", 4), ("square_f32", 1, FP32_MFMA_PEAK_TF, "TFLOP/s", 1),
+                                              ("gemm_f64", 2, FP64_MFMA_PEAK_TF, "TFLOP/s", 1)):
+            ms = prof(kind, n, aux=batch)
+            ach = batch * flops / (ms * 1e-3) / 1e12
+            kernels[name] = {"ms_per_launch": round(ms, 4), "channels_per_launch": batch, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                             "frac": round(ach / peak, 4), "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4)}
         ms = prof(3, n, aux=d, reps=5)  # refine: 16 B per entry algorithmic (8 value + 4 old + 4 new label)
         gbs = 16.0 * n * n / (ms * 1e-3) / 1e9
         kernels["refine"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
@@ -234,13 +236,25 @@ def main():
                       "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                       "algorithmic_bytes_per_launch": round(avg_bytes)}
         kernels["sytrd_symv"]["roofline_dense_driver"] = roof_dense
-        # default path: by the rocprofv3 kernel statistics (profiles/) the largest single kernel of a
-        # reduction is the int8 square (one launch, 4 channels): 2*N^3 integer ops per channel
+        # default path: by the rocprofv3 kernel statistics (profiles/) the time of a reduction is
+        # spread over ~15 kernels of comparable weight; the one carrying the O(N^3) work of the path
+        # (and the only MFMA-bound one) is the int8 square: one launch, 4 channels, 2*N^3 integer
+        # ops per channel.  HBM traffic per launch from the committed rocprofv3 --pmc pass
+        # (profiles/r01_pmc_square_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_probe.py).
         ki8 = kernels["square_i8"]
-        roof = {"kernel": "gemm_tn_kernel<i8> (random squares, 4 channels per launch)", "bound": "mfma",
-                "achieved": ki8["achieved"], "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": ki8["frac"], "traffic": None,
+        traffic_i8 = None
+        try:
+            if n == 4096:
+                traffic_i8 = round(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_square_gemm.json")))["i8x4"]["traffic_bytes_per_launch"])
+        except Exception:
+            pass
+        roof = {"kernel": "gemm_tn_dma_kernel<i8> (random squares, 4 channels per launch)", "bound": "mfma",
+                "achieved": ki8["achieved"], "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": ki8["frac"], "traffic": traffic_i8,
+                "ms_per_launch": ki8["ms_per_launch"], "algorithmic_ops_per_launch": 4 * flops,
+                "algorithmic_bytes_per_launch": 4 * (n * n + 4 * n * n),
                 "frac_of_fp32_mfma_peak": ki8["frac_of_fp32_mfma_peak"],
-                "algorithmic": "2*N^3 int8 multiply-adds (as ops) per channel; one launch = channels x 2*N^3"}
+                "algorithmic": "2*N^3 int8 multiply-adds (as ops) per channel; one launch = channels x 2*N^3; "
+                               "algorithmic bytes per launch = channels x (N^2 int8 read + N^2 int32 written)"}
         if args.cpu_n > 0:
             cb = cpu_baseline(pr, args.cpu_n, seed=1)
             scale = (n / cb["n"]) ** 3

@@ -2132,20 +2132,26 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
     if (kind >= 0 && kind <= 2) {
         const size_t es = kind == 0 ? 1 : (kind == 1 ? 4 : 8);
         const size_t os = kind == 0 ? 4 : es;
-        void* X = ctx_buf(c, "prof_x", (size_t)ld * ld * es);
-        void* Cc = ctx_buf(c, "prof_c", (size_t)ld * ld * os);
+        // aux = batch (channels of one launch, as the product path launches them); operands of
+        // all channels are distinct memory
+        const int bt = (int)std::min<int64_t>(std::max<int64_t>(aux, 1), 8);
+        void* X = ctx_buf(c, "prof_x", (size_t)ld * ld * es * bt);
+        void* Cc = ctx_buf(c, "prof_c", (size_t)ld * ld * os * bt);
         uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)ld * ld * 4);
         if (!X || !Cc || !Lb) return SDPSR_OUT_OF_MEMORY;
         // random symmetric operand with full-range values (not zeros: clocks differ on zeros)
         HIP_TRY(c, hipMemsetAsync(Lb, 0, (size_t)ld * ld * 4, s));
         launch_fill_test_sig(s, ld * ld / 2, 1 << 20, (uint64_t*)Lb);  // pseudo-random labels
-        if (kind == 0) launch_gather_i8(s, ld, ld, 1, Lb, 12345, (int8_t*)X);
-        else if (kind == 1) launch_gather_f32(s, ld, ld, 1, 45, Lb, 12345, (float*)X);
-        else launch_gather_f64_padded(s, ld, ld, Lb, 12345, (double*)X);
+        for (int b = 0; b < bt; ++b) {
+            if (kind == 0) launch_gather_i8(s, ld, ld, 1, Lb, 12345 + b, (int8_t*)X + (size_t)b * ld * ld);
+            else if (kind == 1) launch_gather_f32(s, ld, ld, 1, 45, Lb, 12345 + b, (float*)X + (size_t)b * ld * ld);
+            else launch_gather_f64_padded(s, ld, ld, Lb, 12345 + b, (double*)X + (size_t)b * ld * ld);
+        }
+        const int64_t sb = ld * ld;
         auto run = [&]() {
-            if (kind == 0) launch_gemm_tn_i8(s, ld, ld, ld, (int8_t*)X, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, 1, 0, 0, 0);
-            else if (kind == 1) launch_gemm_tn_f32(s, ld, ld, ld, (float*)X, ld, (float*)X, ld, (float*)Cc, ld, 1, 0, 0, 0);
-            else launch_gemm_tn_f64(s, ld, ld, ld, (double*)X, ld, (double*)X, ld, (double*)Cc, ld, 1, 0, 0, 0);
+            if (kind == 0) launch_gemm_tn_i8(s, ld, ld, ld, (int8_t*)X, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, bt, sb, sb, sb);
+            else if (kind == 1) launch_gemm_tn_f32(s, ld, ld, ld, (float*)X, ld, (float*)X, ld, (float*)Cc, ld, bt, sb, sb, sb);
+            else launch_gemm_tn_f64(s, ld, ld, ld, (double*)X, ld, (double*)X, ld, (double*)Cc, ld, bt, sb, sb, sb);
         };
         run();
         HIP_TRY(c, hipEventRecord(e0, s));
