@@ -239,6 +239,8 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
     int log2cap = std::min(full, std::max(12, c->table_log2_hint));
     const int64_t rb = (int64_t)refine_block_entries();
     const int64_t nblk = (len + rb - 1) / rb;
+    int attempts = 0;
+    bool mispredicted = false;
     for (;;) {
         const size_t cap = size_t(1) << log2cap;
         RefineWs ws;
@@ -251,14 +253,21 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
             return SDPSR_OUT_OF_MEMORY;
         ws.log2cap = log2cap;
         ws.nblk = (int)nblk;
+        ws.expect_small = (!mispredicted && c->table_log2_hint <= 12) ? 1 : 0;  // hint 12 <=> last dim <= 512
         launch_refine(c->stream, len, sig, labels, ws);
         uint32_t* h = (uint32_t*)c->pinned;
         HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
+        if (!h[1] && ws.expect_small && h[0] > refine_small_k()) {  // more classes than predicted: general ranking
+            mispredicted = true;
+            continue;
+        }
         if (h[1]) {  // table too small for this many classes
             if (log2cap >= full) return ctx_fail(c, SDPSR_HIP_ERROR, "refine hash table overflow at full size");
-            log2cap = std::min(full, log2cap + 4);
+            // the dimension can jump by orders of magnitude between two refinements (generic
+            // problems go from a handful of classes to ~n^2/2 in one step): one large step, then full
+            log2cap = (++attempts >= 2) ? full : std::min(full, log2cap + 6);
             continue;
         }
         *nparts = h[2];

@@ -9,6 +9,7 @@
 //
 // All of these are HBM-bound: one pass over n^2 entries each, 16-byte accesses per lane,
 // grid sized to a few blocks per CU with grid-stride loops.
+#include <cstdlib>
 #include "sdpsr_internal.h"
 
 namespace sdpsr {
@@ -436,7 +437,7 @@ constexpr int REFINE_PER_THREAD = 4;
 constexpr int REFINE_BLOCK = REFINE_THREADS * REFINE_PER_THREAD;  // 1024 entries
 constexpr int LDS_SLOTS = 2048;
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
-constexpr int MAX_PROBES = 4096;
+constexpr int MAX_PROBES = 512;
 // Few-classes fast path: the first SMALL_K distinct signatures also append their global slot to
 // a list (counters[LIST_OFF + i]); when the whole partition has <= SMALL_K classes one workgroup
 // ranks those slots by first index and the three entry-level ranking passes exit at once.
@@ -444,10 +445,13 @@ constexpr uint32_t SMALL_K = 1024;
 constexpr int LIST_OFF = 16;
 
 size_t refine_block_entries() { return REFINE_BLOCK; }
+uint32_t refine_small_k() { return SMALL_K; }
 size_t refine_counters_bytes() { return (size_t)(LIST_OFF + SMALL_K) * sizeof(uint32_t); }
 
 __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned long long* tab,
                                                           uint32_t mask, uint32_t* counters) {
+    // (the overflow flag is checked once per chunk by the caller: after an overflow the host
+    // repeats the pass with a larger table, nobody should keep walking a full one)
     uint32_t idx = (uint32_t)sg & mask;
     for (int probe = 0; probe < MAX_PROBES; ++probe) {
         unsigned long long cur = tab[idx];  // slots are write-once: a stale read can only be 0
@@ -479,38 +483,80 @@ __global__ void __launch_bounds__(REFINE_THREADS)
 refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
                      uint32_t* __restrict__ slot_out, unsigned long long* __restrict__ tab_sig,
                      uint32_t* __restrict__ tab_min, uint32_t mask, uint32_t* counters) {
+    // The LDS table lives across the chunks of a workgroup: a signature is published to the
+    // global table only the first time the workgroup meets it (its chunks come in increasing
+    // index order, so that chunk also holds the workgroup's smallest index of the class); later
+    // chunks reuse the resolved global slot.  The table is reset when it gets half full.
     __shared__ unsigned long long l_sig[LDS_SLOTS];
     __shared__ uint32_t l_min[LDS_SLOTS];
     __shared__ uint32_t l_gslot[LDS_SLOTS];
+    __shared__ uint32_t l_count, l_overflow;
+    constexpr uint32_t PENDING = 0xFFFFFFFEu;
     const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
+    bool need_clear = true, bypass = false;
     for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x) {
-        for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
-            l_sig[i] = 0ull;
-            l_min[i] = 0xFFFFFFFFu;
+        if (need_clear) {
+            for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
+                l_sig[i] = 0ull;
+                l_min[i] = 0xFFFFFFFFu;
+            }
+            if (threadIdx.x == 0) l_count = 0;
         }
+        if (threadIdx.x == 0) l_overflow = __builtin_nontemporal_load(&counters[1]);
         __syncthreads();
+        if (l_overflow) return;  // uniform: the host repeats the pass with a larger table
         const int64_t base = blk * INSERT_CHUNK;
+        if (bypass) {
+            // many classes (the previous chunk half filled the LDS table on its own): the LDS
+            // level only costs probes, every entry goes to the global table directly
+#pragma unroll 4
+            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
+                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+                if (e < len) {
+                    const uint64_t sg = __builtin_nontemporal_load(&sig[e]);
+                    uint32_t out = NO_SLOT;
+                    if (sg) {
+                        out = global_find_or_insert(sg, tab_sig, mask, counters);
+                        if (out != NO_SLOT && tab_min[out] > (uint32_t)e) atomicMin(&tab_min[out], (uint32_t)e);
+                    }
+                    slot_out[e] = out;
+                }
+            }
+            continue;
+        }
         // >= 0: LDS slot; -1: zero signature; <= -2: already resolved global slot (-2 - g)
         int myslot[INSERT_PER_THREAD];
+        // all 16 signature loads are issued before the first probe: the probe loop contains LDS
+        // atomics, which the compiler will not move global loads across
+        uint64_t sgs[INSERT_PER_THREAD];
 #pragma unroll
         for (int q = 0; q < INSERT_PER_THREAD; ++q) {
             const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-            const uint64_t sg = (e < len) ? sig[e] : 0ull;
+            sgs[q] = (e < len) ? __builtin_nontemporal_load(&sig[e]) : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < INSERT_PER_THREAD; ++q) {
+            const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+            const uint64_t sg = sgs[q];
             myslot[q] = -1;
             if (sg) {
                 uint32_t idx = (uint32_t)(sg >> 40) & (LDS_SLOTS - 1);
                 int probes = 0;
-                bool placed = false;
+                int placed = 0;  // 1: found, 2: inserted by this thread
                 while (probes < LDS_MAX_PROBES) {
                     unsigned long long cur = l_sig[idx];
                     if (cur == sg) {
-                        placed = true;
+                        placed = 1;
                         break;
                     }
                     if (cur == 0ull) {
                         unsigned long long old = atomicCAS(&l_sig[idx], 0ull, (unsigned long long)sg);
-                        if (old == 0ull || old == sg) {
-                            placed = true;
+                        if (old == 0ull) {
+                            placed = 2;
+                            break;
+                        }
+                        if (old == sg) {
+                            placed = 1;
                             break;
                         }
                     }
@@ -518,6 +564,10 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
                     ++probes;
                 }
                 if (placed) {
+                    if (placed == 2) {
+                        l_gslot[idx] = PENDING;
+                        atomicAdd(&l_count, 1u);
+                    }
                     // l_min only decreases: a plain read that is already <= e makes the atomic a
                     // no-op (true for every entry after the first of its class in this thread's
                     // increasing index order, i.e. almost always when classes are few)
@@ -533,14 +583,12 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
             }
         }
         __syncthreads();
-        // publish distinct signatures of this chunk
+        // publish the signatures this workgroup has not resolved yet
         for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
-            unsigned long long sg = l_sig[i];
-            if (sg) {
-                uint32_t g = global_find_or_insert(sg, tab_sig, mask, counters);
+            if (l_sig[i] != 0ull && l_gslot[i] == PENDING) {
+                const uint32_t g = global_find_or_insert(l_sig[i], tab_sig, mask, counters);
                 // tab_min only ever decreases, so a (possibly stale) plain read that is already
-                // <= our candidate proves the atomic cannot change anything: skip it.  In the
-                // few-classes regime this removes almost every contended atomic on the hot slots.
+                // <= our candidate proves the atomic cannot change anything: skip it.
                 if (g != NO_SLOT) {
                     const uint32_t mine = l_min[i];
                     if (tab_min[g] > mine) atomicMin(&tab_min[g], mine);
@@ -559,6 +607,8 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
                 slot_out[e] = out;
             }
         }
+        need_clear = l_count > LDS_SLOTS / 2;  // uniform (read after the barrier above)
+        bypass = need_clear;
         __syncthreads();
     }
 }
@@ -725,11 +775,17 @@ void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* la
                                                       (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                       (uint32_t)(cap - 1), ws.counters);
     const int g2 = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
+    // ws.expect_small: the host predicts <= SMALL_K classes (from the previous refinement) and
+    // launches the one-workgroup ranking only; it checks counters[0] afterwards and repeats the
+    // pass with expect_small = 0 on a misprediction (the three general kernels would exit at once
+    // anyway, but three empty launches cost ~15 us of a ~150 us refinement)
     refine_small_rank_kernel<<<1, 1024, 0, s>>>(ws.tab_min, ws.tab_lab, ws.counters);
-    refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt, ws.counters);
-    refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
-    refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt,
-                                                     ws.tab_lab, ws.counters);
+    if (!ws.expect_small) {
+        refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt, ws.counters);
+        refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
+        refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt,
+                                                         ws.tab_lab, ws.counters);
+    }
     refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, labels_out, ws.tab_lab);
 }
 

@@ -114,12 +114,14 @@ struct RefineWs {
     uint32_t* tab_min;   // cap
     uint32_t* tab_lab;   // cap
     uint32_t* blk_cnt;   // nblk + 1
+    int expect_small = 0;  // host prediction: <= refine_small_k() classes (see launch_refine)
     uint32_t* counters;  // [0] = inserted, [1] = overflow flag, [2] = nparts, [16..] slot list (refine_counters_bytes())
     int log2cap;
     int nblk;
 };
 size_t refine_block_entries();
 size_t refine_counters_bytes();
+uint32_t refine_small_k();
 void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out,
                    const RefineWs& ws);
 
