@@ -1614,8 +1614,10 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     const int wmax = (int)std::min<int64_t>(std::min<int64_t>(n / 2, 500), 2 * d + 8);
     if (wmax < 2) return krylov_fallback(c, "module too small to compress");
     const int64_t wcap = round_up(wmax + 2, 128);
+    const int64_t ycap = 2 * wcap;                  // candidate columns of one round
+    const int64_t wtot = wcap + ycap + 128;         // basis | candidates | padding of the last tile
     uint32_t* flag = (uint32_t*)ctx_buf(c, "bd_flag", 64);
-    double* W = (double*)ctx_buf(c, "cm_w", (size_t)ld * wcap * 8);
+    double* W = (double*)ctx_buf(c, "cm_w", (size_t)ld * wtot * 8);
     double* T = (double*)ctx_buf(c, "cm_t", (size_t)ld * wcap * 8);
     double* zy = (double*)ctx_buf(c, "cm_zy", (size_t)ld * 2 * 8);
     double* dout = (double*)ctx_buf(c, "cm_out", 64);
@@ -1647,31 +1649,26 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     };
     dbg_mark("compressed: buffers + symmetric check done");
     tm.begin(SDPSR_T_EIGEN);
-    HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)ld * wcap * 8, s));
+    HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)ld * wtot * 8, s));
     double* y = zy;
     launch_random_vector(s, n, next_key(c), y);
     launch_lanczos_init(s, n, ld, W, 0, y, ld, 1, dout);  // W[:,0] = x / |x|
     int w = 1;
-    // Block growth: candidates Y = [A_a W, A_b W] for two fresh generic elements, projected off
-    // W (block CGS, twice); the new directions are selected by a pivoted Cholesky factorisation
-    // of the Gram matrix Y'Y (rank gap: O(1) against eps^2, sharp because every candidate is a
-    // first power of a well-scaled matrix) and orthonormalised as Y P R^-1, then once more
-    // against W.  The module is complete when a round adds nothing.
-    const int64_t ycap = 2 * wcap;
-    double* Y = (double*)ctx_buf(c, "cm_y", (size_t)ld * ycap * 8);
-    double* Cc = (double*)ctx_buf(c, "cm_c", (size_t)ycap * ycap * 8);
-    double* dSm = (double*)ctx_buf(c, "cm_sm", (size_t)(ycap * ycap + ycap) * 8);
-    double* nrm_part = (double*)ctx_buf(c, "cm_nrm_part", (size_t)ycap * 64 * 8);
+    // Block growth.  The candidates of a round (class sums of x, then A_g W for G fresh generic
+    // elements) are written right behind the basis, Y = W[:, w : w+m), so that ONE split-K MFMA
+    // product [W Y]' Y delivers both C = W'Y and the Gram matrix Y'Y.  On the host the Gram matrix
+    // of the projected candidates is G - C'C (its cancellation error ~eps |Y|^2 sits four orders
+    // below the rank threshold), a pivoted Cholesky factorisation picks the new directions
+    // (rank gap: O(1) against eps^2, sharp because every candidate is a first power of a
+    // well-scaled matrix) and Q1 = [W Y] [-C X; X] forms them in one pass.  A second product
+    // [W Q1]' Q1 with the same structure re-orthonormalises (CholQR2).  A round that adds nothing
+    // (the module is complete) therefore costs one product.
+    double* Cc = (double*)ctx_buf(c, "cm_c", (size_t)(wcap + ycap + 128) * ycap * 8);
+    double* dSm = (double*)ctx_buf(c, "cm_sm", (size_t)(wcap + ycap) * ycap * 8);
     double* Q1 = (double*)ctx_buf(c, "cm_q1", (size_t)ld * ycap * 8);
-    if (!Y || !Cc || !dSm || !Q1 || !nrm_part) return SDPSR_OUT_OF_MEMORY;
-    std::vector<double> hG, hS;
-    auto project_off_W = [&](double* Yb, int64_t ncolp, int ncol) {  // Yb -= W (W' Yb), twice
-        const int64_t wpp = round_up(w, 128);
-        for (int pass = 0; pass < 2; ++pass) {
-            gemm_tn_splitk(c, wpp, ncolp, ld, W, ld, Yb, ld, Cc, wpp);  // C = W' Y
-            launch_tall_times_small(s, n, ld, W, w, Cc, (int)wpp, ncol, -1.0, 1.0, Yb, ld);
-        }
-    };
+    if (!Cc || !dSm || !Q1) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemsetAsync(Q1, 0, (size_t)ld * ycap * 8, s));  // rows >= n stay zero for good
+    std::vector<double> hG;
     // pivoted Cholesky of the m x m Gram matrix (leading dimension ldg): returns rank r, the
     // pivot order and X = R11^-1 scattered into an m x r coefficient matrix (column-major, ld m)
     auto gram_select = [&](const std::vector<double>& G, int64_t ldg, int m, double tol_abs, std::vector<double>& coef) -> int {
@@ -1720,51 +1717,67 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         return r;
     };
     double ref = 0;  // squared scale of a candidate column before projection (first batch)
-    // absorb m densely packed candidate columns Y[:, 0:m) into W; returns the number of new
-    // basis vectors (0 = nothing left the span), < 0 on error (status in `abs_err`)
     int abs_err = SDPSR_OK;
-    auto absorb = [&](int m) -> int {
-        const int64_t mp = round_up(m, 128);
-        const bool need_ref = (ref == 0);
-        // scale reference: squared column norms of the candidates BEFORE projection (after it, a
-        // complete module leaves only rounding noise and a relative test would compare noise with
-        // noise); they ride behind the Gram matrix in the same read-back
-        if (need_ref) launch_col_norms2(s, ld, m, Y, nrm_part, 64, dSm + (size_t)mp * mp);
-        project_off_W(Y, mp, m);
-        gemm_tn_splitk(c, mp, mp, ld, Y, ld, Y, ld, dSm, mp);  // Gram
-        hG.resize((size_t)mp * mp + (size_t)m);
-        abs_err = d2h_sync(c, hG.data(), dSm, ((size_t)mp * mp + (need_ref ? (size_t)m : 0)) * 8);
+    // One orthonormalisation step on the mc columns behind the basis, V = W[:, w : w+mc):
+    // product [W V]' V, projected Gram matrix on the host, selection X (mc x r); returns r and
+    // the stacked coefficients S = [-C X; X] ((w+mc) x r) with V_new = [W V] S.  r < 0: error.
+    auto ortho_step = [&](int mc, double tol_abs, bool take_ref, std::vector<double>& stacked) -> int {
+        const int64_t ap = round_up(w + mc, 128), mp = round_up(mc, 128);
+        abs_err = gemm_tn_splitk(c, ap, mp, ld, W, ld, W + (size_t)w * ld, ld, Cc, ap);
         if (abs_err) return -1;
-        if (need_ref)
-            for (int64_t i = 0; i < m; ++i) ref = std::max(ref, hG[(size_t)mp * mp + (size_t)i]);
-        std::vector<double> coefc;
-        const int r_new = gram_select(hG, mp, m, 1e-12 * ref, coefc);
-        if (r_new == 0) return 0;
+        hG.resize((size_t)ap * mp);
+        abs_err = d2h_sync(c, hG.data(), Cc, (size_t)ap * mp * 8);
+        if (abs_err) return -1;
+        // scale reference: the candidates BEFORE projection (after it, a complete module leaves
+        // only rounding noise and a relative test would compare noise with noise)
+        if (take_ref && ref == 0)
+            for (int i = 0; i < mc; ++i) ref = std::max(ref, hG[(size_t)(w + i) + (size_t)i * ap]);
+        std::vector<double> G1((size_t)mc * mc);
+        for (int j = 0; j < mc; ++j)
+            for (int i = 0; i < mc; ++i) {
+                double v = hG[(size_t)(w + i) + (size_t)j * ap];
+                for (int t = 0; t < w; ++t) v -= hG[(size_t)t + (size_t)i * ap] * hG[(size_t)t + (size_t)j * ap];
+                G1[(size_t)i + (size_t)j * mc] = v;
+            }
+        std::vector<double> X;
+        const int r = gram_select(G1, mc, mc, take_ref ? tol_abs * ref : tol_abs, X);
+        if (r <= 0) return 0;
+        stacked.assign((size_t)(w + mc) * r, 0.0);
+        for (int cc = 0; cc < r; ++cc) {
+            double* col = stacked.data() + (size_t)cc * (w + mc);
+            for (int i = 0; i < mc; ++i) {
+                const double xi = X[(size_t)i + (size_t)cc * mc];
+                col[w + i] = xi;
+                if (xi != 0.0)
+                    for (int t = 0; t < w; ++t) col[t] -= hG[(size_t)t + (size_t)i * ap] * xi;
+            }
+        }
+        return r;
+    };
+    // V_new = [W V] S into Q1, then back behind the basis (the old V is dead by then)
+    auto apply_stacked = [&](int mc, int r, const std::vector<double>& stacked) -> int {
+        int e2 = h2d_sync(c, dSm, stacked.data(), (size_t)(w + mc) * r * 8);
+        if (e2) return e2;
+        launch_tall_times_small(s, n, ld, W, w + mc, dSm, w + mc, r, 1.0, 0.0, Q1, ld);
+        HIP_TRY(c, hipMemcpyAsync(W + (size_t)w * ld, Q1, (size_t)ld * r * 8, hipMemcpyDeviceToDevice, s));
+        return SDPSR_OK;
+    };
+    // absorb m candidate columns W[:, w : w+m) into the basis; returns the number of new basis
+    // vectors (0 = nothing left the span), < 0 on error (status in `abs_err`)
+    auto absorb = [&](int m) -> int {
+        std::vector<double> st1, st2;
+        const int r_new = ortho_step(m, 1e-12, true, st1);
+        if (r_new <= 0) return r_new;
         if (w + r_new >= wmax) {
             abs_err = krylov_fallback(c, "module dimension exceeds " + std::to_string(wmax));
             return -1;
         }
-        // Q1 = Y * coef
-        abs_err = h2d_sync(c, dSm, coefc.data(), (size_t)m * r_new * 8);
+        abs_err = apply_stacked(m, r_new, st1);
         if (abs_err) return -1;
-        const int64_t rp = round_up(r_new, 128);
-        if (hipMemsetAsync(Q1, 0, (size_t)ld * rp * 8, s) != hipSuccess) {
-            abs_err = ctx_fail(c, SDPSR_HIP_ERROR, "memset");
-            return -1;
-        }
-        launch_tall_times_small(s, n, ld, Y, m, dSm, m, r_new, 1.0, 0.0, Q1, ld);
-        // second orthonormalisation pass (CholQR2): off W again, then Gram + Cholesky of Q1 itself
-        project_off_W(Q1, rp, r_new);
-        gemm_tn_splitk(c, rp, rp, ld, Q1, ld, Q1, ld, Cc, rp);
-        hG.resize((size_t)rp * rp);
-        abs_err = d2h_sync(c, hG.data(), Cc, (size_t)rp * rp * 8);
+        const int r2 = ortho_step(r_new, 1e-6, false, st2);  // Q1 columns have unit scale
+        if (r2 <= 0) return r2;
+        abs_err = apply_stacked(r_new, r2, st2);
         if (abs_err) return -1;
-        std::vector<double> coef2;
-        const int r2 = gram_select(hG, rp, r_new, 1e-6, coef2);  // Q1 columns have unit scale
-        if (r2 <= 0) return 0;
-        abs_err = h2d_sync(c, dSm, coef2.data(), (size_t)r_new * r2 * 8);
-        if (abs_err) return -1;
-        launch_tall_times_small(s, n, ld, Q1, r_new, dSm, r_new, r2, 1.0, 0.0, W + (size_t)w * ld, ld);
         w += r2;
         return r2;
     };
@@ -1772,8 +1785,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     // row-sum kernel of basis_image with a single column).  For a commutative algebra this
     // already is the whole module.
     if (ld == n && basis_image_two_stage_fits(n, d, 1) && d <= ycap && d + 1 < wmax) {
-        HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * round_up(d, 128) * 8, s));
-        launch_class_sums(s, n, d, L, W, Y);  // Y[:, i] = P_{i+1} x
+        launch_class_sums(s, n, d, L, W, W + (size_t)w * ld);  // W[:, w + i] = P_{i+1} x
         const int got = absorb((int)d);
         if (got < 0) {
             tm.end();
@@ -1790,7 +1802,8 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         // module into itself form a subspace of S; it contains a generic point iff it is S)
         if ((int64_t)G * w > ycap || w >= d) G = 1;
         const int m = G * w;
-        // candidates: Y[:, g*w + (0:w)] = A_g W for fresh generic elements A_g
+        // candidates: W[:, w + g*w + (0:w)] = A_g W for fresh generic elements A_g (rows >= n zero)
+        double* Y = W + (size_t)w * ld;
         HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * round_up(m, 128) * 8, s));
         for (int gidx = 0; gidx < G; ++gidx) {
             int e2 = apply_generic(w, Y + (size_t)gidx * w * ld);
@@ -1806,7 +1819,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     }
     // columns >= w must be zero for the padded products below
     const int64_t wp = round_up(w, 128);
-    HIP_TRY(c, hipMemsetAsync(W + (size_t)w * ld, 0, (size_t)ld * (wcap - w) * 8, s));
+    HIP_TRY(c, hipMemsetAsync(W + (size_t)w * ld, 0, (size_t)ld * (wtot - w) * 8, s));
     tm.end();
     tm.collect();
     if (getenv("SDPSR_DEBUG")) fprintf(stderr, "[sdpsr] module compression: n=%lld dim(P)=%lld -> w=%d\n", (long long)n, (long long)d, w);
