@@ -4,6 +4,8 @@
 // Round-1 driver: rocSOLVER in three explicit phases so that each can be timed and the
 // tridiagonalisation can be replaced by the hand-written HIP panel kernel without touching
 // the callers:   sytrd (A = Q T Q')  ->  stedc (T = Z D Z')  ->  ormtr (V = Q Z).
+#include <cstdlib>
+#include <cstdio>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
@@ -83,10 +85,13 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w) {
                              hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             return ctx_fail(c, SDPSR_HIP_ERROR, "copy of eigenvectors failed");
     }
-    rocblas_int hinfo = 0;
-    if (hipMemcpyAsync(&hinfo, info, sizeof(hinfo), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+    // read-back through the pinned scratch of the ctx (a pageable 4-byte copy costs tens of us)
+    rocblas_int* hpin = (rocblas_int*)c->pinned;
+    if (!hpin || hipMemcpyAsync(hpin, info, 2 * sizeof(rocblas_int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess)
         return ctx_fail(c, SDPSR_HIP_ERROR, "eigensolver info read-back failed");
+    const rocblas_int hinfo = hpin[0];
+    if (getenv("SDPSR_DEBUG") && n <= 128) fprintf(stderr, "[sdpsr] small syev n=%lld: %d sweeps\n", (long long)n, (int)hpin[1]);
     if (hinfo != 0)
         return ctx_fail(c, SDPSR_SOLVER_ERROR, "eigensolver did not converge, info=" + std::to_string(hinfo));
     return SDPSR_OK;
