@@ -233,8 +233,10 @@ struct PhaseTimer {
 };
 
 // ---- canonical refinement of a signature array --------------------------------
+// sym_n > 0: the new labels (an sym_n x sym_n matrix) are also checked for symmetry on the device
+// and the verdict rides back with the counters (same synchronisation): *sym_out = 1 if symmetric.
 int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* labels,
-                      int64_t* nparts) {
+                      int64_t* nparts, int64_t sym_n = 0, uint32_t* symflag_dev = nullptr, int* sym_out = nullptr) {
     const int full = std::max(12, ceil_log2((uint64_t)len * 2));
     int log2cap = std::min(full, std::max(12, c->table_log2_hint));
     const int64_t rb = (int64_t)refine_block_entries();
@@ -257,7 +259,12 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
         launch_refine(c->stream, len, sig, labels, ws);
         uint32_t* h = (uint32_t*)c->pinned;
         HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (sym_n > 0 && symflag_dev) {
+            launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);  // flag = 1 if NOT symmetric
+            HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (sym_n > 0 && symflag_dev && sym_out) *sym_out = h[8] ? 0 : 1;
         HIP_TRY(c, hipGetLastError());
         if (!h[1] && ws.expect_small && h[0] > refine_small_k()) {  // more classes than predicted: general ranking
             mispredicted = true;
@@ -590,7 +597,11 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     const int nblk = 2048;
     double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * nblk * 8);
     double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
-    if (st || !sig || !partial || !coef) return st ? st : SDPSR_OUT_OF_MEMORY;
+    uint32_t* symflag = (uint32_t*)ctx_buf(c, "adm_symflag", 64);  // [0] verdict of the last check, [8] constant 0
+    if (st || !sig || !partial || !coef || !symflag) return st ? st : SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemsetAsync(symflag, 0, 64, s));
+    const uint32_t* zero_flag = symflag + 8;  // "symmetric" for the kernels that take a device flag
+    int labels_sym = 0;
 
     const int mode = c->opts.square_mode;
     const int T = (mode == SDPSR_SQUARE_F64) ? 1 : c->opts.channels;
@@ -647,7 +658,8 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         tm.end();
         tm.begin(SDPSR_T_REFINE);
         int64_t d1 = 0;
-        st = refine_signatures(c, len, sig, L, &d1);
+        const bool int_mode = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
+        st = refine_signatures(c, len, sig, L, &d1, int_mode ? n : 0, symflag, &labels_sym);
         tm.end();
         if (st) return st;
         // --- random square (:166-174) ---
@@ -655,16 +667,44 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         for (;;) {
             tm.begin(SDPSR_T_SQUARE);
             const uint64_t key2 = next_key(c);
+            // Integer modes.  Symmetric labels (the Jordan-algebra case; the verdict came back
+            // with the counters of the last refinement): X is symmetric, X X = X'X is symmetric
+            // and exact, so only the lower-triangle tiles are computed, only entries i >= j get
+            // a signature, and the strict upper triangle of the new labels is mirrored after the
+            // refinement (first occurrences in column-major order always sit in the lower
+            // triangle: same canonical numbering).  Non-symmetric labels: X X literally, with
+            // the K-contiguous left operand gathered from the transposed labels (same draw).
+            const uint32_t* lower = labels_sym ? zero_flag : nullptr;
+            const uint32_t* Lleft = L;
+            if (int_mode && !labels_sym) {
+                uint32_t* Lt = (uint32_t*)ctx_buf(c, "des_lt", len * 4);
+                if (!Lt) return SDPSR_OUT_OF_MEMORY;
+                launch_transpose_labels(s, n, L, Lt);
+                Lleft = Lt;
+            }
             if (mode == SDPSR_SQUARE_I8) {
+                int8_t* Xl = (int8_t*)Xp;
                 launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp);
-                launch_gemm_tn_i8(s, ld, ld, ld, (const int8_t*)Xp, ld, (const int8_t*)Xp, ld,
-                                  (int32_t*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
-                launch_sig_i32(s, n, ld, T, L, (const int32_t*)Cp, sig);
+                if (!labels_sym) {
+                    Xl = (int8_t*)ctx_buf(c, "des_yi8", (size_t)T * ld * ld);
+                    if (!Xl) return SDPSR_OUT_OF_MEMORY;
+                    launch_gather_i8(s, n, ld, T, Lleft, key2, Xl);
+                    launch_gemm_tn_i8(s, ld, ld, ld, Xl, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
+                } else {
+                    launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, lower);
+                }
+                launch_sig_i32(s, n, ld, T, L, (const int32_t*)Cp, sig, lower);
             } else if (mode == SDPSR_SQUARE_F32) {
                 launch_gather_f32(s, n, ld, T, vmax, L, key2, (float*)Xp);
-                launch_gemm_tn_f32(s, ld, ld, ld, (const float*)Xp, ld, (const float*)Xp, ld,
-                                   (float*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
-                launch_sig_f32(s, n, ld, T, L, (const float*)Cp, sig);
+                if (!labels_sym) {
+                    float* Xl = (float*)ctx_buf(c, "adm_xlf32", (size_t)T * ld * ld * 4);
+                    if (!Xl) return SDPSR_OUT_OF_MEMORY;
+                    launch_gather_f32(s, n, ld, T, vmax, Lleft, key2, Xl);
+                    launch_gemm_tn_f32(s, ld, ld, ld, Xl, ld, (const float*)Xp, ld, (float*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
+                } else {
+                    launch_gemm_tn_f32_sym(s, ld, ld, (const float*)Xp, ld, (float*)Cp, ld, T, ld * ld, ld * ld, lower);
+                }
+                launch_sig_f32(s, n, ld, T, L, (const float*)Cp, sig, lower);
             } else {
                 // reference-literal: the projected element is squared when the projection
                 // step did not refine S (X is overwritten in place at :160-163), a fresh
@@ -680,6 +720,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             tm.end();
             tm.begin(SDPSR_T_REFINE);
             st = refine_signatures(c, len, sig, L, &d2);
+            if (!st && int_mode && labels_sym) launch_mirror_labels(s, n, L, zero_flag);
             tm.end();
             if (st) return st;
             tm.collect();

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(NT)
 gemm_tn_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag, int64_t lda,
                const typename GemmTraits<KIND>::in_t* __restrict__ Bg, int64_t ldb,
                typename GemmTraits<KIND>::out_t* __restrict__ Cg, int64_t ldc, int64_t strideA,
-               int64_t strideB, int64_t strideC) {
+               int64_t strideB, int64_t strideC, const uint32_t* __restrict__ nonsym_flag) {
     typedef GemmTraits<KIND> TR;
     typedef typename TR::in_t in_t;
     typedef typename TR::out_t out_t;
@@ -77,6 +77,9 @@ gemm_tn_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag
 
     const int64_t i0 = (int64_t)blockIdx.x * BM;
     const int64_t j0 = (int64_t)blockIdx.y * BN;
+    // symmetric product (C = X'X) whose consumer only reads the lower triangle: tiles above the
+    // diagonal are skipped while the device flag says the labels are symmetric
+    if (nonsym_flag && i0 < j0 && *nonsym_flag == 0u) return;
     const char* Ab = reinterpret_cast<const char*>(Ag + (int64_t)blockIdx.z * strideA + i0 * lda);
     const char* Bb = reinterpret_cast<const char*>(Bg + (int64_t)blockIdx.z * strideB + j0 * ldb);
     out_t* C = Cg + (int64_t)blockIdx.z * strideC;
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(NT)
 gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag, int64_t lda,
                    const typename GemmTraits<KIND>::in_t* __restrict__ Bg, int64_t ldb,
                    typename GemmTraits<KIND>::out_t* __restrict__ Cg, int64_t ldc, int64_t strideA, int64_t strideB,
-                   int64_t strideC) {
+                   int64_t strideC, const uint32_t* __restrict__ nonsym_flag) {
     typedef typename GemmTraits<KIND>::in_t in_t;
     typedef typename GemmTraits<KIND>::out_t out_t;
     constexpr int ES = sizeof(in_t);
@@ -264,7 +267,20 @@ gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict_
     // walk the tiles in 8-row groups, so the workgroups resident on an XCD at any time share
     // operand rows through its L2.
     int bi = blockIdx.x, bj = blockIdx.y;
-    {
+    const bool sym_lower = nonsym_flag && *nonsym_flag == 0u;  // uniform
+    if (sym_lower) {
+        // lower-triangle tiles only: workgroup number t (dealt round-robin over the XCDs by the
+        // hardware, which balances the triangle) takes tile t of the row-major enumeration
+        // (bi, bj <= bi); the workgroups beyond the triangle have nothing to do
+        const int t = blockIdx.y * gridDim.x + blockIdx.x;
+        const int gm = gridDim.x;
+        if (t >= gm * (gm + 1) / 2) return;
+        int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (row * (row + 1) / 2 > t) --row;
+        while ((row + 1) * (row + 2) / 2 <= t) ++row;
+        bi = row;
+        bj = t - row * (row + 1) / 2;
+    } else {
         const int gm = gridDim.x, gn = gridDim.y;
         const int nwg = gm * gn;
         if ((nwg & 7) == 0 && (gm & 7) == 0) {
@@ -438,7 +454,7 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
                         const typename GemmTraits<KIND>::in_t* A, int64_t lda,
                         const typename GemmTraits<KIND>::in_t* B, int64_t ldb,
                         typename GemmTraits<KIND>::out_t* C, int64_t ldc, int batch,
-                        int64_t strideA, int64_t strideB, int64_t strideC) {
+                        int64_t strideA, int64_t strideB, int64_t strideC, const uint32_t* nonsym_flag = nullptr) {
     constexpr int KB = GemmTraits<KIND>::KB;
     constexpr size_t lds = 2 * 2 * BM * (KB + 16);
     dim3 grid((unsigned)(m / BM), (unsigned)(n / BN), (unsigned)batch);
@@ -453,7 +469,7 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
             dma_attr_set = true;
         }
-        gemm_tn_dma_kernel<KIND><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC);
+        gemm_tn_dma_kernel<KIND><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
         return;
     }
     static bool attr_set = false;
@@ -462,7 +478,7 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    gemm_tn_kernel<KIND><<<grid, NT, lds, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC);
+    gemm_tn_kernel<KIND><<<grid, NT, lds, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
 }
 
 void launch_gemm_tn_i8(hipStream_t s, int64_t m, int64_t n, int64_t k, const int8_t* A,
@@ -479,6 +495,17 @@ void launch_gemm_tn_f64(hipStream_t s, int64_t m, int64_t n, int64_t k, const do
                         int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                         int batch, int64_t strideA, int64_t strideB, int64_t strideC) {
     launch_gemm<KIND_F64>(s, m, n, k, A, lda, B, ldb, C, ldc, batch, strideA, strideB, strideC);
+}
+
+// C = X'X with only the lower-triangle tiles computed while *nonsym_flag == 0 (device-side
+// decision, no host round trip); the consumer must then read C[i,j] for i >= j only
+void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc,
+                           int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag) {
+    launch_gemm<KIND_I8>(s, n, n, k, X, ldx, X, ldx, C, ldc, batch, strideX, strideX, strideC, nonsym_flag);
+}
+void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X, int64_t ldx, float* C, int64_t ldc,
+                            int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag) {
+    launch_gemm<KIND_F32>(s, n, n, k, X, ldx, X, ldx, C, ldc, batch, strideX, strideX, strideC, nonsym_flag);
 }
 
 }  // namespace sdpsr

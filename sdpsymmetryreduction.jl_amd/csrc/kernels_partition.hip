@@ -383,14 +383,24 @@ void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_
 // grid (row chunks, columns): no 64-bit division per entry
 template <typename CT>
 __global__ void sig_channels_kernel(int64_t n, int64_t ld, int T, const uint32_t* __restrict__ L,
-                                    const CT* __restrict__ C, uint64_t* __restrict__ sig) {
+                                    const CT* __restrict__ C, uint64_t* __restrict__ sig,
+                                    const uint32_t* __restrict__ nonsym_flag) {
     const int64_t istride = (int64_t)gridDim.x * blockDim.x;
+    // lower != 0: labels and products are symmetric, only entries i >= j get a signature (the
+    // strict upper triangle gets the zero signature and is mirrored after the refinement; first
+    // occurrences in column-major order always sit in the lower triangle, so the canonical
+    // numbering is unchanged)
+    const bool lower = nonsym_flag && *nonsym_flag == 0u;
     for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
         const uint32_t* Lj = L + j * n;
         uint64_t* sj = sig + j * n;
         const CT* Cj = C + j * ld;
 #pragma unroll 2
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += istride) {
+            if (lower && i < j) {
+                sj[i] = 0ull;
+                continue;
+            }
             const uint32_t l = Lj[i];
             uint64_t h = sdpsr_sig_start(l);
             bool allz = true;
@@ -411,12 +421,12 @@ static inline dim3 column_grid(int64_t n) {
     return dim3((unsigned)gx, (unsigned)(n < 65535 ? n : 65535));
 }
 void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const int32_t* C, uint64_t* sig) {
-    sig_channels_kernel<int32_t><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig);
+                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag) {
+    sig_channels_kernel<int32_t><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag);
 }
 void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const float* C, uint64_t* sig) {
-    sig_channels_kernel<float><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig);
+                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag) {
+    sig_channels_kernel<float><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -815,6 +825,29 @@ void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_
     hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
     const unsigned t = (unsigned)((n + 63) / 64);
     check_symmetric_kernel<<<dim3(t, t), 256, 0, s>>>(n, L, flag);
+}
+
+// L[i,j] = L[j,i] for i < j while *nonsym_flag == 0 (64 x 64 tiles through LDS)
+__global__ void __launch_bounds__(256)
+mirror_labels_kernel(int64_t n, uint32_t* __restrict__ L, const uint32_t* __restrict__ nonsym_flag) {
+    __shared__ uint32_t tile[64][65];
+    if (*nonsym_flag != 0u) return;
+    const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;  // source tile (lower): rows i0.., cols j0..
+    if (i0 < j0) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4) {
+        const int64_t r = i0 + tx, cc = j0 + c;
+        tile[c][tx] = (r < n && cc < n) ? L[r + cc * n] : 0u;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {  // destination: rows j0 + tx, columns i0 + c  (= L[i0+c, j0+tx])
+        const int64_t r = j0 + tx, cc = i0 + c;
+        if (r < n && cc < n && r < cc) L[r + cc * n] = tile[tx][c];
+    }
+}
+void launch_mirror_labels(hipStream_t s, int64_t n, uint32_t* L, const uint32_t* nonsym_flag) {
+    const unsigned t = (unsigned)((n + 63) / 64);
+    mirror_labels_kernel<<<dim3(t, t), 256, 0, s>>>(n, L, nonsym_flag);
 }
 
 // Lt[k + i*n] = L[i + k*n]: 64 x 64 label tiles through LDS (both sides coalesced)

@@ -384,3 +384,23 @@ def test_admissible_without_constraints_and_bad_arguments(pkg, problems, oracle,
     d = C.c_int64(0)
     assert lib.sdpsr_partition_from_f64(gpu_ctx._h, 0, None, None, C.byref(d), 0) == 5
     assert lib.sdpsr_block_diagonalize(gpu_ctx._h, 0, None, 0, 1e-8, None, None, None, None, 0) == 5
+
+
+@pytest.mark.gpu
+def test_admissible_nonsymmetric_labels_square_literally(pkg, oracle, gpu_ctx):
+    """Non-symmetric input: the random square is X*X as in src/partitions.jl:172 (the left operand
+    is gathered from the transposed labels), not the symmetric shortcut X'X of the Jordan case."""
+    rng = np.random.default_rng(5)
+    for n in (9, 16):
+        M = rng.integers(0, 3, size=(n, n))
+        assert not np.array_equal(M, M.T)
+        Cv = M.astype(np.float64).ravel(order="F")
+        A = np.zeros((0, n * n))
+        b = np.zeros(0)
+        ref = oracle.admissible_subspace(Cv, A, b, rng=np.random.default_rng(2))
+        P = pkg.admissible_subspace(Cv, A, b, ctx=gpu_ctx)
+        assert P.nparts == ref.nparts
+        assert np.array_equal(P.matrix, ref.matrix)
+        with pkg.Context(seed=3, square_mode=pkg.SQUARE_F32) as ctx32:
+            P32 = pkg.admissible_subspace(Cv, A, b, ctx=ctx32)
+            assert np.array_equal(P32.matrix, ref.matrix)
