@@ -2197,7 +2197,13 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         const size_t os = kind == 0 ? 4 : es;
         // aux = batch (channels of one launch, as the product path launches them); operands of
         // all channels are distinct memory
+        // aux >= 100: the lower-triangle launch of the product path (symmetric labels), batch aux - 100
+        const bool tri = aux >= 100 && kind <= 1;
+        if (tri) aux -= 100;
         const int bt = (int)std::min<int64_t>(std::max<int64_t>(aux, 1), 8);
+        uint32_t* zflag = (uint32_t*)ctx_buf(c, "prof_zero", 64);
+        if (!zflag) return SDPSR_OUT_OF_MEMORY;
+        HIP_TRY(c, hipMemsetAsync(zflag, 0, 64, s));
         void* X = ctx_buf(c, "prof_x", (size_t)ld * ld * es * bt);
         void* Cc = ctx_buf(c, "prof_c", (size_t)ld * ld * os * bt);
         uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)ld * ld * 4);
@@ -2212,7 +2218,9 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         }
         const int64_t sb = ld * ld;
         auto run = [&]() {
-            if (kind == 0) launch_gemm_tn_i8(s, ld, ld, ld, (int8_t*)X, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, bt, sb, sb, sb);
+            if (tri && kind == 0) launch_gemm_tn_i8_sym(s, ld, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, bt, sb, sb, zflag);
+            else if (tri && kind == 1) launch_gemm_tn_f32_sym(s, ld, ld, (float*)X, ld, (float*)Cc, ld, bt, sb, sb, zflag);
+            else if (kind == 0) launch_gemm_tn_i8(s, ld, ld, ld, (int8_t*)X, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, bt, sb, sb, sb);
             else if (kind == 1) launch_gemm_tn_f32(s, ld, ld, ld, (float*)X, ld, (float*)X, ld, (float*)Cc, ld, bt, sb, sb, sb);
             else launch_gemm_tn_f64(s, ld, ld, ld, (double*)X, ld, (double*)X, ld, (double*)Cc, ld, bt, sb, sb, sb);
         };
