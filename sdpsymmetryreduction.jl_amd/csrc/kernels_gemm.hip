@@ -16,6 +16,7 @@
 // cut the same way, so each MFMA multiplies matching k indices; the order in which k is
 // consumed differs from the natural one, which only permutes an exact sum (integers) or
 // the fp rounding order (f32/f64).
+#include <cstdlib>
 #include "sdpsr_internal.h"
 
 namespace sdpsr {
@@ -449,6 +450,143 @@ gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// 256 x 256 C tile, 8 waves (2 x 4, a wave owns 128 x 64), int8 and f32 only.  Same LDS-DMA
+// staging and swizzle as gemm_tn_dma_kernel; the point of the larger tile is the LDS pipe: with
+// 128 x 128 / 4 waves every K-tile costs as many LDS-read cycles (64 KiB at 128 B/clk) as MFMA
+// cycles (one wave per SIMD, 16 MFMAs), so the kernel sat at ~30 % of the int8 peak.  Here a K-tile
+// is 192 KiB of fragment reads (1536 clk) against 2 waves x 32 MFMAs per SIMD (2048 clk), and
+// the L2 -> LDS traffic per MFMA halves.  Two 64 KiB buffers, one workgroup per CU.
+// ---------------------------------------------------------------------------
+constexpr int BM2 = 256, NT2 = 512;
+
+template <int KIND>
+__global__ void __launch_bounds__(NT2)
+gemm_tn_dma256_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag, int64_t lda,
+                      const typename GemmTraits<KIND>::in_t* __restrict__ Bg, int64_t ldb,
+                      typename GemmTraits<KIND>::out_t* __restrict__ Cg, int64_t ldc, int64_t strideA, int64_t strideB,
+                      int64_t strideC, const uint32_t* __restrict__ nonsym_flag) {
+    static_assert(KIND == KIND_I8 || KIND == KIND_F32, "int8 / f32 only");
+    typedef typename GemmTraits<KIND>::in_t in_t;
+    typedef typename GemmTraits<KIND>::out_t out_t;
+    constexpr int ES = sizeof(in_t);
+    constexpr int KB = 128;            // bytes of K per row per tile
+    constexpr int KE = KB / ES;
+    constexpr int OPB = BM2 * KB;      // 32 KiB per operand tile
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = wave >> 1;
+    int bi = blockIdx.x, bj = blockIdx.y;
+    if (nonsym_flag && *nonsym_flag == 0u) {  // lower-triangle tiles only (see gemm_tn_dma_kernel)
+        const int t = blockIdx.y * gridDim.x + blockIdx.x;
+        const int gm = gridDim.x;
+        if (t >= gm * (gm + 1) / 2) return;
+        int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (row * (row + 1) / 2 > t) --row;
+        while ((row + 1) * (row + 2) / 2 <= t) ++row;
+        bi = row;
+        bj = t - row * (row + 1) / 2;
+    }
+    const int64_t i0 = (int64_t)bi * BM2;
+    const int64_t j0 = (int64_t)bj * BM2;
+    const char* Ab = reinterpret_cast<const char*>(Ag + (int64_t)blockIdx.z * strideA + i0 * lda);
+    const char* Bb = reinterpret_cast<const char*>(Bg + (int64_t)blockIdx.z * strideB + j0 * ldb);
+    out_t* C = Cg + (int64_t)blockIdx.z * strideC;
+
+    // an operand tile is 32 DMA instructions of 1 KiB (8 rows x 128 B); this wave issues 4 of them
+    int64_t srcA[4], srcB[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int r = 8 * (wave * 4 + s) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        srcA[s] = (int64_t)r * lda * ES + c * 16;
+        srcB[s] = (int64_t)r * ldb * ES + c * 16;
+    }
+    auto issue = [&](int buf, int64_t kt) {
+        const int64_t kb = kt * KB;
+        char* base = smem + buf * 2 * OPB + (wave * 4) * 1024;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + srcA[s] + kb), (lds_void_t*)(base + s * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + srcB[s] + kb), (lds_void_t*)(base + OPB + s * 1024), 16, 0, 0);
+        }
+    };
+    const int64_t nk = k / KE;
+    typedef typename std::conditional<KIND == KIND_I8, v16i, v16f>::type acc_t;
+    acc_t acc[2][4];  // [tj: 32-col tiles of B side][ti: 32-row tiles of A side]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+    const int r32 = lane & 31, h = lane >> 5;
+    int rowA[4], rowB[2], swA[4], swB[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        rowA[t] = wi * 128 + t * 32 + r32;
+        swA[t] = (rowA[t] >> 1) & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowB[t] = wj * 64 + t * 32 + r32;
+        swB[t] = (rowB[t] >> 1) & 7;
+    }
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int buf = (int)(kt & 1);
+        if (kt + 1 < nk) issue(buf ^ 1, kt + 1);
+        const char* tA = smem + buf * 2 * OPB;
+        const char* tB = tA + OPB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 fi[4], fj[2];
+            const int ch = 2 * q + h;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fi[t] = *reinterpret_cast<const uint4*>(tA + rowA[t] * KB + ((ch ^ swA[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fj[t] = *reinterpret_cast<const uint4*>(tB + rowB[t] * KB + ((ch ^ swB[t]) << 4));
+            if constexpr (KIND == KIND_I8) {
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti) {
+                        v4i a = {(int)fj[tj].x, (int)fj[tj].y, (int)fj[tj].z, (int)fj[tj].w};
+                        v4i b = {(int)fi[ti].x, (int)fi[ti].y, (int)fi[ti].z, (int)fi[ti].w};
+                        acc[tj][ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[tj][ti], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                        for (int ti = 0; ti < 4; ++ti)
+                            acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(reinterpret_cast<const float*>(&fj[tj])[e],
+                                                                               reinterpret_cast<const float*>(&fi[ti])[e],
+                                                                               acc[tj][ti], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const int64_t ii = i0 + wi * 128 + ti * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t jj = j0 + wj * 64 + tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                C[ii + jj * ldc] = acc[tj][ti][r];
+            }
+        }
+}
+
 template <int KIND>
 static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
                         const typename GemmTraits<KIND>::in_t* A, int64_t lda,
@@ -462,6 +600,25 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
     if ((k * ESZ) % 128 == 0 && ((lda * ESZ) % 16) == 0 && ((ldb * ESZ) % 16) == 0 &&
         ((strideA * ESZ) % 16) == 0 && ((strideB * ESZ) % 16) == 0 &&
         (reinterpret_cast<uintptr_t>(A) % 16) == 0 && (reinterpret_cast<uintptr_t>(B) % 16) == 0) {
+        if constexpr (KIND == KIND_I8 || KIND == KIND_F32) {
+            static const bool only128 = getenv("SDPSR_GEMM128") != nullptr;  // A/B switch for measurements
+            // 256 x 256 tiles pay off (6-15 % measured) once the launch has >= 4 workgroups per CU
+            // (one resident workgroup per CU: fewer leave a ragged last round)
+            const int64_t t2 = m / BM2;
+            const int64_t wgs = (nonsym_flag ? t2 * (t2 + 1) / 2 : t2 * (n / BM2)) * batch;
+            if (!only128 && m % BM2 == 0 && n % BM2 == 0 && wgs >= 1024) {
+                constexpr size_t lds256 = 2 * 2 * BM2 * 128;  // 128 KiB
+                static bool attr256 = false;
+                if (!attr256) {
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma256_kernel<KIND>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                    attr256 = true;
+                }
+                dim3 grid2((unsigned)(m / BM2), (unsigned)(n / BM2), (unsigned)batch);
+                gemm_tn_dma256_kernel<KIND><<<grid2, NT2, lds256, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
+                return;
+            }
+        }
         constexpr size_t lds_dma = 2 * 2 * BM * 128;  // 64 KiB
         static bool dma_attr_set = false;
         if (!dma_attr_set) {
