@@ -121,6 +121,12 @@ int sdpsr_partition_from_u32(sdpsr_ctx* ctx, int64_t len, const uint32_t* in,
    (p1, p2); label 0 only where both are 0.  *d1 is updated. */
 int sdpsr_refine(sdpsr_ctx* ctx, int64_t len, uint32_t* p1, int64_t* d1,
                  const uint32_t* p2, int64_t d2, int mem);
+/* Base.:(==)(p::Partition, q::Partition), src/partitions.jl:16-17 (same matrix), as a 128-bit
+   position-weighted checksum of the canonical label matrix: equal partitions have equal
+   checksums, different ones collide with probability ~2^-64 per word.  Used to agree the result
+   of independent restarts across GPUs without moving the n x n labels.
+   out[0..1] is host memory; `mem` says where `labels` lives. */
+int sdpsr_partition_checksum(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, uint64_t* out, int mem);
 /* fill!(M, P; values), src/partitions.jl:68-75: M[idx] = values[label-1], 0 -> 0.0.
    `values` has d entries. */
 int sdpsr_fill(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, const double* values,

@@ -67,6 +67,7 @@ def load_library():
         "sdpsr_partition_from_f64": (C.c_int, [vp, i64, vp, vp, pi64, C.c_int]),
         "sdpsr_partition_from_u32": (C.c_int, [vp, i64, vp, vp, pi64, C.c_int]),
         "sdpsr_refine": (C.c_int, [vp, i64, vp, pi64, vp, i64, C.c_int]),
+        "sdpsr_partition_checksum": (C.c_int, [vp, i64, vp, vp, C.c_int]),
         "sdpsr_fill": (C.c_int, [vp, i64, vp, vp, i64, vp, C.c_int]),
         "sdpsr_randomize": (C.c_int, [vp, i64, vp, vp, C.c_int]),
         "sdpsr_clamp_round": (C.c_int, [vp, i64, vp, dbl, C.c_int]),

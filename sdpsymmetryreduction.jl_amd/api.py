@@ -193,6 +193,23 @@ def refine(P1, P2, ctx=None):
     return P1
 
 
+def partition_checksum(P, ctx=None):
+    """128-bit checksum of the canonical label matrix: a probabilistic ``==`` of two partitions
+    (src/partitions.jl:16-17) that avoids moving n^2 labels between GPUs.
+    ``P`` is a Partition or a flat torch/NumPy array of column-major labels."""
+    ctx = _ctx(ctx)
+    if isinstance(P, Partition):
+        lab, mem = _labels_arg(P)
+    elif _is_torch(P):
+        lab, mem = P.contiguous().view(-1), (L.MEM_DEVICE if P.is_cuda else L.MEM_HOST)
+    else:
+        lab, mem = np.ascontiguousarray(P, dtype=np.uint32).ravel(), L.MEM_HOST
+    n_entries = lab.numel() if _is_torch(lab) else lab.size
+    out = (C.c_uint64 * 2)()
+    ctx.check(ctx._lib.sdpsr_partition_checksum(ctx._h, n_entries, _ptr(lab), C.cast(out, C.c_void_p), mem))
+    return int(out[0]), int(out[1])
+
+
 def fill(P, values, ctx=None):
     """``fill!(M, P; values)`` (src/partitions.jl:68-75)."""
     ctx = _ctx(ctx)

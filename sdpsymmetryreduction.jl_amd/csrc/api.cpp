@@ -449,6 +449,19 @@ int sdpsr_refine(sdpsr_ctx* c, int64_t len, uint32_t* p1, int64_t* d1, const uin
     return out_finish(c, p1, dL, len, mem);
 }
 
+int sdpsr_partition_checksum(sdpsr_ctx* c, int64_t len, const uint32_t* labels, uint64_t* out, int mem) {
+    CHECK_CTX(c);
+    if (!labels || !out) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    int st = check_len(c, len);
+    if (st) return st;
+    const uint32_t* dL = in_dev(c, "chk_labels", labels, (size_t)len, mem, &st);
+    uint64_t* scratch = (uint64_t*)ctx_buf(c, "chk_scratch", (size_t)(2 * 2048 + 2) * 8);
+    if (st || !scratch) return st ? st : SDPSR_OUT_OF_MEMORY;
+    launch_labels_checksum(c->stream, len, dL, scratch, scratch + 2 * 2048);
+    HIP_TRY(c, hipGetLastError());
+    return d2h_sync(c, out, scratch + 2 * 2048, 16);
+}
+
 int sdpsr_fill(sdpsr_ctx* c, int64_t len, const uint32_t* labels, const double* values, int64_t d,
                double* M, int mem) {
     CHECK_CTX(c);

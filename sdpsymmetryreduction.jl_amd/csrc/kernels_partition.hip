@@ -800,6 +800,57 @@ void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* la
 }
 
 // ---------------------------------------------------------------------------
+// checksum of a label array: two position-weighted sums mod 2^64 (order of summation irrelevant)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+labels_checksum_kernel(int64_t len, const uint32_t* __restrict__ L, unsigned long long* __restrict__ partial) {
+    __shared__ unsigned long long sh[2][4];
+    unsigned long long h1 = 0, h2 = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const unsigned long long l = (unsigned long long)L[e] + 1ull;
+        const unsigned long long ee = (unsigned long long)e;
+        h1 += l * (ee * 0x9E3779B97F4A7C15ull + 0xD1342543DE82EF95ull);
+        h2 += (l * l + 0x27D4EB2F165667C5ull) * ((ee ^ (ee >> 13)) * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        h1 += __shfl_down(h1, o, 64);
+        h2 += __shfl_down(h2, o, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][w] = h1;
+        sh[1][w] = h2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        partial[gridDim.x + blockIdx.x] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+__global__ void __launch_bounds__(256)
+labels_checksum_final_kernel(int nblk, const unsigned long long* __restrict__ partial, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long sh[4];
+    for (int which = 0; which < 2; ++which) {
+        unsigned long long h = 0;
+        for (int b = threadIdx.x; b < nblk; b += 256) h += partial[which * nblk + b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = h;
+        __syncthreads();
+        if (threadIdx.x == 0) out[which] = sh[0] + sh[1] + sh[2] + sh[3];
+        __syncthreads();
+    }
+}
+// partial: 2 * 2048 words of scratch, out: 2 words (device)
+void launch_labels_checksum(hipStream_t s, int64_t len, const uint32_t* L, uint64_t* partial, uint64_t* out) {
+    const int nblk = grid_for(len, 256);
+    labels_checksum_kernel<<<nblk, 256, 0, s>>>(len, L, (unsigned long long*)partial);
+    labels_checksum_final_kernel<<<1, 256, 0, s>>>(nblk, (const unsigned long long*)partial, (unsigned long long*)out);
+}
+
+// ---------------------------------------------------------------------------
 // symmetric label check
 // ---------------------------------------------------------------------------
 // 64 x 64 tiles through LDS: both the tile and its mirror image are read along columns

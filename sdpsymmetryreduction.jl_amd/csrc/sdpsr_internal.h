@@ -126,6 +126,7 @@ void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* la
                    const RefineWs& ws);
 
 void launch_transpose_labels(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* Lt);
+void launch_labels_checksum(hipStream_t s, int64_t len, const uint32_t* L, uint64_t* partial, uint64_t* out);
 int64_t reduce_columns_chunk(int64_t len, int64_t m, int64_t d);
 bool launch_reduce_columns(hipStream_t s, int64_t len, int64_t m, int64_t d, const uint32_t* L, const double* A,
                            double* partial, double* out);

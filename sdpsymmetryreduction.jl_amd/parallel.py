@@ -2,10 +2,12 @@
 
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm, "gloo" in the CPU
 tests).  Every rank runs the reduction with its own seed; the canonical label matrices are
-equal with probability 1, which one MIN and one MAX all-reduce over the uint32 labels verify
-(64 MiB at N=4096, 256 MiB at N=8192: link-bound at a few ms over xGMI).  If they differ (a
-split missed by one rank's draws), the meet of the partitions is taken: a universal hash
-``sum_r a_r * label_r mod 2^64`` is summed with one more all-reduce and canonically relabelled.
+equal with probability 1.  The ranks first compare a 128-bit checksum of their label matrix
+(``sdpsr_partition_checksum`` on the device, two int64 words all-gathered): a reduction takes
+~2.5 ms at N=4096, two all-reduces over the 64 MiB labels would cost about as much over xGMI.
+Only if the checksums differ (a split missed by one rank's draws) the labels themselves travel:
+MIN/MAX all-reduce to confirm, then the meet of the partitions -- a universal hash
+``sum_r a_r * label_r mod 2^64`` summed with one more all-reduce and canonically relabelled.
 """
 from __future__ import annotations
 
@@ -24,13 +26,42 @@ def _signed(x):
     return x - 2 ** 64 if x >= 2 ** 63 else x
 
 
-def agree_partition(labels, relabel, group=None):
+def torch_checksum(labels):
+    """Position-weighted checksum with plain torch ops (wraps mod 2^64): the stand-in for
+    ``sdpsr_partition_checksum`` where the HIP library is not loaded (CPU gloo tests)."""
+    import torch
+    idx = torch.arange(labels.numel(), dtype=torch.int64, device=labels.device)
+    l = labels.reshape(-1).to(torch.int64) + 1
+    # same formula and constants as labels_checksum_kernel (csrc/kernels_partition.hip)
+    h1 = (l * (idx * _signed(0x9E3779B97F4A7C15) + _signed(0xD1342543DE82EF95))).sum()
+    h2 = ((l * l + _signed(0x27D4EB2F165667C5)) *
+          ((idx ^ (idx >> 13)) * _signed(0xBF58476D1CE4E5B9) + _signed(0x94D049BB133111EB))).sum()
+    return int(h1.item()), int(h2.item())
+
+
+def checksums_agree(words, group=None, device=None):
+    """All-gather two 64-bit words per rank; True iff every rank holds the same pair."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([_signed(words[0]), _signed(words[1])], dtype=torch.int64, device=device)
+    world = dist.get_world_size(group)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
+    return all(bool((g == got[0]).all()) for g in got)
+
+
+def agree_partition(labels, relabel, group=None, checksum=None):
     """labels: flat torch integer tensor (column-major label matrix of this rank).
     relabel(sig_int64_tensor) -> (labels_tensor, nparts): canonical relabel of arbitrary 64-bit
     keys (0 stays 0) -- on the GPU this is the refine kernel.
+    checksum(labels) -> (word0, word1): defaults to ``torch_checksum``; on the GPU pass
+    ``lambda t: pkg.partition_checksum(t, ctx)``.
     Returns (agreed_without_meet, labels)."""
     import torch
     import torch.distributed as dist
+    words = (checksum or torch_checksum)(labels)
+    if checksums_agree(words, group=group, device=labels.device):
+        return True, labels
     lo = labels.clone()
     hi = labels.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)

@@ -404,3 +404,28 @@ def test_admissible_nonsymmetric_labels_square_literally(pkg, oracle, gpu_ctx):
         with pkg.Context(seed=3, square_mode=pkg.SQUARE_F32) as ctx32:
             P32 = pkg.admissible_subspace(Cv, A, b, ctx=ctx32)
             assert np.array_equal(P32.matrix, ref.matrix)
+
+
+@pytest.mark.gpu
+def test_partition_checksum_matches_restatement(pkg, gpu_ctx):
+    """sdpsr_partition_checksum (the probabilistic == of src/partitions.jl:16-17 used to agree
+    restarts across GPUs) against its formula in NumPy and against the torch stand-in."""
+    import torch
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 300):
+        lab = rng.integers(0, 50, size=n * n).astype(np.uint32)
+        e = np.arange(n * n, dtype=np.uint64)
+        l = lab.astype(np.uint64) + np.uint64(1)
+        with np.errstate(over="ignore"):
+            h1 = int((l * (e * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xD1342543DE82EF95))).sum(dtype=np.uint64))
+            h2 = int(((l * l + np.uint64(0x27D4EB2F165667C5)) *
+                      ((e ^ (e >> np.uint64(13))) * np.uint64(0xBF58476D1CE4E5B9) + np.uint64(0x94D049BB133111EB))).sum(dtype=np.uint64))
+        got = pkg.partition_checksum(lab, ctx=gpu_ctx)
+        assert got == (h1, h2)
+        dev = pkg.partition_checksum(torch.from_numpy(lab.astype(np.int32)).cuda(), ctx=gpu_ctx)
+        assert dev == (h1, h2)
+        tw = pkg.parallel.torch_checksum(torch.from_numpy(lab.astype(np.int64)))
+        assert (tw[0] % 2**64, tw[1] % 2**64) == (h1, h2)
+        lab2 = lab.copy()
+        lab2[n * n // 2] += 1
+        assert pkg.partition_checksum(lab2, ctx=gpu_ctx) != (h1, h2)
