@@ -89,6 +89,16 @@ function Base.fill!(M::AbstractMatrix{Float64}, p::HIPPartition; values::Abstrac
 end
 SR._constraints(p::HIPPartition) = SR._constraints(SR.Partition{UInt32}(p.nparts, p.matrix))
 
+# 128-bit checksum of the canonical labels: a probabilistic `==` (partitions.jl:16-17) that lets
+# independent restarts on several GPUs agree without exchanging the n x n label matrices
+function checksum(p::HIPPartition)
+    out = zeros(UInt64, 2); c = ctx()
+    check(c, ccall((:sdpsr_partition_checksum, libsdpsr), Cint,
+                   (Ptr{Cvoid}, Int64, Ptr{UInt32}, Ptr{UInt64}, Cint),
+                   c.handle, length(p.matrix), p.matrix, out, MEM_HOST))
+    return (out[1], out[2])
+end
+
 # ---- admissible_subspace: setup on the host (partitions.jl:117-142), loop on the device ----
 function SR.admissible_subspace(::Type{HIPPartition}, C::AbstractVector{T}, A::AbstractMatrix{T},
                                 b::AbstractVector{T}; verbose::Bool=false,
