@@ -2064,7 +2064,12 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     if (st || !L || !Qhat || !Qrm) return st ? st : SDPSR_OUT_OF_MEMORY;
     launch_transpose_to_rowmajor(s, n, S1, Qhat, Qrm);
     const double atol = 1e-12 * (double)n;  // basis_image default atol (src/diagonalize.jl:67)
-    if (basis_image_two_stage_fits(n, d, S1)) {
+    // SDPSR_BASIS_IMAGE = two_stage | outer | chunk forces one of the three kernels (tests: the
+    // automatic choice reaches `outer` / `chunk` only for shapes far beyond the test sizes)
+    const char* force = getenv("SDPSR_BASIS_IMAGE");
+    const bool f_two = force && !strcmp(force, "two_stage"), f_outer = force && !strcmp(force, "outer"),
+               f_chunk = force && !strcmp(force, "chunk");
+    if (basis_image_two_stage_fits(n, d, S1) && !f_outer && !f_chunk) {
         // two-stage form (class sums per row, then the s_k x s_k dots): descriptor = the two
         // columns of Q_hat every output multiplies, blocks side by side, column-major inside
         std::vector<int32_t> hdesc(2 * (size_t)S);
@@ -2092,6 +2097,39 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     int64_t* class_ptr = nullptr;  // host, size d+2: class_ptr[l]..class_ptr[l+1] = label l
     st = sort_entries_by_label(c, len, d, L, &ent, &class_ptr);
     if (st) return st;
+    int max_s = 0;
+    for (int32_t sz : c->bd_sizes) max_s = std::max(max_s, (int)sz);
+    // many small classes (average class below 4096 entries) and blocks up to 256: outer-product
+    // kernel, one workgroup per (class, block), every output written once, no partial sums
+    (void)f_two;
+    if (max_s <= 256 && d > 0 && (len / d < 4096 || f_outer) && !f_chunk && d <= 0x7FFFFFFF && c->bd_sizes.size() <= 65535) {
+        const int nb = (int)c->bd_sizes.size();
+        std::vector<int32_t> hcol(nb), hsz(nb);
+        std::vector<int64_t> hoff(nb);
+        int64_t colbase = 0, off = 0;
+        for (int k2 = 0; k2 < nb; ++k2) {
+            hcol[k2] = (int32_t)colbase;
+            hsz[k2] = c->bd_sizes[k2];
+            hoff[k2] = off;
+            colbase += hsz[k2];
+            off += (int64_t)hsz[k2] * hsz[k2];
+        }
+        int32_t* d_col = (int32_t*)ctx_buf(c, "bi_col", (size_t)nb * 4);
+        int32_t* d_sz = (int32_t*)ctx_buf(c, "bi_sz", (size_t)nb * 4);
+        int64_t* d_off = (int64_t*)ctx_buf(c, "bi_off", (size_t)nb * 8);
+        int64_t* d_cls = (int64_t*)ctx_buf(c, "bi_cls_ptr", (size_t)(d + 2) * 8);
+        if (!d_col || !d_sz || !d_off || !d_cls) {
+            free(class_ptr);
+            return SDPSR_OUT_OF_MEMORY;
+        }
+        st = h2d_sync(c, d_col, hcol.data(), (size_t)nb * 4);
+        if (!st) st = h2d_sync(c, d_sz, hsz.data(), (size_t)nb * 4);
+        if (!st) st = h2d_sync(c, d_off, hoff.data(), (size_t)nb * 8);
+        if (!st) st = h2d_sync(c, d_cls, class_ptr, (size_t)(d + 2) * 8);
+        free(class_ptr);
+        if (st) return st;
+        launch_basis_image_outer(s, n, d, S1, S, nb, max_s, Qrm, ent, d_cls, d_col, d_sz, d_off, atol, out);
+    } else {
     // chunks + output descriptors
     const int64_t CH = 4096;
     std::vector<int64_t> chunk_ptr(d + 1, 0), cb, ce;
@@ -2136,6 +2174,7 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     }
     launch_basis_image(s, n, d, S1, S, Qrm, ent, nullptr, d_dA, d_dB, d_chunk_ptr, nch, nullptr, d_cb, d_ce,
                        partial, out, atol);
+    }
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(s));  // host vectors above must outlive the copies

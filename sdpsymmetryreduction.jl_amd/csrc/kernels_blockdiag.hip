@@ -244,6 +244,78 @@ void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t
 }
 
 // ---------------------------------------------------------------------------
+// basis_image for MANY SMALL classes (d ~ n^2 / few dozen, e.g. QAP relaxations): one workgroup
+// per (class i, block k) accumulates the rank-1 terms Q_k[r,:]' Q_k[c,:] of the class's entries
+// as outer products: the two row segments of a batch of entries are staged in LDS, a thread owns
+// one row index a of the s_k x s_k output and every G-th column b (accumulators in registers), so
+// there is one LDS read per FMA, no partial sums and every output is written exactly once.
+// ---------------------------------------------------------------------------
+constexpr int BO_THREADS = 256;
+constexpr int BO_EB = 8;       // entries staged per batch
+constexpr int BO_MAXACC = 32;  // accumulators per thread and pass
+
+__global__ void __launch_bounds__(BO_THREADS)
+basis_image_outer_kernel(int64_t n, int64_t S1, int64_t S, const double* __restrict__ Qrm,
+                         const uint32_t* __restrict__ ent, const int64_t* __restrict__ cls_ptr,
+                         const int32_t* __restrict__ blk_col, const int32_t* __restrict__ blk_size,
+                         const int64_t* __restrict__ blk_off, double atol, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double bo_smem[];  // qr[EB][s], qc[EB][s]
+    const int i = blockIdx.x, k = blockIdx.y;
+    const int s = blk_size[k], cb = blk_col[k];
+    const int64_t p_begin = cls_ptr[i + 1], p_end = cls_ptr[i + 2];  // label i + 1
+    double* qr = bo_smem;
+    double* qc = bo_smem + BO_EB * s;
+    const int G = BO_THREADS / s;  // >= 1 (s <= 256)
+    const int tid = threadIdx.x;
+    const bool active = tid < G * s;
+    const int a = active ? tid % s : 0, g = active ? tid / s : 0;
+    double* o = out + (int64_t)i * S + blk_off[k];
+    for (int b0 = 0; b0 < s; b0 += G * BO_MAXACC) {  // passes over the columns b (one pass if s <= G * 32)
+        double acc[BO_MAXACC];
+#pragma unroll
+        for (int j = 0; j < BO_MAXACC; ++j) acc[j] = 0.0;
+        for (int64_t p0 = p_begin; p0 < p_end; p0 += BO_EB) {
+            const int ne = (int)((p_end - p0 < BO_EB) ? (p_end - p0) : BO_EB);
+            __syncthreads();
+            for (int t = tid; t < ne * s; t += BO_THREADS) {
+                const int e = t / s, j = t - e * s;
+                const uint32_t lin = ent[p0 + e];
+                const int64_t c = lin / n, r = lin - c * n;
+                qr[e * s + j] = Qrm[r * S1 + cb + j];
+                qc[e * s + j] = Qrm[c * S1 + cb + j];
+            }
+            __syncthreads();
+            if (active)
+                for (int e = 0; e < ne; ++e) {
+                    const double x = qr[e * s + a];
+                    const double* qce = qc + e * s + b0 + g;
+#pragma unroll
+                    for (int j = 0; j < BO_MAXACC; ++j)
+                        if (b0 + g + j * G < s) acc[j] = fma(x, qce[j * G], acc[j]);
+                }
+        }
+        if (active)
+#pragma unroll
+            for (int j = 0; j < BO_MAXACC; ++j) {
+                const int b = b0 + g + j * G;
+                if (b < s) {
+                    const double v = acc[j];
+                    o[a + (int64_t)b * s] = (fabs(v) < atol) ? 0.0 : v;
+                }
+            }
+    }
+}
+
+void launch_basis_image_outer(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks, int max_s,
+                              const double* Qrm, const uint32_t* ent, const int64_t* cls_ptr,
+                              const int32_t* blk_col, const int32_t* blk_size, const int64_t* blk_off, double atol,
+                              double* out) {
+    const size_t lds = (size_t)2 * BO_EB * max_s * sizeof(double);
+    dim3 g((unsigned)d, (unsigned)nblocks);
+    basis_image_outer_kernel<<<g, BO_THREADS, lds, s>>>(n, S1, S, Qrm, ent, cls_ptr, blk_col, blk_size, blk_off, atol, out);
+}
+
+// ---------------------------------------------------------------------------
 // basis_image, two-stage form for symmetric partitions (the only ones diagonalize accepts):
 //   stage 1   T[i][r][:] = sum over c with L[c,r] == i of Qhat[c,:]      ( = (1[P==i] Qhat)[r,:] )
 //             one wave per row r: the wave walks column r of L (contiguous), lanes own the S1

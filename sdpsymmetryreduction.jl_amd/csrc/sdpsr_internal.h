@@ -196,6 +196,10 @@ void launch_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t
                         const int64_t* chunk_begin, const int64_t* chunk_end, double* partial,
                         double* out, double atol);
 bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1);
+void launch_basis_image_outer(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks, int max_s,
+                              const double* Qrm, const uint32_t* ent, const int64_t* cls_ptr,
+                              const int32_t* blk_col, const int32_t* blk_size, const int64_t* blk_off, double atol,
+                              double* out);
 // out[r + i*n] = sum over c with L[c + r*n] == i+1 of x[c]   (class sums of a vector, i < d)
 void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out);
 void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S,

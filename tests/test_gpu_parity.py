@@ -429,3 +429,24 @@ def test_partition_checksum_matches_restatement(pkg, gpu_ctx):
         lab2 = lab.copy()
         lab2[n * n // 2] += 1
         assert pkg.partition_checksum(lab2, ctx=gpu_ctx) != (h1, h2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["two_stage", "outer", "chunk"])
+@pytest.mark.parametrize("name", ["er7", "esc16j", "numerical_issues"])
+def test_basis_image_kernel_variants(pkg, oracle, golden, name, variant, monkeypatch):
+    """The three basis_image kernels (class sums + contraction; outer products per class for many
+    small classes; sorted chunks with partial sums) against Q_k' 1[P==i] Q_k (src/diagonalize.jl:64-89).
+    The automatic choice only reaches the last two for shapes far beyond these sizes."""
+    monkeypatch.setenv("SDPSR_BASIS_IMAGE", variant)
+    L = golden[f"{name}_P"]
+    P = pkg.Partition(int(L.max()), L.copy())
+    kw = {"epsilon": 1e-7} if name == "numerical_issues" else {}
+    with pkg.Context(seed=4) as ctx:
+        bd = pkg.blockDiagonalize(P, ctx=ctx, **kw)
+    assert sorted(bd.blkSizes) == list(golden[f"{name}_blk"])
+    Po = oracle.Partition(P.nparts, L.astype(np.int64))
+    ref = oracle.basis_image([np.asarray(q) for q in bd.Q_hat], Po)
+    for i in range(P.nparts):
+        for k in range(len(bd.blkSizes)):
+            assert np.allclose(bd.blks[i][k], ref[i][k], atol=1e-10), (variant, i, k)
