@@ -1592,12 +1592,10 @@ int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen*
                                           hipMemcpyDeviceToDevice, s));
         launch_gemm_tn_f64(s, ld, nfp, ld, A3, ld, F, ld, Bf, ld, 1, 0, 0, 0);  // B = A3' F = A3 F
     }
-    double* wv = (double*)ctx_buf(c, "bd_wv", (size_t)n * 8);
-    double* cv = (double*)ctx_buf(c, "bd_cv", (size_t)n * 8);
-    double* inv = (double*)ctx_buf(c, "bd_inv", 64);
-    if (!wv || !cv || !inv) return SDPSR_OUT_OF_MEMORY;
     int64_t col = 0;
     std::vector<int32_t> cp_src, cp_dst;  // first members, copied in one launch after the loop
+    std::vector<int32_t> pairs;           // the other members: one workgroup each, one launch
+    int64_t max_m2 = 0;
     for (size_t p = 0; p < roots.size(); ++p) {
         const int i = roots[p];
         const int64_t mi = info.ptrs[i + 1] - info.ptrs[i];
@@ -1608,14 +1606,35 @@ int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen*
         for (size_t q = 1; q < members[p].size(); ++q) {
             const int j = members[p][q];
             const int64_t mj = info.ptrs[j + 1] - info.ptrs[j];
-            // first column of P_blk = block(A,Ei,Ej)' is Qj' (A q_i1)             (:333)
-            launch_gemv_t(s, n, ld, Q, info.ptrs[j], mj, Bf + (size_t)fcol[i] * ld, wv);
-            // norm(P_blk[1,:]) = || Qi' (A q_j1) ||                              (:335)
-            launch_gemv_t(s, n, ld, Q, info.ptrs[i], mi, Bf + (size_t)fcol[j] * ld, cv);
-            launch_inv_norm(s, mi, cv, inv);
-            // column of P_hat = Qj * first column of the normalised block       (:338-344)
-            launch_gemv_n_scaled(s, n, ld, Q, info.ptrs[j], mj, wv, inv, Qhat + (size_t)col * n);
+            // first column of P_blk = block(A,Ei,Ej)' is Qj' (A q_i1)  (:333); its norm is
+            // || Qi' (A q_j1) ||  (:335); column of P_hat = Qj * that column, normalised (:338-344)
+            const int32_t dsc[7] = {(int32_t)info.ptrs[i], (int32_t)mi, (int32_t)info.ptrs[j], (int32_t)mj,
+                                    (int32_t)fcol[i], (int32_t)fcol[j], (int32_t)col};
+            pairs.insert(pairs.end(), dsc, dsc + 7);
+            max_m2 = std::max(max_m2, mi + mj);
             ++col;
+        }
+    }
+    if (!pairs.empty()) {
+        int32_t* d_pairs = (int32_t*)ctx_buf(c, "bd_pairs", pairs.size() * 4);
+        if (!d_pairs) return SDPSR_OUT_OF_MEMORY;
+        st = h2d_sync(c, d_pairs, pairs.data(), pairs.size() * 4);
+        if (st) return st;
+        if ((size_t)(max_m2 + 2) * 8 <= 60 * 1024) {
+            launch_irreducible_pairs(s, n, ld, Q, Bf, (int)(pairs.size() / 7), (int)max_m2, d_pairs, Qhat);
+        } else {
+            // eigenspaces too large for the LDS of the pair kernel: four small launches per pair
+            double* wv = (double*)ctx_buf(c, "bd_wv", (size_t)n * 8);
+            double* cv = (double*)ctx_buf(c, "bd_cv", (size_t)n * 8);
+            double* inv = (double*)ctx_buf(c, "bd_inv", 64);
+            if (!wv || !cv || !inv) return SDPSR_OUT_OF_MEMORY;
+            for (size_t q = 0; q + 7 <= pairs.size(); q += 7) {
+                const int32_t* dsc = pairs.data() + q;
+                launch_gemv_t(s, n, ld, Q, dsc[2], dsc[3], Bf + (size_t)dsc[4] * ld, wv);
+                launch_gemv_t(s, n, ld, Q, dsc[0], dsc[1], Bf + (size_t)dsc[5] * ld, cv);
+                launch_inv_norm(s, dsc[1], cv, inv);
+                launch_gemv_n_scaled(s, n, ld, Q, dsc[2], dsc[3], wv, inv, Qhat + (size_t)dsc[6] * n);
+            }
         }
     }
     launch_copy_cols(s, n, (int64_t)cp_src.size(), cp_src.data(), cp_dst.data(), Q, ld, Qhat, n);

@@ -73,6 +73,56 @@ void launch_gemv_t(hipStream_t s, int64_t n, int64_t ld, const double* Q, int64_
     gemv_t_kernel<<<grid_for(m * 64, 256), 256, 0, s>>>(n, ld, Q, col0, m, a, out);
 }
 
+// irreducible_decomposition, all (class, member) pairs in ONE launch
+// (src/eigen_decomposition.jl:326-344).  Pair descriptor: 7 ints
+//   {first column of E_i, dim E_i, first column of E_j, dim E_j, column of B for i, column of B for j, output column}.
+// One workgroup per pair:  w = Q_j' b_i,  c = Q_i' b_j,  column = Q_j w / ||c||   (b_x = A q_x1).
+__global__ void __launch_bounds__(256)
+irreducible_pairs_kernel(int64_t n, int64_t ld, const double* __restrict__ Q, const double* __restrict__ Bf,
+                         const int32_t* __restrict__ desc, double* __restrict__ Qhat) {
+    extern __shared__ __attribute__((aligned(16))) double ip_smem[];  // w[mj], c[mi], 1 scalar
+    const int32_t* dsc = desc + (int64_t)blockIdx.x * 7;
+    const int ci = dsc[0], mi = dsc[1], cj = dsc[2], mj = dsc[3], fi = dsc[4], fj = dsc[5], oc = dsc[6];
+    double* wv = ip_smem;
+    double* cv = ip_smem + mj;
+    double* sc = cv + mi;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* bi = Bf + (int64_t)fi * ld;
+    const double* bj = Bf + (int64_t)fj * ld;
+    for (int t = wave; t < mj + mi; t += 4) {  // one wave per dot product
+        const bool first = t < mj;
+        const double* q = Q + (int64_t)(first ? cj + t : ci + (t - mj)) * ld;
+        const double* b = first ? bi : bj;
+        double acc = 0;
+        for (int64_t r = lane; r < n; r += 64) acc = fma(q[r], b[r], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) (first ? wv[t] : cv[t - mj]) = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double acc = 0;
+        for (int t = lane; t < mi; t += 64) acc = fma(cv[t], cv[t], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) sc[0] = 1.0 / sqrt(acc);
+    }
+    __syncthreads();
+    const double inv = sc[0];
+    double* dst = Qhat + (int64_t)oc * n;
+    for (int64_t r = threadIdx.x; r < n; r += 256) {
+        double acc = 0;
+        for (int t = 0; t < mj; ++t) acc = fma(Q[r + (int64_t)(cj + t) * ld], wv[t], acc);
+        dst[r] = acc * inv;
+    }
+}
+void launch_irreducible_pairs(hipStream_t s, int64_t n, int64_t ld, const double* Q, const double* Bf, int npairs,
+                              int max_m2, const int32_t* desc, double* Qhat) {
+    if (npairs <= 0) return;
+    const size_t lds = (size_t)(max_m2 + 2) * sizeof(double);  // max over pairs of mi + mj
+    irreducible_pairs_kernel<<<npairs, 256, lds, s>>>(n, ld, Q, Bf, desc, Qhat);
+}
+
 // dst[i] = inv_norm[0] * sum_j Q[i, col0 + j] * w[j]
 __global__ void gemv_n_scaled_kernel(int64_t n, int64_t ld, const double* __restrict__ Q,
                                      int64_t col0, int64_t m, const double* __restrict__ w,

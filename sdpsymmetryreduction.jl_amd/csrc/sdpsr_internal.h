@@ -181,6 +181,8 @@ void launch_gemv_n_scaled(hipStream_t s, int64_t n, int64_t ld, const double* Q,
                           int64_t m, const double* w, const double* inv_norm, double* dst);
 // copy column / clamp
 void launch_copy_col(hipStream_t s, int64_t n, const double* src, double* dst);
+void launch_irreducible_pairs(hipStream_t s, int64_t n, int64_t ld, const double* Q, const double* Bf, int npairs,
+                              int max_m2, const int32_t* desc, double* Qhat);
 void launch_copy_cols(hipStream_t s, int64_t n, int64_t count, const int32_t* src_cols, const int32_t* dst_cols,
                       const double* src, int64_t ld_src, double* dst, int64_t ld_dst);
 void launch_clamptol(hipStream_t s, int64_t len, double* a, double atol);
