@@ -18,6 +18,8 @@
 //    triangles) in one tiled kernel.
 // Output is LAPACK-compatible (d, e, tau, reflectors below the subdiagonal of A), so the
 // tridiagonal solve (rocSOLVER stedc) and the back-transformation (ormtr) plug in unchanged.
+#include <mutex>
+#include <cstdlib>
 #include "sdpsr_internal.h"
 
 namespace sdpsr {
@@ -386,8 +388,22 @@ size_t sytrd_workspace_doubles(int64_t n, int64_t ld) {
     return (size_t)2 * ld * SY_NB + (size_t)n + 2 * SY_NB + 2 * 4096 + 64;
 }
 
-void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
-                  double* ws) {
+static void sytrd_set_attributes() {
+    static bool attr_set = false;
+    if (attr_set) return;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<8>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<16>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<32>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<64>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr_set = true;
+}
+
+static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
+                                double* ws) {
     const int n = (int)n64;
     SytrdArgs a;
     a.A = A;
@@ -411,18 +427,7 @@ void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, 
     int n_vav = 0;
     int cf = 0;  // panel column of the column currently being formed
     const size_t lds_v = ((size_t)n + 4) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<16>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<32>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<64>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set = true;
-    }
+    sytrd_set_attributes();
     // column 0: plain form (no panel yet)
     {
         const int nb_form = (n + SY_FROWS - 1) / SY_FROWS;
@@ -504,6 +509,83 @@ void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, 
             sytrd_symv_kernel<32><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
         else
             sytrd_symv_kernel<64><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+    }
+}
+
+
+// For n up to a few thousand the ~2n + n/32 launches of the tridiagonalisation are shorter than
+// the cost of launching them (2-3 us of kernel against 4-5 us of launch): the launch sequence of
+// one problem shape is captured once into a hipGraph and replayed.  Key = every value baked into
+// the nodes (order, leading dimension, all pointers); the ctx's buffers are grow-only, so the key
+// is stable across calls.  A few graphs are kept (generic elements alternate between two or
+// three buffers).
+namespace {
+struct SytrdGraph {
+    int device = -1;
+    int64_t n = 0, ld = 0;
+    const void *A = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr, *ws = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t last_use = 0;
+};
+SytrdGraph g_sytrd_graphs[6];
+uint64_t g_sytrd_clock = 0;
+std::mutex g_sytrd_mutex;  // distinct ctxs may be driven from distinct host threads
+}  // namespace
+
+void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
+                  double* ws) {
+    static const bool no_graph = getenv("SDPSR_NO_GRAPH") != nullptr;
+    if (no_graph || n64 < 64 || n64 > 3072) {  // large orders: the kernels outlast their launches
+        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_sytrd_mutex);
+    sytrd_set_attributes();
+    int device = 0;
+    (void)hipGetDevice(&device);
+    ++g_sytrd_clock;
+    SytrdGraph* slot = nullptr;
+    for (auto& g : g_sytrd_graphs)
+        if (g.exec && g.device == device && g.n == n64 && g.ld == ld && g.A == A && g.d == d && g.e == e && g.tau == tau && g.ws == ws) slot = &g;
+    if (!slot) {
+        SytrdGraph* victim = &g_sytrd_graphs[0];
+        for (auto& g : g_sytrd_graphs)
+            if (!g.exec) {
+                victim = &g;
+                break;
+            } else if (g.last_use < victim->last_use) {
+                victim = &g;
+            }
+        if (victim->exec) hipGraphExecDestroy(victim->exec);
+        victim->exec = nullptr;
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
+            ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph;
+        }
+        if (ok) ok = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) {  // capture not possible here (e.g. the stream is already being captured): plain launches
+            victim->exec = nullptr;
+            (void)hipGetLastError();
+            launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
+            return;
+        }
+        victim->device = device;
+        victim->n = n64;
+        victim->ld = ld;
+        victim->A = A;
+        victim->d = d;
+        victim->e = e;
+        victim->tau = tau;
+        victim->ws = ws;
+        slot = victim;
+    }
+    slot->last_use = g_sytrd_clock;
+    if (hipGraphLaunch(slot->exec, s) != hipSuccess) {
+        (void)hipGetLastError();
+        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
     }
 }
 
