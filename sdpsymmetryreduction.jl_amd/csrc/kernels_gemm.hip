@@ -488,6 +488,19 @@ gemm_tn_dma256_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restri
         while ((row + 1) * (row + 2) / 2 <= t) ++row;
         bi = row;
         bj = t - row * (row + 1) / 2;
+    } else {
+        // XCD-aware order (see gemm_tn_dma_kernel): the 32 workgroups resident on an XCD form an
+        // 8 x 4 cluster of tiles and share operand panels through that XCD's L2
+        const int gm = gridDim.x, gn = gridDim.y;
+        const int nwg = gm * gn;
+        if ((nwg & 7) == 0 && (gm & 7) == 0) {
+            const int lin = blockIdx.y * gm + blockIdx.x;
+            const int swz = (lin & 7) * (nwg >> 3) + (lin >> 3);
+            const int per_group = 8 * gn;
+            const int grp = swz / per_group, within = swz - grp * per_group;
+            bi = grp * 8 + (within & 7);
+            bj = within >> 3;
+        }
     }
     const int64_t i0 = (int64_t)bi * BM2;
     const int64_t j0 = (int64_t)bj * BM2;
