@@ -177,9 +177,9 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    one_step(check=True)  # results still correct after the timed region
-    phase_timed = phase.copy()
+    phase_timed = phase.copy()  # snapshots of the timed region only
     iters_timed = iters_total
+    one_step(check=True)  # results still correct after the timed region
 
     # the same reduction with the dense eigensolver forced (hand-written tridiagonalisation on the
     # full n x n element): reported beside the default driver, never as `value`
