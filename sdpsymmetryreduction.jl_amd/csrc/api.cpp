@@ -1837,9 +1837,15 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     };
     // absorb m candidate columns W[:, w : w+m) into the basis; returns the number of new basis
     // vectors (0 = nothing left the span), < 0 on error (status in `abs_err`)
+    bool first_product_intact = false;
     auto absorb = [&](int m) -> int {
         std::vector<double> st1, st2;
-        const int r_new = ortho_step(m, 1e-12, true, st1);
+        // threshold 1e-10 |Y|^2: the projected Gram matrix comes from the cancellation G - C'C,
+        // whose error is ~ w sqrt(n) eps |Y|^2 (~1e-13 at n = 4096: with 1e-12 about one
+        // invariance round in ten let noise-level candidates through to the second step); a
+        // genuine new direction of a generic element has an O(1) relative component
+        const int r_new = ortho_step(m, 1e-10, true, st1);
+        first_product_intact = (r_new == 0);  // Cc still holds [W Y]'Y (no second product ran)
         if (r_new <= 0) return r_new;
         if (w + r_new >= wmax) {
             abs_err = krylov_fallback(c, "module dimension exceeds " + std::to_string(wmax));
@@ -1866,6 +1872,8 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             return abs_err;
         }
     }
+    bool have_saved = false;
+    int64_t saved_ld = 0;
     for (int round = 0; round < 40; ++round) {
         const bool fused = (w <= 64 && d <= 4000);
         int G = (fused && w <= 16) ? 4 : 2;  // generic elements per round
@@ -1888,7 +1896,14 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             tm.collect();
             return abs_err;
         }
-        if (got == 0) break;
+        if (got == 0) {
+            // the module is complete: the top block of this round's product, C = W' (A W), IS the
+            // compressed generic element W' A W of the round's first element -- keep it for the
+            // eigen stage instead of forming another one (one label product + one GEMM saved)
+            saved_ld = round_up(w + m, 128);
+            have_saved = first_product_intact;  // not if noise-level candidates went through the second step
+            break;
+        }
     }
     // columns >= w must be zero for the padded products below
     const int64_t wp = round_up(w, 128);
@@ -1900,6 +1915,14 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     dbg_mark("compressed: module grown");
     ElemGen gen;
     gen.make = [&](double* dst) -> int {
+        if (have_saved) {  // first element: the product of the final invariance round (see above)
+            have_saved = false;
+            HIP_TRY(c, hipMemsetAsync(dst, 0, (size_t)wp * wp * 8, s));
+            HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)wp * 8, Cc, (size_t)saved_ld * 8, (size_t)w * 8, (size_t)w,
+                                        hipMemcpyDeviceToDevice, s));
+            launch_symmetrize(s, w, wp, dst);
+            return SDPSR_OK;
+        }
         HIP_TRY(c, hipMemsetAsync(T, 0, (size_t)ld * wp * 8, s));
         { int e2 = apply_generic(w, T); if (e2) return e2; }   // T = A W
         gemm_tn_splitk(c, wp, wp, ld, W, ld, T, ld, dst, wp);  // B = W' T  (wp x wp)

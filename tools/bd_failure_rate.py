@@ -1,0 +1,18 @@
+"""Failure rate of blockDiagonalize on the synthetic N x N partition over many draws."""
+import sys, os, collections, numpy as np, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package
+pkg = load_package(); pr = pkg.problems; L = pkg._lib
+import torch
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+Ls, d = pr.synthetic_jordan_partition(n, seed=1)
+lab = torch.from_numpy(np.ascontiguousarray(Ls.ravel(order="F")).astype(np.int32)).cuda()
+out = collections.Counter()
+with pkg.Context(seed=77) as ctx:
+    lib = ctx._lib
+    for rep in range(reps):
+        nb = C.c_int32(0); ssq = C.c_int64(0); ss = C.c_int64(0)
+        st = lib.sdpsr_block_diagonalize(ctx._h, n, C.c_void_p(lab.data_ptr()), d, 1.4901161193847656e-08, C.byref(nb), C.byref(ssq), C.byref(ss), None, L.MEM_DEVICE)
+        out[(st, nb.value if st == 0 else -1)] += 1
+print("n", n, "dim", d, "results (status, nblocks):", dict(out))
