@@ -6,7 +6,13 @@ pkg = load_package(); pr = pkg.problems; L = pkg._lib
 import torch
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-Ls, d = pr.synthetic_jordan_partition(n, seed=1)
+kind = sys.argv[3] if len(sys.argv) > 3 else "commutative"
+if kind == "commutative":
+    Ls, d = pr.synthetic_jordan_partition(n, seed=1)
+else:  # non-commutative: ER(7) algebra (x) {I, J - I} on n // 57 points (blocks [2,2,2,2,3] twice)
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "golden_partitions.npz"))
+    Ls, d = pr.kron_with_complete(g["er7_P"].astype(np.int64), max(2, n // 57), seed=5)
+    n = Ls.shape[0]
 lab = torch.from_numpy(np.ascontiguousarray(Ls.ravel(order="F")).astype(np.int32)).cuda()
 out = collections.Counter()
 with pkg.Context(seed=77) as ctx:
