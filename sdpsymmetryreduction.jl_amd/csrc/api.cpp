@@ -363,6 +363,9 @@ void sdpsr_destroy(sdpsr_ctx* c) {
         if (kv.second.p) hipFree(kv.second.p);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->h2d_ring) hipHostFree(c->h2d_ring);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1089,6 +1092,10 @@ struct EigInfo {
 struct ElemGen {
     // writes an (n_eff x n_eff, leading dimension ld_eff, zero padded) symmetric matrix
     std::function<int(double* dst)> make;
+    // optional: start making the NEXT element into dst on a side stream (returns 0 if started),
+    // and make the main stream wait for it
+    std::function<int(double* dst)> prefetch;
+    std::function<int()> join;
 };
 
 int make_element(sdpsr_ctx* c, const ElemGen* gen, int64_t n, int64_t ld, const uint32_t* L, double* dst) {
@@ -1124,10 +1131,16 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     int st = make_element(c, gen, n, ld, L, Q);
     if (st) return st;
     dbg_mark("eigen_decomposition: element made");
+    // the second generic element does not depend on the eigendecomposition of the first: when
+    // the generator can, it is formed on a side stream while the (one-workgroup) eigensolver runs
+    const bool prefetched = gen && gen->prefetch && gen->join && gen->prefetch(Ap) == SDPSR_OK;
     st = syev_device(c, n, Q, ld, w);
     dbg_mark("eigen_decomposition: syev returned");
     tm.end();
-    if (st) return st;
+    if (st) {
+        if (prefetched) gen->join();  // never leave side-stream work behind
+        return st;
+    }
     info.vals.resize(n);
     st = d2h_sync(c, info.vals.data(), w, n * 8);
     if (st) return st;
@@ -1153,7 +1166,7 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     st = h2d_sync(c, dspace, space_of.data(), n * 4);
     if (st) return st;
     HIP_TRY(c, hipMemsetAsync(dnorms, 0, (size_t)neig * neig * 8, s));
-    st = make_element(c, gen, n, ld, L, Ap);
+    st = prefetched ? gen->join() : make_element(c, gen, n, ld, L, Ap);
     if (st) return st;
     launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);   // T = A Q (A symmetric)
     launch_gemm_tn_f64(s, ld, ld, ld, Q, ld, Tp, ld, Ap, ld, 1, 0, 0, 0);   // M = Q' T  (into Ap)
@@ -1927,6 +1940,35 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         { int e2 = apply_generic(w, T); if (e2) return e2; }   // T = A W
         gemm_tn_splitk(c, wp, wp, ld, W, ld, T, ld, dst, wp);  // B = W' T  (wp x wp)
         launch_symmetrize(s, w, wp, dst);
+        return SDPSR_OK;
+    };
+    gen.prefetch = [&](double* dst) -> int {
+        if (!c->side_stream) {
+            if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return SDPSR_HIP_ERROR;
+            }
+        }
+        if (have_saved) return SDPSR_BAD_STATE;  // the next element is the saved one: nothing to overlap
+        hipStream_t main_stream = c->stream;
+        if (hipEventRecord(c->ev_fork, main_stream) != hipSuccess) return SDPSR_HIP_ERROR;
+        if (hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return SDPSR_HIP_ERROR;
+        c->stream = c->side_stream;  // every helper launches on c->stream / s
+        s = c->side_stream;
+        const int e2 = gen.make(dst);
+        const bool rec = hipEventRecord(c->ev_join, c->side_stream) == hipSuccess;
+        c->stream = main_stream;
+        s = main_stream;
+        if (e2 || !rec) {
+            hipStreamSynchronize(c->side_stream);
+            return e2 ? e2 : SDPSR_HIP_ERROR;
+        }
+        return SDPSR_OK;
+    };
+    gen.join = [&]() -> int {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         return SDPSR_OK;
     };
     int st = dense_diagonalize(c, w, nullptr, &gen, atol, info, sizes, S1, S, tm);

@@ -28,6 +28,8 @@ struct sdpsr_ctx {
     uint64_t stream_counter = 0;  // fresh RNG stream per randomize call
     sdpsr_opts opts{};
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;  // lazily created: work that overlaps a one-workgroup kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool own_stream = false;
     std::string err;
     std::map<std::string, DevBuf> bufs;
