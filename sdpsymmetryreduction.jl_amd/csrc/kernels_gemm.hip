@@ -270,12 +270,17 @@ gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict_
     int bi = blockIdx.x, bj = blockIdx.y;
     const bool sym_lower = nonsym_flag && *nonsym_flag == 0u;  // uniform
     if (sym_lower) {
-        // lower-triangle tiles only: workgroup number t (dealt round-robin over the XCDs by the
-        // hardware, which balances the triangle) takes tile t of the row-major enumeration
-        // (bi, bj <= bi); the workgroups beyond the triangle have nothing to do
-        const int t = blockIdx.y * gridDim.x + blockIdx.x;
+        // lower-triangle tiles only, row-major enumeration (bi, bj <= bi); the workgroups beyond
+        // the triangle have nothing to do
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
         const int gm = gridDim.x;
-        if (t >= gm * (gm + 1) / 2) return;
+        const int ntri = gm * (gm + 1) / 2;
+        if (lin >= ntri) return;
+        // workgroup lin runs on XCD lin % 8: give every XCD one contiguous, equally long run of
+        // the row-major triangle sequence (balanced, and neighbours in the run share operand
+        // panels through that XCD's L2); the last ntri % 8 tiles keep their own number
+        const int per = ntri >> 3;
+        const int t = (lin < 8 * per) ? (lin & 7) * per + (lin >> 3) : lin;
         int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
         while (row * (row + 1) / 2 > t) --row;
         while ((row + 1) * (row + 2) / 2 <= t) ++row;
@@ -480,9 +485,15 @@ gemm_tn_dma256_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restri
     const int wi = wave & 1, wj = wave >> 1;
     int bi = blockIdx.x, bj = blockIdx.y;
     if (nonsym_flag && *nonsym_flag == 0u) {  // lower-triangle tiles only (see gemm_tn_dma_kernel)
-        const int t = blockIdx.y * gridDim.x + blockIdx.x;
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
         const int gm = gridDim.x;
-        if (t >= gm * (gm + 1) / 2) return;
+        const int ntri = gm * (gm + 1) / 2;
+        if (lin >= ntri) return;
+        // workgroup lin runs on XCD lin % 8: give every XCD one contiguous, equally long run of
+        // the row-major triangle sequence (balanced, and neighbours in the run share operand
+        // panels through that XCD's L2); the last ntri % 8 tiles keep their own number
+        const int per = ntri >> 3;
+        const int t = (lin < 8 * per) ? (lin & 7) * per + (lin >> 3) : lin;
         int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
         while (row * (row + 1) / 2 > t) --row;
         while ((row + 1) * (row + 2) / 2 <= t) ++row;
