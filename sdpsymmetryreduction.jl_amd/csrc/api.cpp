@@ -345,6 +345,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
     }
     c->own_stream = true;
     c->pinned_bytes = 1 << 16;
+    if (hipHostMalloc((void**)&c->pinned_small, 256, hipHostMallocDefault) != hipSuccess) c->pinned_small = nullptr;
     if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         hipStreamDestroy(c->stream);
         delete c;
@@ -363,6 +364,7 @@ void sdpsr_destroy(sdpsr_ctx* c) {
         if (kv.second.p) hipFree(kv.second.p);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->h2d_ring) hipHostFree(c->h2d_ring);
+    if (c->pinned_small) hipHostFree(c->pinned_small);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
@@ -1708,12 +1710,14 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     double* zy = (double*)ctx_buf(c, "cm_zy", (size_t)ld * 2 * 8);
     double* dout = (double*)ctx_buf(c, "cm_out", 64);
     if (!flag || !W || !T || !zy || !dout) return SDPSR_OUT_OF_MEMORY;
+    // symmetric check: the verdict is copied back without a synchronisation of its own and is
+    // looked at after the first read-back of the module growth (the kernels in between are
+    // memory-safe for any labels, their results are simply discarded)
+    if (!c->pinned_small) return SDPSR_OUT_OF_MEMORY;
     launch_check_symmetric(s, n, L, flag);
-    uint32_t* hflag = (uint32_t*)c->pinned;
-    HIP_TRY(c, hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (hflag[0]) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
-                                  "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
+    c->pinned_small[0] = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->pinned_small, flag, 4, hipMemcpyDeviceToHost, s));
+    bool sym_checked = false;
     // Y <- A W for a fresh generic element A: fused label product when the shape allows it,
     // gather + split-K MFMA GEMM otherwise.  Columns >= wcols of dst keep their old content.
     auto apply_generic = [&](int wcols, double* dst) -> int {
@@ -1814,6 +1818,14 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         hG.resize((size_t)ap * mp);
         abs_err = d2h_sync(c, hG.data(), Cc, (size_t)ap * mp * 8);
         if (abs_err) return -1;
+        if (!sym_checked) {  // the stream has been synchronised: the verdict of the symmetric check is in
+            sym_checked = true;
+            if (c->pinned_small[0]) {
+                abs_err = ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
+                                   "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
+                return -1;
+            }
+        }
         // scale reference: the candidates BEFORE projection (after it, a complete module leaves
         // only rounding noise and a relative test would compare noise with noise)
         if (take_ref && ref == 0)
@@ -1971,26 +1983,19 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         return SDPSR_OK;
     };
+    if (!ctx_buf(c, "bd_qhat", (size_t)n * wmax * 8)) return SDPSR_OUT_OF_MEMORY;  // final size now: no move later
     int st = dense_diagonalize(c, w, nullptr, &gen, atol, info, sizes, S1, S, tm);
     if (st) return st;
     dbg_mark("compressed: small dense diagonalize done");
     // lift: Q_hat = W * Q_hat_small
     tm.begin(SDPSR_T_IRRED);
+    // "bd_qhat" was sized for n x wmax before the small problem ran (S1 <= w < wmax), so the
+    // small Q_hat sits at its start and the buffer does not move here: stream order suffices
     double* qs = (double*)ctx_buf(c, "cm_qsmall", (size_t)w * S1 * 8);
-    double* small = (double*)ctx_buf(c, "bd_qhat", (size_t)w * S1 * 8);
-    if (!qs || !small) return SDPSR_OUT_OF_MEMORY;
-    HIP_TRY(c, hipMemcpyAsync(qs, small, (size_t)w * S1 * 8, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
     double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
-    int* dlift = (int*)ctx_buf(c, "cm_lift", (size_t)S1 * 2 * 4);
-    if (!Qhat || !dlift) return SDPSR_OUT_OF_MEMORY;
-    std::vector<int> hl(2 * (size_t)S1);
-    for (int64_t i = 0; i < S1; ++i) {
-        hl[i] = 0;
-        hl[S1 + i] = w;
-    }
-    { int e2 = h2d_sync(c, dlift, hl.data(), (size_t)S1 * 2 * 4); if (e2) return e2; }
-    launch_ritz_combine(s, n, ld, W, 0, dlift, dlift + S1, qs, w, (int)S1, Qhat, n);
+    if (!qs || !Qhat) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(qs, Qhat, (size_t)w * S1 * 8, hipMemcpyDeviceToDevice, s));
+    launch_tall_times_small(s, n, ld, W, w, qs, w, (int)S1, 1.0, 0.0, Qhat, n);
     launch_clamptol(s, n * S1, Qhat, atol);
     tm.end();
     HIP_TRY(c, hipStreamSynchronize(s));

@@ -35,6 +35,7 @@ struct sdpsr_ctx {
     std::map<std::string, DevBuf> bufs;
     void* pinned = nullptr;  // small pinned host scratch for scalar read-backs
     size_t pinned_bytes = 0;
+    uint32_t* pinned_small = nullptr;  // 256 B pinned: flags read back without their own synchronisation
     void* h2d_ring = nullptr;  // pinned ring for small stream-ordered uploads (no sync per upload)
     int h2d_ring_next = 0;
     void* rocblas = nullptr;  // rocblas_handle, created lazily

@@ -450,3 +450,21 @@ def test_basis_image_kernel_variants(pkg, oracle, golden, name, variant, monkeyp
     for i in range(P.nparts):
         for k in range(len(bd.blkSizes)):
             assert np.allclose(bd.blks[i][k], ref[i][k], atol=1e-10), (variant, i, k)
+
+
+@pytest.mark.gpu
+def test_nonsymmetric_partition_rejected_by_both_drivers(pkg, gpu_ctx):
+    """A non-symmetric partition has a generic element with a complex spectrum
+    (src/eigen_decomposition.jl:247-253): InvalidDecompositionField from the dense driver (small n)
+    and from the module-compression driver (n >= 512, verdict read with the first Gram matrix)."""
+    rng = np.random.default_rng(11)
+    for n in (24, 640):
+        M = rng.integers(1, 4, size=(n, n)).astype(np.uint32)
+        assert not np.array_equal(M, M.T)
+        P = pkg.Partition(3, M)
+        with pytest.raises(pkg.InvalidDecompositionField):
+            pkg.blockDiagonalize(P, ctx=gpu_ctx)
+    # the ctx stays usable afterwards
+    Ls = np.array([[1, 2], [2, 1]], dtype=np.uint32)
+    bd = pkg.blockDiagonalize(pkg.Partition(2, Ls), ctx=gpu_ctx, retries=50)
+    assert sorted(bd.blkSizes) == [1, 1]
