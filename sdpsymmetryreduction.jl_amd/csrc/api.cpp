@@ -60,6 +60,25 @@ static void ctx_free_buf(sdpsr_ctx* c, const char* name) {
     c->bufs.erase(it);
 }
 
+namespace sdpsr {
+// Small host<->device transfers go through a growable pinned staging area: a hipMemcpyAsync
+// to or from pageable memory costs milliseconds of host time on this stack.
+void* ctx_pinned(sdpsr_ctx* c, size_t bytes) {  // shared with eigen.cpp
+    if (c->pinned_bytes >= bytes) return c->pinned;
+    hipStreamSynchronize(c->stream);
+    if (c->pinned) hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
+    size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+    if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) {
+        c->pinned = nullptr;
+        return nullptr;
+    }
+    c->pinned_bytes = want;
+    return c->pinned;
+}
+}  // namespace sdpsr
+
 namespace {
 
 // SDPSR_DEBUG=1: host wall-clock marks (relative to the previous mark)
@@ -118,22 +137,6 @@ int out_finish(sdpsr_ctx* c, T* host, const T* dev, size_t count, int mem) {
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-// Small host<->device transfers go through a growable pinned staging area: a hipMemcpyAsync
-// to or from pageable memory costs milliseconds of host time on this stack.
-void* ctx_pinned(sdpsr_ctx* c, size_t bytes) {
-    if (c->pinned_bytes >= bytes) return c->pinned;
-    hipStreamSynchronize(c->stream);
-    if (c->pinned) hipHostFree(c->pinned);
-    c->pinned = nullptr;
-    c->pinned_bytes = 0;
-    size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
-    if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) {
-        c->pinned = nullptr;
-        return nullptr;
-    }
-    c->pinned_bytes = want;
-    return c->pinned;
-}
 int d2h_sync(sdpsr_ctx* c, void* host, const void* dev, size_t bytes) {
     void* p = ctx_pinned(c, bytes);
     if (!p) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
@@ -1136,16 +1139,14 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     // the second generic element does not depend on the eigendecomposition of the first: when
     // the generator can, it is formed on a side stream while the (one-workgroup) eigensolver runs
     const bool prefetched = gen && gen->prefetch && gen->join && gen->prefetch(Ap) == SDPSR_OK;
-    st = syev_device(c, n, Q, ld, w);
+    info.vals.resize(n);
+    st = syev_device(c, n, Q, ld, w, info.vals.data());
     dbg_mark("eigen_decomposition: syev returned");
     tm.end();
     if (st) {
         if (prefetched) gen->join();  // never leave side-stream work behind
         return st;
     }
-    info.vals.resize(n);
-    st = d2h_sync(c, info.vals.data(), w, n * 8);
-    if (st) return st;
     tm.collect();
     // EigenDecomposition ctor (:19-40): new eigenspace where |dv| > atol
     info.ptrs.assign(1, 0);

@@ -5,6 +5,7 @@
 // tridiagonalisation can be replaced by the hand-written HIP panel kernel without touching
 // the callers:   sytrd (A = Q T Q')  ->  stedc (T = Z D Z')  ->  ormtr (V = Q Z).
 #include <cstdlib>
+#include <cstring>
 #include <cstdio>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
@@ -37,7 +38,7 @@ void destroy_handle(sdpsr_ctx* c) {
 
 // A: n x n column-major with leading dimension lda, lower triangle referenced; on exit the
 // columns of A are the orthonormal eigenvectors, w ascending.
-int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w) {
+int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, double* host_w) {
     int st = ensure_handle(c);
     if (st) return st;
     rocblas_handle h = (rocblas_handle)c->rocblas;
@@ -86,10 +87,12 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w) {
             return ctx_fail(c, SDPSR_HIP_ERROR, "copy of eigenvectors failed");
     }
     // read-back through the pinned scratch of the ctx (a pageable 4-byte copy costs tens of us)
-    rocblas_int* hpin = (rocblas_int*)c->pinned;
+    rocblas_int* hpin = (rocblas_int*)ctx_pinned(c, 64 + (host_w ? (size_t)n * sizeof(double) : 0));
     if (!hpin || hipMemcpyAsync(hpin, info, 2 * sizeof(rocblas_int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        (host_w && hipMemcpyAsync((char*)hpin + 64, w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
         hipStreamSynchronize(c->stream) != hipSuccess)
         return ctx_fail(c, SDPSR_HIP_ERROR, "eigensolver info read-back failed");
+    if (host_w) memcpy(host_w, (char*)hpin + 64, (size_t)n * sizeof(double));
     const rocblas_int hinfo = hpin[0];
     if (getenv("SDPSR_DEBUG") && n <= 128) fprintf(stderr, "[sdpsr] small syev n=%lld: %d sweeps\n", (long long)n, (int)hpin[1]);
     if (hinfo != 0)

@@ -220,7 +220,9 @@ int sort_entries_by_label(sdpsr_ctx* c, int64_t len, int64_t d, const uint32_t* 
 // eigen.cpp (rocSOLVER)
 // ---------------------------------------------------------------------------
 // A (n x n, leading dimension lda) is overwritten with the eigenvectors; w[n] ascending.
-int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w);
+// host_w (optional): the eigenvalues are also delivered to the host, riding on the status read-back
+int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, double* host_w = nullptr);
+void* ctx_pinned(sdpsr_ctx* c, size_t bytes);
 void destroy_handle(sdpsr_ctx* c);
 
 }  // namespace sdpsr
