@@ -149,15 +149,17 @@ int d2h_sync(sdpsr_ctx* c, void* host, const void* dev, size_t bytes) {
 // stream-ordered (the caller's buffer is free on return, no host wait); the stream is only
 // synchronised when the ring wraps, so a slot is never rewritten while its copy is in flight.
 constexpr size_t H2D_SLOT = 32 * 1024;
-constexpr int H2D_SLOTS = 16;
+constexpr int H2D_SLOTS = 32;
 int h2d_sync(sdpsr_ctx* c, void* dev, const void* host, size_t bytes) {
     if (bytes <= H2D_SLOT) {
         if (!c->h2d_ring && hipHostMalloc(&c->h2d_ring, H2D_SLOT * H2D_SLOTS, hipHostMallocDefault) != hipSuccess) {
             c->h2d_ring = nullptr;
             return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned upload ring");
         }
-        if (c->h2d_ring_next == H2D_SLOTS) {
+        if (c->h2d_ring_next == H2D_SLOTS) {  // every stream that may still read a slot
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->side_stream && c->side_stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->side_stream));
+            if (c->main_shadow && c->main_shadow != c->stream) HIP_TRY(c, hipStreamSynchronize(c->main_shadow));
             c->h2d_ring_next = 0;
         }
         void* slot = (char*)c->h2d_ring + (size_t)c->h2d_ring_next++ * H2D_SLOT;
@@ -1969,10 +1971,12 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         if (hipEventRecord(c->ev_fork, main_stream) != hipSuccess) return SDPSR_HIP_ERROR;
         if (hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return SDPSR_HIP_ERROR;
         c->stream = c->side_stream;  // every helper launches on c->stream / s
+        c->main_shadow = main_stream;
         s = c->side_stream;
         const int e2 = gen.make(dst);
         const bool rec = hipEventRecord(c->ev_join, c->side_stream) == hipSuccess;
         c->stream = main_stream;
+        c->main_shadow = nullptr;
         s = main_stream;
         if (e2 || !rec) {
             hipStreamSynchronize(c->side_stream);
