@@ -716,7 +716,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
                 } else {
                     launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, lower);
                 }
-                launch_sig_i32(s, n, ld, T, L, (const int32_t*)Cp, sig, lower);
+                launch_sig_i32(s, n, ld, T, L, (const int32_t*)Cp, sig, lower, labels_sym);
             } else if (mode == SDPSR_SQUARE_F32) {
                 launch_gather_f32(s, n, ld, T, vmax, L, key2, (float*)Xp);
                 if (!labels_sym) {
@@ -727,7 +727,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
                 } else {
                     launch_gemm_tn_f32_sym(s, ld, ld, (const float*)Xp, ld, (float*)Cp, ld, T, ld * ld, ld * ld, lower);
                 }
-                launch_sig_f32(s, n, ld, T, L, (const float*)Cp, sig, lower);
+                launch_sig_f32(s, n, ld, T, L, (const float*)Cp, sig, lower, labels_sym);
             } else {
                 // reference-literal: the projected element is squared when the projection
                 // step did not refine S (X is overwritten in place at :160-163), a fresh
@@ -742,8 +742,18 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             }
             tm.end();
             tm.begin(SDPSR_T_REFINE);
-            st = refine_signatures(c, len, sig, L, &d2);
-            if (!st && int_mode && labels_sym) launch_mirror_labels(s, n, L, zero_flag);
+            if (int_mode && labels_sym) {
+                // symmetric labels: the signatures were written for the packed lower triangle
+                // only; refine n (n + 1) / 2 entries (same relative order, same canonical
+                // numbering), then expand to the full symmetric matrix
+                const int64_t lenp = n * (n + 1) / 2;
+                uint32_t* Lp = (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4);
+                if (!Lp) return SDPSR_OUT_OF_MEMORY;
+                st = refine_signatures(c, lenp, sig, Lp, &d2);
+                if (!st) launch_unpack_symmetric_labels(s, n, Lp, L);
+            } else {
+                st = refine_signatures(c, len, sig, L, &d2);
+            }
             tm.end();
             if (st) return st;
             tm.collect();

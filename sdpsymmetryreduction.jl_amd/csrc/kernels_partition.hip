@@ -384,7 +384,7 @@ void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_
 template <typename CT>
 __global__ void sig_channels_kernel(int64_t n, int64_t ld, int T, const uint32_t* __restrict__ L,
                                     const CT* __restrict__ C, uint64_t* __restrict__ sig,
-                                    const uint32_t* __restrict__ nonsym_flag) {
+                                    const uint32_t* __restrict__ nonsym_flag, int packed) {
     const int64_t istride = (int64_t)gridDim.x * blockDim.x;
     // lower != 0: labels and products are symmetric, only entries i >= j get a signature (the
     // strict upper triangle gets the zero signature and is mirrored after the refinement; first
@@ -393,12 +393,16 @@ __global__ void sig_channels_kernel(int64_t n, int64_t ld, int T, const uint32_t
     const bool lower = nonsym_flag && *nonsym_flag == 0u;
     for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
         const uint32_t* Lj = L + j * n;
-        uint64_t* sj = sig + j * n;
+        // packed != 0 (with lower): the signatures of the lower triangle are written densely,
+        // column j at offset j n - j (j - 1) / 2, rows j .. n-1 -- the refinement then runs on
+        // n (n + 1) / 2 entries in the same relative order
+        const bool pk = lower && packed;
+        uint64_t* sj = pk ? sig + (j * n - j * (j - 1) / 2 - j) : sig + j * n;
         const CT* Cj = C + j * ld;
 #pragma unroll 2
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += istride) {
             if (lower && i < j) {
-                sj[i] = 0ull;
+                if (!pk) sj[i] = 0ull;
                 continue;
             }
             const uint32_t l = Lj[i];
@@ -421,12 +425,12 @@ static inline dim3 column_grid(int64_t n) {
     return dim3((unsigned)gx, (unsigned)(n < 65535 ? n : 65535));
 }
 void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag) {
-    sig_channels_kernel<int32_t><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag);
+                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag, int packed) {
+    sig_channels_kernel<int32_t><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag, packed);
 }
 void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag) {
-    sig_channels_kernel<float><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag);
+                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag, int packed) {
+    sig_channels_kernel<float><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag, packed);
 }
 
 // ---------------------------------------------------------------------------
@@ -899,6 +903,35 @@ mirror_labels_kernel(int64_t n, uint32_t* __restrict__ L, const uint32_t* __rest
 void launch_mirror_labels(hipStream_t s, int64_t n, uint32_t* L, const uint32_t* nonsym_flag) {
     const unsigned t = (unsigned)((n + 63) / 64);
     mirror_labels_kernel<<<dim3(t, t), 256, 0, s>>>(n, L, nonsym_flag);
+}
+
+// Full symmetric label matrix from the packed lower triangle (column j at offset
+// j n - j (j - 1) / 2, rows j .. n-1): both triangles are written along columns, the mirrored
+// one through a 64 x 64 LDS tile.
+__global__ void __launch_bounds__(256)
+unpack_symmetric_labels_kernel(int64_t n, const uint32_t* __restrict__ Lp, uint32_t* __restrict__ L) {
+    __shared__ uint32_t tile[64][65];
+    const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;  // lower tile: rows i0.., cols j0..
+    if (i0 < j0) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4) {
+        const int64_t r = i0 + tx, cc = j0 + c;
+        uint32_t v = 0u;
+        if (r < n && cc < n && r >= cc) {
+            v = Lp[cc * n - cc * (cc - 1) / 2 + (r - cc)];
+            L[r + cc * n] = v;
+        }
+        tile[c][tx] = v;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {  // destination: row j0 + tx, column i0 + c  (= entry (i0 + c, j0 + tx))
+        const int64_t r = j0 + tx, cc = i0 + c;
+        if (r < n && cc < n && r < cc) L[r + cc * n] = tile[tx][c];
+    }
+}
+void launch_unpack_symmetric_labels(hipStream_t s, int64_t n, const uint32_t* Lp, uint32_t* L) {
+    const unsigned t = (unsigned)((n + 63) / 64);
+    unpack_symmetric_labels_kernel<<<dim3(t, t), 256, 0, s>>>(n, Lp, L);
 }
 
 // Lt[k + i*n] = L[i + k*n]: 64 x 64 label tiles through LDS (both sides coalesced)

@@ -107,9 +107,9 @@ void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_
                     uint64_t* sig);
 // T channels of int32 / f32 squares, padded ld, C[t] at C + t*ld*ld
 void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr);
+                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr, int packed = 0);
 void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr);
+                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr, int packed = 0);
 
 // canonical relabel of signatures (hash table + first-occurrence ranking).
 // Workspace layout is owned by the caller (see refine_workspace_bytes).
@@ -157,6 +157,7 @@ void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X,
 void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X, int64_t ldx, float* C, int64_t ldc,
                             int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag);
 void launch_mirror_labels(hipStream_t s, int64_t n, uint32_t* L, const uint32_t* nonsym_flag);
+void launch_unpack_symmetric_labels(hipStream_t s, int64_t n, const uint32_t* Lp, uint32_t* L);
 void launch_gemm_tn_i8(hipStream_t s, int64_t m, int64_t n, int64_t k, const int8_t* A,
                        int64_t lda, const int8_t* B, int64_t ldb, int32_t* C, int64_t ldc,
                        int batch, int64_t strideA, int64_t strideB, int64_t strideC);
