@@ -882,29 +882,6 @@ void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_
     check_symmetric_kernel<<<dim3(t, t), 256, 0, s>>>(n, L, flag);
 }
 
-// L[i,j] = L[j,i] for i < j while *nonsym_flag == 0 (64 x 64 tiles through LDS)
-__global__ void __launch_bounds__(256)
-mirror_labels_kernel(int64_t n, uint32_t* __restrict__ L, const uint32_t* __restrict__ nonsym_flag) {
-    __shared__ uint32_t tile[64][65];
-    if (*nonsym_flag != 0u) return;
-    const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;  // source tile (lower): rows i0.., cols j0..
-    if (i0 < j0) return;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int c = ty; c < 64; c += 4) {
-        const int64_t r = i0 + tx, cc = j0 + c;
-        tile[c][tx] = (r < n && cc < n) ? L[r + cc * n] : 0u;
-    }
-    __syncthreads();
-    for (int c = ty; c < 64; c += 4) {  // destination: rows j0 + tx, columns i0 + c  (= L[i0+c, j0+tx])
-        const int64_t r = j0 + tx, cc = i0 + c;
-        if (r < n && cc < n && r < cc) L[r + cc * n] = tile[tx][c];
-    }
-}
-void launch_mirror_labels(hipStream_t s, int64_t n, uint32_t* L, const uint32_t* nonsym_flag) {
-    const unsigned t = (unsigned)((n + 63) / 64);
-    mirror_labels_kernel<<<dim3(t, t), 256, 0, s>>>(n, L, nonsym_flag);
-}
-
 // Full symmetric label matrix from the packed lower triangle (column j at offset
 // j n - j (j - 1) / 2, rows j .. n-1): both triangles are written along columns, the mirrored
 // one through a 64 x 64 LDS tile.

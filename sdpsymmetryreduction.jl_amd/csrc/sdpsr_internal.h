@@ -156,7 +156,6 @@ void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X,
                            int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag);
 void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X, int64_t ldx, float* C, int64_t ldc,
                             int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag);
-void launch_mirror_labels(hipStream_t s, int64_t n, uint32_t* L, const uint32_t* nonsym_flag);
 void launch_unpack_symmetric_labels(hipStream_t s, int64_t n, const uint32_t* Lp, uint32_t* L);
 void launch_gemm_tn_i8(hipStream_t s, int64_t m, int64_t n, int64_t k, const int8_t* A,
                        int64_t lda, const int8_t* B, int64_t ldb, int32_t* C, int64_t ldc,
