@@ -226,14 +226,21 @@ struct PhaseTimer {
         pending.push_back({cur_slot, cur_a, b});
         cur_slot = -1;
     }
-    void collect() {  // call after a stream sync
+    void collect() {  // intervals whose end event has not completed yet stay pending
+        std::vector<Pending> later;
         for (auto& p : pending) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) acc[p.slot] += ms;
+            const hipError_t e = hipEventElapsedTime(&ms, p.a, p.b);
+            if (e == hipErrorNotReady) {
+                later.push_back(p);
+                continue;
+            }
+            if (e == hipSuccess) acc[p.slot] += ms;
             pool.push_back(p.a);
             pool.push_back(p.b);
         }
-        pending.clear();
+        (void)hipGetLastError();
+        pending.swap(later);
     }
 };
 
