@@ -58,8 +58,8 @@ def cpu_baseline(pr, n_sample, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--mode", default="i8", choices=["i8", "f32", "f64"])
     ap.add_argument("--cpu-n", type=int, default=2048, help="order of the bounded CPU-baseline sample (0 = skip)")
