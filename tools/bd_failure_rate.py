@@ -15,10 +15,15 @@ else:  # non-commutative: ER(7) algebra (x) {I, J - I} on n // 57 points (blocks
     n = Ls.shape[0]
 lab = torch.from_numpy(np.ascontiguousarray(Ls.ravel(order="F")).astype(np.int32)).cuda()
 out = collections.Counter()
+msgs = []
 with pkg.Context(seed=77) as ctx:
     lib = ctx._lib
     for rep in range(reps):
         nb = C.c_int32(0); ssq = C.c_int64(0); ss = C.c_int64(0)
         st = lib.sdpsr_block_diagonalize(ctx._h, n, C.c_void_p(lab.data_ptr()), d, 1.4901161193847656e-08, C.byref(nb), C.byref(ssq), C.byref(ss), None, L.MEM_DEVICE)
         out[(st, nb.value if st == 0 else -1)] += 1
+        if st != 0 and len(msgs) < 6:
+            msgs.append(lib.sdpsr_last_error(ctx._h).decode()[:160])
 print("n", n, "dim", d, "results (status, nblocks):", dict(out))
+for m in msgs:
+    print("   ", m)
