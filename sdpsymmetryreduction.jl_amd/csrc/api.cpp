@@ -714,11 +714,11 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             }
             if (mode == SDPSR_SQUARE_I8) {
                 int8_t* Xl = (int8_t*)Xp;
-                launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp);
+                launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp, d2);  // d2 = current dimension
                 if (!labels_sym) {
                     Xl = (int8_t*)ctx_buf(c, "des_yi8", (size_t)T * ld * ld);
                     if (!Xl) return SDPSR_OUT_OF_MEMORY;
-                    launch_gather_i8(s, n, ld, T, Lleft, key2, Xl);
+                    launch_gather_i8(s, n, ld, T, Lleft, key2, Xl, d2);
                     launch_gemm_tn_i8(s, ld, ld, ld, Xl, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
                 } else {
                     launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, lower);

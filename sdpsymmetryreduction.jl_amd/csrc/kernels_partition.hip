@@ -66,9 +66,21 @@ void launch_clamp_round(hipStream_t s, int64_t len, double* a, double atol, doub
 // column of the padded ld x ld matrix; each channel gets one 16-byte store (int8) or
 // four (f32).  Padding rows/columns are zero.
 // ---------------------------------------------------------------------------
+constexpr int GATHER_LUT = 2048;  // classes whose random bits are tabulated in LDS
+
 template <int T>
 __global__ void gather_i8_kernel(int64_t n, int64_t ld, const uint32_t* __restrict__ L,
-                                 uint64_t key, int8_t* __restrict__ X) {
+                                 uint64_t key, int8_t* __restrict__ X, int dlut) {
+    // dlut > 0: the labels are <= dlut <= GATHER_LUT and their 64 random bits come from an LDS
+    // table (the per-entry hash costs three quarter-rate 64-bit multiplies, more than the
+    // memory traffic of this kernel); the labels of a thread's 16 rows are read as four 16-byte
+    // loads when the row count allows it
+    __shared__ uint64_t lut[GATHER_LUT + 1];
+    if (dlut > 0) {
+        for (int i = threadIdx.x; i <= dlut; i += blockDim.x) lut[i] = i ? sdpsr_class_bits(key, (uint32_t)i) : 0ull;
+        __syncthreads();
+    }
+    const bool vec = (n & 3) == 0;
     const int64_t chunks_per_col = ld / 16;
     const int64_t total = chunks_per_col * ld;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -81,11 +93,25 @@ __global__ void gather_i8_kernel(int64_t n, int64_t ld, const uint32_t* __restri
 #pragma unroll
             for (int w = 0; w < 4; ++w) out[t][w] = 0;
         if (j < n) {
+            uint32_t lab[16];
+            if (vec && i0 + 16 <= n) {
+                const uint4* p = reinterpret_cast<const uint4*>(L + i0 + j * n);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const uint4 v = p[q4];
+                    lab[4 * q4] = v.x;
+                    lab[4 * q4 + 1] = v.y;
+                    lab[4 * q4 + 2] = v.z;
+                    lab[4 * q4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) lab[q] = (i0 + q < n) ? L[i0 + q + j * n] : 0u;
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int64_t i = i0 + q;
-                uint32_t l = (i < n) ? L[i + j * n] : 0u;
-                uint64_t bits = l ? sdpsr_class_bits(key, l) : 0ull;
+                const uint32_t l = lab[q];
+                const uint64_t bits = dlut > 0 ? lut[l] : (l ? sdpsr_class_bits(key, l) : 0ull);
 #pragma unroll
                 for (int t = 0; t < T; ++t)
                     out[t][q >> 2] |= (uint32_t)((bits >> (8 * t)) & 0xFFull) << (8 * (q & 3));
@@ -100,17 +126,19 @@ __global__ void gather_i8_kernel(int64_t n, int64_t ld, const uint32_t* __restri
 }
 
 void launch_gather_i8(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                      uint64_t key, int8_t* X) {
+                      uint64_t key, int8_t* X, int64_t dmax) {
+    // dmax: upper bound of the labels (0 = unknown): enables the LDS table of class bits
+    const int dlut = (dmax > 0 && dmax <= GATHER_LUT) ? (int)dmax : 0;
     int g = grid_for(ld / 16 * ld, 256);
     switch (T) {
-        case 1: gather_i8_kernel<1><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
-        case 2: gather_i8_kernel<2><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
-        case 3: gather_i8_kernel<3><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
-        case 4: gather_i8_kernel<4><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
-        case 5: gather_i8_kernel<5><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
-        case 6: gather_i8_kernel<6><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
-        case 7: gather_i8_kernel<7><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
-        default: gather_i8_kernel<8><<<g, 256, 0, s>>>(n, ld, L, key, X); break;
+        case 1: gather_i8_kernel<1><<<g, 256, 0, s>>>(n, ld, L, key, X, dlut); break;
+        case 2: gather_i8_kernel<2><<<g, 256, 0, s>>>(n, ld, L, key, X, dlut); break;
+        case 3: gather_i8_kernel<3><<<g, 256, 0, s>>>(n, ld, L, key, X, dlut); break;
+        case 4: gather_i8_kernel<4><<<g, 256, 0, s>>>(n, ld, L, key, X, dlut); break;
+        case 5: gather_i8_kernel<5><<<g, 256, 0, s>>>(n, ld, L, key, X, dlut); break;
+        case 6: gather_i8_kernel<6><<<g, 256, 0, s>>>(n, ld, L, key, X, dlut); break;
+        case 7: gather_i8_kernel<7><<<g, 256, 0, s>>>(n, ld, L, key, X, dlut); break;
+        default: gather_i8_kernel<8><<<g, 256, 0, s>>>(n, ld, L, key, X, dlut); break;
     }
 }
 

@@ -77,7 +77,7 @@ void launch_clamp_round(hipStream_t s, int64_t len, double* a, double atol, doub
 // int8 / f32 channel matrices, padded to ld (>= n, multiple of 16), zero in the padding.
 // X[t] is at X + t*ld*ld.
 void launch_gather_i8(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                      uint64_t key, int8_t* X);
+                      uint64_t key, int8_t* X, int64_t dmax = 0);
 void launch_gather_f32(hipStream_t s, int64_t n, int64_t ld, int T, int vmax, const uint32_t* L,
                        uint64_t key, float* X);
 void launch_gather_f64_padded(hipStream_t s, int64_t n, int64_t ld, const uint32_t* L,
