@@ -468,3 +468,36 @@ def test_nonsymmetric_partition_rejected_by_both_drivers(pkg, gpu_ctx):
     Ls = np.array([[1, 2], [2, 1]], dtype=np.uint32)
     bd = pkg.blockDiagonalize(pkg.Partition(2, Ls), ctx=gpu_ctx, retries=50)
     assert sorted(bd.blkSizes) == [1, 1]
+
+
+@pytest.mark.gpu
+def test_seed_and_external_stream(pkg, problems, golden):
+    """sdpsr_set_seed reproduces / changes the draws; sdpsr_set_stream runs everything (including
+    the compression driver with its side stream) on a caller-owned HIP stream."""
+    import torch
+    L = golden["er5_P"]
+    P = pkg.Partition(int(L.max()), L.copy())
+    with pkg.Context(seed=1) as ctx:
+        ctx.set_seed(123)
+        a = pkg.randomize(P, ctx=ctx)
+        ctx.set_seed(123)
+        b = pkg.randomize(P, ctx=ctx)
+        ctx.set_seed(124)
+        c = pkg.randomize(P, ctx=ctx)
+        assert np.array_equal(a, b) and not np.array_equal(a, c)
+        # same class -> same value, zero class -> 0.0 (src/abstract_part.jl:107-110)
+        for lbl in range(1, P.nparts + 1):
+            assert np.unique(a[L == lbl]).size == 1
+    stream = torch.cuda.Stream()
+    with pkg.Context(seed=5) as ctx:
+        ctx.set_stream(stream.cuda_stream)
+        Cv, A, bb = problems.theta_prime_problem(problems.er_graph_adjacency(5))
+        Pe = pkg.admissible_subspace(Cv, A, bb, ctx=ctx)
+        assert np.array_equal(Pe.matrix, golden["er5_P"])
+        Ls, d = problems.synthetic_jordan_partition(1024, seed=2)
+        bd = pkg.blockDiagonalize(pkg.Partition(d, Ls.astype(np.uint32)), ctx=ctx)
+        assert len(bd.blkSizes) == d and set(bd.blkSizes) == {1}
+        ctx.synchronize()
+        ctx.set_stream(0)  # back to the ctx's own stream
+        bd2 = pkg.blockDiagonalize(pkg.Partition(int(L.max()), L.copy()), ctx=ctx)
+        assert sorted(bd2.blkSizes) == list(golden["er5_blk"])
