@@ -501,3 +501,30 @@ def test_seed_and_external_stream(pkg, problems, golden):
         ctx.set_stream(0)  # back to the ctx's own stream
         bd2 = pkg.blockDiagonalize(pkg.Partition(int(L.max()), L.copy()), ctx=ctx)
         assert sorted(bd2.blkSizes) == list(golden["er5_blk"])
+
+
+@pytest.mark.gpu
+def test_error_paths(pkg, problems, golden):
+    """Status codes that mirror the reference's exceptions / guards: NOT_CONVERGED when the
+    iteration cap is hit, BAD_STATE for block_images without a decomposition, a library exception
+    (DimensionMismatch / NumericalInconsistency, src/diagonalize.jl:4-9,
+    src/eigen_decomposition.jl:264-270) for a symmetric partition that is not an algebra --
+    and the ctx stays usable after each of them."""
+    Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(7))
+    with pkg.Context(seed=3, max_iters=1) as ctx:
+        with pytest.raises(pkg.NotConverged):
+            pkg.admissible_subspace(Cv, A, b, ctx=ctx)  # ER(7) needs 5 iterations
+    with pkg.Context(seed=3) as ctx:
+        lib = ctx._lib
+        buf = np.zeros(4)
+        st = lib.sdpsr_block_images(ctx._h, C.c_void_p(buf.ctypes.data), None, None, pkg.MEM_HOST)
+        assert st == 10 and b"sdpsr_block_diagonalize" in lib.sdpsr_last_error(ctx._h)
+        rng = np.random.default_rng(2)
+        n = 40
+        M = rng.integers(1, 4, size=(n, n))
+        M = np.triu(M) + np.triu(M, 1).T  # symmetric, 3 classes, not closed under products
+        with pytest.raises((pkg.DimensionMismatch, pkg.NumericalInconsistency)):
+            pkg.blockDiagonalize(pkg.Partition(3, M.astype(np.uint32)), ctx=ctx)
+        L = golden["er3_P"]
+        bd = pkg.blockDiagonalize(pkg.Partition(int(L.max()), L.copy()), ctx=ctx)
+        assert sorted(bd.blkSizes) == list(golden["er3_blk"])
