@@ -812,7 +812,10 @@ void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* la
                                                                    ws.tab_min, ws.counters);
     const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
     const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
-    const int g = (int)(nchunk < 256 * 5 ? nchunk : 256 * 5);
+    // 116 VGPRs + 32 KiB of LDS: four workgroups are resident per CU; with few classes (LDS-level
+    // work) launch exactly one round of resident workgroups -- a fifth per CU would run alone
+    const int per_cu = (ws.log2cap <= 16) ? 4 : 5;  // many classes: bound by the global table, a few more workgroups help
+    const int g = (int)(nchunk < 256 * per_cu ? nchunk : 256 * per_cu);
     refine_insert_kernel<<<g, REFINE_THREADS, 0, s>>>(len, sig, labels_out,
                                                       (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                       (uint32_t)(cap - 1), ws.counters);
