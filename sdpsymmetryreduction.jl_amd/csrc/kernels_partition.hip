@@ -450,7 +450,11 @@ static inline dim3 column_grid(int64_t n) {
     int64_t gx = (n + 1023) / 1024;  // ~4 rows per thread
     if (gx < 1) gx = 1;
     if (gx > 64) gx = 64;
-    return dim3((unsigned)gx, (unsigned)(n < 65535 ? n : 65535));
+    // one round of resident workgroups (8 per CU): the kernel strides over the columns
+    int64_t gy = (256 * 8) / gx;
+    if (gy < 1) gy = 1;
+    if (gy > n) gy = n;
+    return dim3((unsigned)gx, (unsigned)gy);
 }
 void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
                     const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag, int packed) {
