@@ -17,8 +17,12 @@
  *    (SDPSR_MEM_HOST: caller-owned host memory, copied by the library;
  *     SDPSR_MEM_DEVICE: device pointers on ctx's device, used in place);
  *  - scalar outputs (int64_t* etc.) are always host pointers;
- *  - calls on one ctx are serialised on ctx's HIP stream; distinct ctxs may be
- *    used from distinct host threads; no global state; no callbacks;
+ *  - calls on one ctx are serialised on ctx's HIP stream; distinct ctxs (on the same or on
+ *    different devices) may be used from distinct host threads; no global state; no callbacks;
+ *  - ordering of SDPSR_MEM_DEVICE arguments: inputs must be complete when the call is made, or
+ *    be produced on a stream that ctx has been told about (sdpsr_set_stream, or
+ *    sdpsr_wait_stream right before the call); on return from EVERY entry point the outputs
+ *    are complete (the call synchronises ctx's stream before it returns);
  *  - return value: sdpsr_status; details via sdpsr_last_error(ctx).
  */
 #ifndef SDPSR_H
@@ -106,6 +110,10 @@ int sdpsr_version(void);
 /* Use an existing HIP stream (hipStream_t) for all work of ctx; NULL = ctx's own. */
 int sdpsr_set_stream(sdpsr_ctx* ctx, void* hip_stream);
 int sdpsr_synchronize(sdpsr_ctx* ctx);
+/* Make all later work of ctx wait for what has been submitted to `hip_stream` (hipStream_t,
+   NULL = the legacy default stream) so far: event record + hipStreamWaitEvent, no host wait.
+   For device-resident arguments produced by the caller's own kernels. */
+int sdpsr_wait_stream(sdpsr_ctx* ctx, void* hip_stream);
 /* Reseed (tests; independent restarts use distinct seeds per rank). */
 int sdpsr_set_seed(sdpsr_ctx* ctx, uint64_t seed);
 
@@ -134,8 +142,12 @@ int sdpsr_fill(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, const double
 /* randomize!(M, P), src/abstract_part.jl:107-110: one uniform [0,1) draw per class from
    the ctx's counter-based generator (a fresh stream per call). */
 int sdpsr_randomize(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, double* M, int mem);
-/* _clamp_round!, src/utils.jl:34-53 with round-to-nearest on the 7-digit mantissa
-   (DESIGN.md "rounding"); in place. */
+/* _clamp_round!, src/utils.jl:34-53; in place.  BEHAVIOURAL DIFFERENCE a Julia caller will
+   see: the reference TRUNCATES the 7-digit decimal mantissa (unsafe_trunc, src/utils.jl:49-53),
+   this library rounds it TO NEAREST.  Values that sit on a truncation edge (0.0625 = 0.5 * 2^-3)
+   are split into two classes by last-bit noise under truncation (esc16j: 10712 classes instead
+   of the pinned 150 with NumPy's projection arithmetic); nearest rounding keeps them together.
+   Results differ from Julia's only for entries within 1 ulp of such an edge. */
 int sdpsr_clamp_round(sdpsr_ctx* ctx, int64_t len, double* a, double atol, int mem);
 /* x .-= projL(x), src/partitions.jl:161 + src/utils.jl:62-66, with qr(A') folded into an
    orthonormal basis U (len x r, column-major) of rowspace(A). */
@@ -164,9 +176,10 @@ int sdpsr_gemm_tn_f64(sdpsr_ctx* ctx, int64_t m, int64_t n, int64_t k, const dou
 int sdpsr_admissible_subspace(sdpsr_ctx* ctx, int64_t n, const double* CL, const double* X0L,
                               const double* U, int64_t r, double atol, uint32_t* P_out,
                               int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem);
-/* Convenience for dense problems: does the setup stage on the host (Householder QR of A',
-   min-norm solution) and then calls the loop.  C: n^2, A: m x n^2 column-major, b: m;
-   host pointers.  P_out is in `mem_out`. */
+/* Convenience for dense problems: the setup stage (:117-142) runs on the DEVICE as well
+   (pivoted modified Gram-Schmidt with re-orthogonalisation on the rows of A in place of qr(A'),
+   C_L, min-norm x0 = U R^-T b), then the loop.  C: n^2, A: m x n^2 column-major, b: m;
+   host pointers (copied by the library).  P_out is in `mem_out`. */
 int sdpsr_admissible_subspace_dense(sdpsr_ctx* ctx, int64_t n, int64_t m, const double* C,
                                     const double* A, const double* b, double atol,
                                     uint32_t* P_out, int64_t* dim_out, int32_t* iters_out,
@@ -192,8 +205,12 @@ int sdpsr_reduce_constraints(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels
 int sdpsr_block_diagonalize(sdpsr_ctx* ctx, int64_t n, const uint32_t* P, int64_t d,
                             double epsilon, int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s,
                             double* phase_ms, int mem);
-/* blkSizes of the last successful phase 1 (host array of nblocks ints). */
+/* blkSizes of the last phase 1 that got as far as check_block_sizes (host array of nblocks ints). */
 int sdpsr_block_sizes(sdpsr_ctx* ctx, int32_t* blk_sizes);
+/* Q_hat = diagonalize(Float64, P; atol) itself (src/diagonalize.jl:25-40), n x sum_s column-major,
+   blocks side by side: available after sdpsr_block_diagonalize returned OK or
+   SDPSR_DIMENSION_MISMATCH (diagonalize does not run check_block_sizes, src/compat.jl:60 does). */
+int sdpsr_q_hat(sdpsr_ctx* ctx, double* Q_hat, int mem);
 /* Phase 2 = basis_image(Q_hat, P) (src/diagonalize.jl:64-89).
    blks: d * sum_sq doubles, class-major, then block, each block column-major s_k x s_k.
    Q_hat (optional, may be NULL): n x sum_s column-major, blocks side by side. */

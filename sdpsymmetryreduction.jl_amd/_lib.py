@@ -63,6 +63,7 @@ def load_library():
         "sdpsr_version": (C.c_int, []),
         "sdpsr_set_stream": (C.c_int, [vp, vp]),
         "sdpsr_synchronize": (C.c_int, [vp]),
+        "sdpsr_wait_stream": (C.c_int, [vp, vp]),
         "sdpsr_set_seed": (C.c_int, [vp, C.c_uint64]),
         "sdpsr_partition_from_f64": (C.c_int, [vp, i64, vp, vp, pi64, C.c_int]),
         "sdpsr_partition_from_u32": (C.c_int, [vp, i64, vp, vp, pi64, C.c_int]),
@@ -82,6 +83,7 @@ def load_library():
         "sdpsr_desymmetrize": (C.c_int, [vp, i64, vp, pi64, pi32, C.c_int]),
         "sdpsr_block_diagonalize": (C.c_int, [vp, i64, vp, i64, dbl, pi32, pi64, pi64, vp, C.c_int]),
         "sdpsr_block_sizes": (C.c_int, [vp, vp]),
+        "sdpsr_q_hat": (C.c_int, [vp, vp, C.c_int]),
         "sdpsr_block_images": (C.c_int, [vp, vp, vp, vp, C.c_int]),
         "sdpsr_eigen_decomposition": (C.c_int, [vp, i64, vp, i64, dbl, pi32, pi32, C.c_int]),
         "sdpsr_syev_f64": (C.c_int, [vp, i64, vp, vp, vp, C.c_int]),

@@ -116,6 +116,16 @@ class Context:
     def synchronize(self):
         self.check(self._lib.sdpsr_synchronize(self._h))
 
+    def wait_for(self, *arrays):
+        """Order ctx's stream behind torch's current stream when any argument is a CUDA tensor
+        (it may have been produced by a kernel that is still running): sdpsr_wait_stream."""
+        for a in arrays:
+            if _is_torch(a) and a.is_cuda:
+                import torch
+                sp = torch.cuda.current_stream(a.device).cuda_stream
+                self.check(self._lib.sdpsr_wait_stream(self._h, C.c_void_p(sp)))
+                return
+
 
 _default_ctx = None
 
@@ -205,6 +215,7 @@ def partition_checksum(P, ctx=None):
     else:
         lab, mem = np.ascontiguousarray(P, dtype=np.uint32).ravel(), L.MEM_HOST
     n_entries = lab.numel() if _is_torch(lab) else lab.size
+    ctx.wait_for(lab)
     out = (C.c_uint64 * 2)()
     ctx.check(ctx._lib.sdpsr_partition_checksum(ctx._h, n_entries, _ptr(lab), C.cast(out, C.c_void_p), mem))
     return int(out[0]), int(out[1])
@@ -329,6 +340,7 @@ def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, se
     d = C.c_int64(0)
     it = C.c_int32(0)
     ms = (C.c_double * L.T_COUNT)()
+    ctx.wait_for(CL, X0L, U)
     st = ctx._lib.sdpsr_admissible_subspace(
         ctx._h, n, _ptr(CL), _ptr(X0L), _ptr(U) if r > 0 else None, r, float(atol), _ptr(P),
         C.byref(d), C.byref(it), C.cast(ms, C.c_void_p), L.MEM_DEVICE if on_dev else L.MEM_HOST)
@@ -408,6 +420,7 @@ def blockDiagonalize(P, verbose=False, epsilon=RTOL_DEFAULT, complex=False, ctx=
                 print(f"[sdpsr] blockDiagonalize attempt {attempt + 1} failed ({type(e).__name__}); retrying")
     n = P.shape[0]
     lab, mem = _labels_arg(P)
+    ctx.wait_for(lab)
     nb = C.c_int32(0)
     ssq = C.c_int64(0)
     ss = C.c_int64(0)
@@ -441,23 +454,30 @@ def blockDiagonalize(P, verbose=False, epsilon=RTOL_DEFAULT, complex=False, ctx=
 
 
 def diagonalize(P, atol=None, ctx=None):
-    """``diagonalize(Float64, P; atol)`` (src/diagonalize.jl:25-40): list of n x s_k."""
+    """``diagonalize(Float64, P; atol)`` (src/diagonalize.jl:25-40): ``Q_hat``, a list of
+    n x s_k matrices (one column per merged eigenspace of an isomorphism class)."""
     n = P.shape[0]
     atol = 1e-12 * n if atol is None else atol
     ctx = _ctx(ctx)
     lab, mem = _labels_arg(P)
+    ctx.wait_for(lab)
     nb = C.c_int32(0)
     ssq = C.c_int64(0)
     ss = C.c_int64(0)
     st = ctx._lib.sdpsr_block_diagonalize(ctx._h, n, _ptr(lab), P.nparts, float(atol), C.byref(nb),
                                           C.byref(ssq), C.byref(ss), None, mem)
-    if st == 3:
-        st = 0  # diagonalize itself does not run check_block_sizes (src/compat.jl:60 does)
-        ctx_valid = False
-    ctx.check(st)
+    if st != 3:  # diagonalize itself does not run check_block_sizes (src/compat.jl:60 does)
+        ctx.check(st)
     sizes = np.zeros(nb.value, dtype=np.int32)
     ctx.check(ctx._lib.sdpsr_block_sizes(ctx._h, _ptr(sizes)))
-    return [int(s) for s in sizes]
+    qh = np.empty(n * ss.value, dtype=np.float64)
+    ctx.check(ctx._lib.sdpsr_q_hat(ctx._h, _ptr(qh), L.MEM_HOST))
+    qh = qh.reshape(n, ss.value, order="F")
+    Q, off = [], 0
+    for s in sizes:
+        Q.append(qh[:, off:off + s])
+        off += s
+    return Q
 
 
 def eigen_decomposition(P, atol=None, ctx=None):
@@ -467,6 +487,7 @@ def eigen_decomposition(P, atol=None, ctx=None):
     atol = 1e-12 * n if atol is None else atol
     ctx = _ctx(ctx)
     lab, mem = _labels_arg(P)
+    ctx.wait_for(lab)
     ne = C.c_int32(0)
     nc = C.c_int32(0)
     ctx.check(ctx._lib.sdpsr_eigen_decomposition(ctx._h, n, _ptr(lab), P.nparts, float(atol), C.byref(ne), C.byref(nc), mem))

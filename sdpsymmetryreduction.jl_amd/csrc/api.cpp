@@ -129,8 +129,9 @@ T* out_dev(sdpsr_ctx* c, const char* name, T* p, size_t count, int mem, int* st)
 
 template <typename T>
 int out_finish(sdpsr_ctx* c, T* host, const T* dev, size_t count, int mem) {
-    if (mem == SDPSR_MEM_DEVICE) return SDPSR_OK;
-    HIP_TRY(c, hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    // outputs are complete on return in both memory spaces (ordering rule of sdpsr.h)
+    if (mem != SDPSR_MEM_DEVICE)
+        HIP_TRY(c, hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SDPSR_OK;
 }
@@ -269,7 +270,8 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
         ws.nblk = (int)nblk;
         ws.expect_small = (!mispredicted && c->table_log2_hint <= 12) ? 1 : 0;  // hint 12 <=> last dim <= 512
         launch_refine(c->stream, len, sig, labels, ws);
-        uint32_t* h = (uint32_t*)c->pinned;
+        uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
+        if (!h) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
         HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         if (sym_n > 0 && symflag_dev) {
             launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);  // flag = 1 if NOT symmetric
@@ -356,6 +358,17 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
         return SDPSR_HIP_ERROR;
     }
     c->own_stream = true;
+    // per-device kernel attributes (dynamic LDS above 64 KiB); cheap and idempotent
+    gemm_set_device_attributes();
+    blockdiag_set_device_attributes();
+    partition_set_device_attributes();
+    sytrd_set_device_attributes();
+    small_syev_set_device_attributes();
+    if (hipGetLastError() != hipSuccess) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return SDPSR_HIP_ERROR;
+    }
     c->pinned_bytes = 1 << 16;
     if (hipHostMalloc((void**)&c->pinned_small, 256, hipHostMallocDefault) != hipSuccess) c->pinned_small = nullptr;
     if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
@@ -372,6 +385,7 @@ void sdpsr_destroy(sdpsr_ctx* c) {
     DeviceGuard dg(c->device);
     hipStreamSynchronize(c->stream);
     destroy_handle(c);
+    sytrd_graph_cache_destroy(c->sytrd_graphs);
     for (auto& kv : c->bufs)
         if (kv.second.p) hipFree(kv.second.p);
     if (c->pinned) hipHostFree(c->pinned);
@@ -379,6 +393,7 @@ void sdpsr_destroy(sdpsr_ctx* c) {
     if (c->pinned_small) hipHostFree(c->pinned_small);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_wait) hipEventDestroy(c->ev_wait);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -403,6 +418,15 @@ int sdpsr_set_stream(sdpsr_ctx* c, void* hip_stream) {
 int sdpsr_synchronize(sdpsr_ctx* c) {
     CHECK_CTX(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDPSR_OK;
+}
+
+int sdpsr_wait_stream(sdpsr_ctx* c, void* hip_stream) {
+    CHECK_CTX(c);
+    if ((hipStream_t)hip_stream == c->stream) return SDPSR_OK;
+    if (!c->ev_wait) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_wait, (hipStream_t)hip_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_wait, 0));
     return SDPSR_OK;
 }
 
@@ -489,9 +513,17 @@ int sdpsr_fill(sdpsr_ctx* c, int64_t len, const uint32_t* labels, const double* 
     const double* dV = in_dev(c, "prim_in_b", values, (size_t)std::max<int64_t>(d, 1), mem, &st);
     double* dM = out_dev(c, "prim_out", M, len, mem, &st);
     if (st) return st;
-    launch_fill_f64(c->stream, len, dL, dV, dM);
+    // labels beyond d never index `values` (the kernel writes 0.0 there and raises the flag)
+    uint32_t* flag = (uint32_t*)ctx_buf(c, "prim_flag", 64);
+    if (!flag || !c->pinned_small) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemsetAsync(flag, 0, 4, c->stream));
+    launch_fill_f64(c->stream, len, dL, dV, d, dM, flag);
     HIP_TRY(c, hipGetLastError());
-    return out_finish(c, M, dM, len, mem);
+    HIP_TRY(c, hipMemcpyAsync(c->pinned_small, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    st = out_finish(c, M, dM, len, mem);
+    if (st) return st;
+    if (c->pinned_small[0]) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "fill: a label exceeds d = length(values)");
+    return SDPSR_OK;
 }
 
 int sdpsr_randomize(sdpsr_ctx* c, int64_t len, const uint32_t* labels, double* M, int mem) {
@@ -1210,30 +1242,11 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
 }
 
 
-// ===========================================================================
-// Krylov driver of diagonalize (DESIGN.md "Krylov driver").
-//
-// A generic element A1 of the algebra has k = sum_k s_k distinct eigenvalues.  Everything
-// src/eigen_decomposition.jl:236-348 takes from eigen(A1) is (i) the distinct eigenvalues,
-// (ii) which eigenspaces are coupled by a second generic element (Q'A2Q block norms), (iii) one
-// unit vector per eigenspace and its images under a third generic element.  A Lanczos
-// process with full re-orthogonalisation from a random start breaks down after exactly k
-// steps; its Ritz pairs are the eigenvalues and one generic unit vector u_c = P_c x / |P_c x| of
-// every eigenspace.  The coupling matrix is U' A2 U (k x k), and the class members' columns
-// P_j A3 u_r / |.| are the Ritz vectors of short Lanczos runs started from A3 u_r (they break
-// down after s_r = size of the class steps).  Cost: k + max s_r passes over an n x n matrix
-// instead of a 4/3 n^3 tridiagonalisation.  Falls back to the dense driver (return value
-// KRYLOV_FALLBACK) when k is not small, two Ritz values are closer than atol, or a run does
-// not break down where it should.
-// ===========================================================================
-constexpr int KRYLOV_FALLBACK = -1000;
+// status used internally when a driver of diagonalize hands over to the dense one
+constexpr int DRIVER_FALLBACK = -1000;
 
 }  // namespace
 namespace sdpsr {
-void launch_sym_gemv(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* x, double* y);
-void launch_lanczos_orth(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const int* tcur,
-                         double* W, int64_t ldw, const int* active, int nruns, double* alpha_out, double* beta_out,
-                         double* nin_out);
 void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B);
 void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
 size_t label_spmm_partial_doubles(int64_t n, int w);
@@ -1246,337 +1259,18 @@ void launch_col_norms2(hipStream_t s, int64_t len, int64_t k, const double* V, d
 void launch_scale_copy(hipStream_t s, int64_t len, const double* v, double alpha, double* out);
 void launch_rank1_update(hipStream_t s, int64_t len, int64_t m, double* R, const double* u, const double* dots);
 void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double* b, double atol, double scale, double* out);
-void launch_lanczos_init(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const double* X,
+void launch_normalize_columns(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const double* X,
                          int64_t ldx, int nruns, double* norm0);
-void launch_lanczos_pack(hipStream_t s, int64_t n, int64_t ld, const double* H, int64_t hstride, const int* tcur,
-                         const int* active, int nruns, double* V, int64_t ldv);
-void launch_ritz_combine(hipStream_t s, int64_t n, int64_t ld, const double* H, int64_t hstride, const int* run,
-                         const int* kk, const double* S, int lds_, int ncols, double* out, int64_t ldo);
 void launch_random_vector(hipStream_t s, int64_t n, uint64_t key, double* x);
 }
 namespace {
 
-// symmetric tridiagonal eigenproblem (implicit QL, EISPACK tql2 scheme): d[k], e[k-1] ->
-// ascending eigenvalues in d, eigenvectors in the columns of Z (k x k, column-major).
-bool tridiag_eig(std::vector<double>& d, std::vector<double> e, std::vector<double>& Z) {
-    const int k = (int)d.size();
-    Z.assign((size_t)k * k, 0.0);
-    for (int i = 0; i < k; ++i) Z[(size_t)i * k + i] = 1.0;
-    if (k == 1) return true;
-    e.resize(k, 0.0);
-    for (int l = 0; l < k; ++l) {
-        int iter = 0;
-        for (;;) {
-            int m = l;
-            for (; m < k - 1; ++m) {
-                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
-                if (std::fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
-            }
-            if (m == l) break;
-            if (++iter > 60) return false;
-            double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-            double r = std::hypot(g, 1.0);
-            g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
-            double sn = 1.0, cs = 1.0, p = 0.0;
-            int i = m - 1;
-            for (; i >= l; --i) {
-                double f = sn * e[i], b = cs * e[i];
-                r = std::hypot(f, g);
-                e[i + 1] = r;
-                if (r == 0.0) {
-                    d[i + 1] -= p;
-                    e[m] = 0.0;
-                    break;
-                }
-                sn = f / r;
-                cs = g / r;
-                g = d[i + 1] - p;
-                r = (d[i] - g) * sn + 2.0 * cs * b;
-                p = sn * r;
-                d[i + 1] = g + p;
-                g = cs * r - b;
-                for (int q = 0; q < k; ++q) {
-                    f = Z[(size_t)(i + 1) * k + q];
-                    Z[(size_t)(i + 1) * k + q] = sn * Z[(size_t)i * k + q] + cs * f;
-                    Z[(size_t)i * k + q] = cs * Z[(size_t)i * k + q] - sn * f;
-                }
-            }
-            if (r == 0.0 && i >= l) continue;
-            d[l] -= p;
-            e[l] = g;
-            e[m] = 0.0;
-        }
-    }
-    // sort ascending (selection sort on columns)
-    for (int i = 0; i < k - 1; ++i) {
-        int mi = i;
-        for (int j = i + 1; j < k; ++j)
-            if (d[j] < d[mi]) mi = j;
-        if (mi != i) {
-            std::swap(d[i], d[mi]);
-            for (int q = 0; q < k; ++q) std::swap(Z[(size_t)i * k + q], Z[(size_t)mi * k + q]);
-        }
-    }
-    return true;
-}
-
-struct LanczosRun {
-    std::vector<double> alpha, beta;  // T: alpha[0..k-1], beta[0..k-2]
-    double norm0 = 0;
-    bool broke_down = false;
-};
-
-// nruns Lanczos processes on the symmetric A (n x n, ld) from the columns of X (n x nruns, ldx).
-// History H: nruns * hstride doubles, hstride = ld * (cap + 1).  W/Vp: ld x round_up(nruns,128).
-int batched_lanczos(sdpsr_ctx* c, int64_t n, int64_t ld, const double* A, const double* X, int64_t ldx, int nruns,
-                    int cap, double tol, double* H, int64_t hstride, std::vector<LanczosRun>& runs) {
-    hipStream_t s = c->stream;
-    const int64_t np = round_up(nruns, 128);
-    double* Vp = (double*)ctx_buf(c, "kr_vp", (size_t)ld * np * 8);
-    double* Wp = (double*)ctx_buf(c, "kr_wp", (size_t)ld * np * 8);
-    int* d_t = (int*)ctx_buf(c, "kr_t", (size_t)nruns * 4);
-    int* d_act = (int*)ctx_buf(c, "kr_act", (size_t)nruns * 4);
-    double* d_ab = (double*)ctx_buf(c, "kr_ab", (size_t)nruns * 3 * 8);
-    if (!Vp || !Wp || !d_t || !d_act || !d_ab) return SDPSR_OUT_OF_MEMORY;
-    runs.assign(nruns, LanczosRun());
-    std::vector<int> tcur(nruns, 0), active(nruns, 1);
-    std::vector<double> hab((size_t)nruns * 3), scale(nruns, 0.0);
-    launch_lanczos_init(s, n, ld, H, hstride, X, ldx, nruns, d_ab + 2 * nruns);
-    if (nruns > 1) HIP_TRY(c, hipMemsetAsync(Vp, 0, (size_t)ld * np * 8, s));
-    int nactive = nruns;
-    for (int t = 0; t < cap && nactive > 0; ++t) {
-        HIP_TRY(c, hipMemcpyAsync(d_t, tcur.data(), nruns * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(d_act, active.data(), nruns * 4, hipMemcpyHostToDevice, s));
-        if (nruns == 1) {
-            launch_sym_gemv(s, n, ld, A, H + (int64_t)t * ld, Wp);
-        } else {
-            launch_lanczos_pack(s, n, ld, H, hstride, d_t, d_act, nruns, Vp, ld);
-            launch_gemm_tn_f64(s, ld, np, ld, A, ld, Vp, ld, Wp, ld, 1, 0, 0, 0);  // W = A V (A symmetric)
-        }
-        launch_lanczos_orth(s, n, ld, H, hstride, d_t, Wp, ld, d_act, nruns, d_ab, d_ab + nruns, nullptr);
-        HIP_TRY(c, hipMemcpyAsync(hab.data(), d_ab, (size_t)nruns * 3 * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        for (int r = 0; r < nruns; ++r) {
-            if (!active[r]) continue;
-            if (t == 0) runs[r].norm0 = hab[2 * nruns + r];
-            const double al = hab[r], be = hab[nruns + r];
-            if (getenv("SDPSR_DEBUG") && r == 0) fprintf(stderr, "[sdpsr] lanczos t=%d alpha=%.6e beta=%.6e\n", t, al, be);
-            runs[r].alpha.push_back(al);
-            scale[r] = std::max(scale[r], std::max(std::fabs(al), be));
-            if (!(be > tol * scale[r])) {  // invariant subspace reached
-                runs[r].broke_down = true;
-                active[r] = 0;
-                --nactive;
-            } else if (t + 1 >= cap) {
-                active[r] = 0;
-                --nactive;
-            } else {
-                runs[r].beta.push_back(be);
-                tcur[r] = t + 1;
-            }
-        }
-    }
-    HIP_TRY(c, hipGetLastError());
-    return SDPSR_OK;
-}
-
-int krylov_fallback(sdpsr_ctx* c, const std::string& why) {
-    c->err = "Krylov driver fell back to the dense eigensolver: " + why;
+int driver_fallback(sdpsr_ctx* c, const std::string& why) {
+    c->err = "driver fell back to the dense eigensolver: " + why;
     if (getenv("SDPSR_DEBUG")) fprintf(stderr, "[sdpsr] %s\n", c->err.c_str());
-    return KRYLOV_FALLBACK;
+    return DRIVER_FALLBACK;
 }
 
-// On success: info (vals = distinct eigenvalues, ptrs = 0..k, kpart), Qhat device buffer filled
-// (n x S1, class order), sizes.  KRYLOV_FALLBACK -> use the dense driver.
-int krylov_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d, double atol, EigInfo& info,
-                       std::vector<int32_t>& sizes, int64_t* S1_out, int64_t* S_out, bool want_qhat,
-                       PhaseTimer& tm) {
-    hipStream_t s = c->stream;
-    const int64_t ld = round_up(n, 128);
-    int kmax = (int)std::min<int64_t>(256, n / 4);
-    if (d + 1 < kmax) kmax = (int)d + 1;  // k <= dim(P)
-    if (kmax < 2) return krylov_fallback(c, "kmax < 2");
-    uint32_t* flag = (uint32_t*)ctx_buf(c, "bd_flag", 64);
-    double* A1 = (double*)ctx_buf(c, "bd_q", (size_t)ld * ld * 8);
-    double* A2 = (double*)ctx_buf(c, "bd_a", (size_t)ld * ld * 8);
-    const int64_t hstride1 = ld * (int64_t)(kmax + 2);
-    double* H1 = (double*)ctx_buf(c, "kr_h1", (size_t)hstride1 * 8);
-    double* x0 = (double*)ctx_buf(c, "kr_x0", (size_t)ld * 8);
-    if (!flag || !A1 || !A2 || !H1 || !x0) return SDPSR_OUT_OF_MEMORY;
-    launch_check_symmetric(s, n, L, flag);
-    uint32_t* hflag = (uint32_t*)c->pinned;
-    HIP_TRY(c, hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (hflag[0]) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
-                                  "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
-    // --- (i) eigenvalues + one unit vector per eigenspace -------------------------------
-    tm.begin(SDPSR_T_EIGEN);
-    const uint64_t key1 = next_key(c);
-    launch_gather_f64_padded(s, n, ld, L, key1, A1);
-    launch_random_vector(s, n, next_key(c), x0);
-    std::vector<LanczosRun> r1;
-    int st = batched_lanczos(c, n, ld, A1, x0, ld, 1, kmax, 1e-7, H1, hstride1, r1);
-    tm.end();
-    if (st) return st;
-    tm.collect();
-    if (!r1[0].broke_down) return krylov_fallback(c, "no Lanczos breakdown within kmax steps (many distinct eigenvalues)");
-    const int k = (int)r1[0].alpha.size();
-    std::vector<double> theta = r1[0].alpha, Z;
-    if (!tridiag_eig(theta, r1[0].beta, Z)) return krylov_fallback(c, "tridiagonal QL did not converge");
-    for (int i = 0; i + 1 < k; ++i)
-        if (std::fabs(theta[i + 1] - theta[i]) <= std::max(atol, 1e-9 * std::fabs(theta[k - 1] - theta[0])))
-            return krylov_fallback(c, "two Ritz values closer than atol");
-    for (int i = 0; i < k; ++i)
-        if (std::fabs(Z[(size_t)i * k]) < 1e-7) return krylov_fallback(c, "start vector nearly misses an eigenspace");
-    info.vals = theta;
-    info.ptrs.resize(k + 1);
-    for (int i = 0; i <= k; ++i) info.ptrs[i] = i;
-    // Ritz vectors U = H1 Z  (ld x kp, zero padded)
-    tm.begin(SDPSR_T_ISO);
-    const int64_t kp = round_up(k, 128);
-    double* U = (double*)ctx_buf(c, "kr_u", (size_t)ld * kp * 8);
-    double* Zt = (double*)ctx_buf(c, "bd_t", (size_t)ld * std::max<int64_t>(kp, 128) * 8);
-    double* dS = (double*)ctx_buf(c, "kr_s", (size_t)k * k * 8);
-    int* drun = (int*)ctx_buf(c, "kr_run", (size_t)(k + 1) * 2 * 4);
-    double* G = (double*)ctx_buf(c, "kr_g", (size_t)kp * kp * 8);
-    if (!U || !Zt || !dS || !drun || !G) return SDPSR_OUT_OF_MEMORY;
-    {
-        std::vector<int> hr(2 * (size_t)k);
-        for (int i = 0; i < k; ++i) {
-            hr[i] = 0;
-            hr[k + i] = k;
-        }
-        HIP_TRY(c, hipMemsetAsync(U, 0, (size_t)ld * kp * 8, s));
-        HIP_TRY(c, hipMemcpyAsync(dS, Z.data(), (size_t)k * k * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(drun, hr.data(), (size_t)2 * k * 4, hipMemcpyHostToDevice, s));
-        launch_ritz_combine(s, n, ld, H1, hstride1, drun, drun + k, dS, k, k, U, ld);
-        HIP_TRY(c, hipStreamSynchronize(s));  // hr / Z are host temporaries
-    }
-    // --- (ii) couplings: G = U' A2 U (src/eigen_decomposition.jl:201-217 with one vector per
-    //     eigenspace; the equal-dimension filter of :185-186 is not available here) -------------
-    launch_gather_f64_padded(s, n, ld, L, next_key(c), A2);
-    launch_gemm_tn_f64(s, ld, kp, ld, A2, ld, U, ld, Zt, ld, 1, 0, 0, 0);  // Z = A2 U
-    launch_gemm_tn_f64(s, kp, kp, ld, U, ld, Zt, ld, G, kp, 1, 0, 0, 0);   // G = U' Z
-    std::vector<double> hG((size_t)kp * kp);
-    HIP_TRY(c, hipMemcpyAsync(hG.data(), G, (size_t)kp * kp * 8, hipMemcpyDeviceToHost, s));
-    tm.end();
-    HIP_TRY(c, hipStreamSynchronize(s));
-    tm.collect();
-    std::vector<double> norms((size_t)k * k);
-    for (int i = 0; i < k; ++i)
-        for (int j = i; j < k; ++j) {
-            const double v = std::max(std::fabs(hG[(size_t)i + (size_t)j * kp]), std::fabs(hG[(size_t)j + (size_t)i * kp]));
-            norms[(size_t)i * k + j] = norms[(size_t)j * k + i] = v;
-        }
-    st = isomorphism_classes(c, norms, k, atol, info.kpart);
-    if (st) return st;
-    std::vector<int> roots;
-    std::vector<std::vector<int>> members;
-    class_structure(info.kpart, roots, members);
-    sizes.resize(roots.size());
-    int64_t S1 = 0, S = 0;
-    int smax = 1;
-    for (size_t p = 0; p < roots.size(); ++p) {
-        sizes[p] = (int32_t)members[p].size();
-        S1 += sizes[p];
-        S += (int64_t)sizes[p] * sizes[p];
-        smax = std::max(smax, (int)sizes[p]);
-    }
-    *S1_out = S1;
-    *S_out = S;
-    if (!want_qhat) return SDPSR_OK;
-    // --- (iii) irreducible_decomposition (src/eigen_decomposition.jl:295-348) ------------------
-    tm.begin(SDPSR_T_IRRED);
-    double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
-    if (!Qhat) return SDPSR_OUT_OF_MEMORY;
-    std::vector<int> big;  // class positions with more than one member
-    for (size_t p = 0; p < roots.size(); ++p)
-        if (members[p].size() > 1) big.push_back((int)p);
-    const int q = (int)big.size();
-    std::vector<LanczosRun> r2;
-    double* H2 = nullptr;
-    int64_t hstride2 = 0;
-    if (q > 0) {
-        const int64_t qp = round_up(q, 128);
-        const int cap2 = smax + 2;
-        hstride2 = ld * (int64_t)(cap2 + 2);
-        H2 = (double*)ctx_buf(c, "kr_h2", (size_t)hstride2 * q * 8);
-        double* UR = (double*)ctx_buf(c, "kr_ur", (size_t)ld * qp * 8);
-        double* BR = (double*)ctx_buf(c, "kr_br", (size_t)ld * qp * 8);
-        if (!H2 || !UR || !BR) return SDPSR_OUT_OF_MEMORY;
-        HIP_TRY(c, hipMemsetAsync(UR, 0, (size_t)ld * qp * 8, s));
-        for (int b = 0; b < q; ++b)
-            HIP_TRY(c, hipMemcpyAsync(UR + (size_t)b * ld, U + (size_t)roots[big[b]] * ld, (size_t)n * 8,
-                                      hipMemcpyDeviceToDevice, s));
-        launch_gather_f64_padded(s, n, ld, L, next_key(c), A2);                 // generic element #3 (:306)
-        launch_gemm_tn_f64(s, ld, qp, ld, A2, ld, UR, ld, BR, ld, 1, 0, 0, 0);  // a_r = A3 u_r
-        st = batched_lanczos(c, n, ld, A1, BR, ld, q, cap2, 1e-7, H2, hstride2, r2);
-        if (st) return st;
-    }
-    // assemble Q_hat: root column = u_r; member j column = sign * Ritz vector of run r at theta_j
-    std::vector<int> crun, ckk;
-    std::vector<double> cS;          // one coefficient column (length lds2) per combined column
-    std::vector<int64_t> cdst;       // destination column in Qhat
-    const int lds2 = smax + 2;
-    int64_t col = 0;
-    const double vscale = std::max(std::fabs(theta[0]), std::fabs(theta[k - 1]));
-    for (size_t p = 0; p < roots.size(); ++p) {
-        HIP_TRY(c, hipMemcpyAsync(Qhat + (size_t)col * n, U + (size_t)roots[p] * ld, (size_t)n * 8,
-                                  hipMemcpyDeviceToDevice, s));  // P1 = I (:311-313, :326)
-        ++col;
-        if (members[p].size() == 1) continue;
-        const int b = (int)(std::find(big.begin(), big.end(), (int)p) - big.begin());
-        LanczosRun& run = r2[b];
-        const int kr = (int)run.alpha.size();
-        if (!run.broke_down || kr != (int)members[p].size())
-            return krylov_fallback(c, "class run: " + std::to_string(kr) + " steps, broke_down=" + std::to_string(run.broke_down) + ", class size " + std::to_string(members[p].size()));
-        std::vector<double> th = run.alpha, Zr;
-        if (!tridiag_eig(th, run.beta, Zr)) return krylov_fallback(c, "class tridiagonal QL did not converge");
-        for (size_t m = 1; m < members[p].size(); ++m) {
-            const int j = members[p][m];
-            int hit = -1;
-            for (int i = 0; i < kr; ++i)
-                if (std::fabs(th[i] - theta[j]) <= 1e-9 * vscale + 1e-12) hit = (hit < 0) ? i : -2;
-            if (hit < 0) return krylov_fallback(c, "class Ritz value does not match an eigenvalue");
-            const double sg = (Zr[(size_t)hit * kr] >= 0) ? 1.0 : -1.0;  // P_j a_r = s_0 |a_r| y
-            crun.push_back(b);
-            ckk.push_back(kr);
-            for (int t2 = 0; t2 < lds2; ++t2) cS.push_back(t2 < kr ? sg * Zr[(size_t)hit * kr + t2] : 0.0);
-            cdst.push_back(col);
-            ++col;
-        }
-    }
-    if (!crun.empty()) {
-        const int nc = (int)crun.size();
-        int* d_cr = (int*)ctx_buf(c, "kr_cr", (size_t)nc * 2 * 4);
-        double* d_cs = (double*)ctx_buf(c, "kr_cs", (size_t)nc * lds2 * 8);
-        double* tmpc = (double*)ctx_buf(c, "kr_tmpc", (size_t)n * nc * 8);
-        if (!d_cr || !d_cs || !tmpc) return SDPSR_OUT_OF_MEMORY;
-        std::vector<int> hcr(crun);
-        hcr.insert(hcr.end(), ckk.begin(), ckk.end());
-        HIP_TRY(c, hipMemcpyAsync(d_cr, hcr.data(), (size_t)nc * 2 * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(d_cs, cS.data(), (size_t)nc * lds2 * 8, hipMemcpyHostToDevice, s));
-        launch_ritz_combine(s, n, ld, H2, hstride2, d_cr, d_cr + nc, d_cs, lds2, nc, tmpc, n);
-        for (int i = 0; i < nc; ++i)
-            HIP_TRY(c, hipMemcpyAsync(Qhat + (size_t)cdst[i] * n, tmpc + (size_t)i * n, (size_t)n * 8,
-                                      hipMemcpyDeviceToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
-    launch_clamptol(s, n * S1, Qhat, atol);  // src/diagonalize.jl:39
-    tm.end();
-    HIP_TRY(c, hipGetLastError());
-    return SDPSR_OK;
-}
-
-// EXPERIMENTAL, opt-in only (eig_driver = 5).  Measured limit: the Lanczos breakdown that the
-// driver relies on is only sharp for a handful of distinct eigenvalues; with k = 45 (esc16j)
-// rounding noise amplified by the small betas hides it completely (beta_45 ~ 0.3), so the
-// default driver is always the dense one.  See DESIGN.md "Krylov driver (experimental)".
-bool krylov_eligible(const sdpsr_ctx* c, int64_t n, int64_t d) {
-    (void)n;
-    (void)d;
-    return c->opts.eig_driver == 5;
-}
 
 
 // diagonalize(Float64, P) with the dense eigensolver (src/diagonalize.jl:25-40): on success the
@@ -1712,7 +1406,7 @@ int gemm_tn_splitk(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* 
 // Q_hat of the full problem.  M is grown one vector at a time: y = A z for a fresh generic
 // element A and a random z in the current span; y is appended if it leaves the span (CGS2);
 // three consecutive misses end the growth.  Only first powers of well-scaled matrices are
-// involved (unlike the Krylov driver), so the rank decisions are sharp (eps vs O(1)).
+// involved, so the rank decisions are sharp (eps vs O(1)).
 // Cost: w passes over an n x n element + a dense w x w diagonalisation, against 4/3 n^3.
 // ===========================================================================
 int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d, double atol, EigInfo& info,
@@ -1720,7 +1414,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     hipStream_t s = c->stream;
     const int64_t ld = round_up(n, 128);
     const int wmax = (int)std::min<int64_t>(std::min<int64_t>(n / 2, 500), 2 * d + 8);
-    if (wmax < 2) return krylov_fallback(c, "module too small to compress");
+    if (wmax < 2) return driver_fallback(c, "module too small to compress");
     const int64_t wcap = round_up(wmax + 2, 128);
     const int64_t ycap = 2 * wcap;                  // candidate columns of one round
     const int64_t wtot = wcap + ycap + 128;         // basis | candidates | padding of the last tile
@@ -1762,7 +1456,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)ld * wtot * 8, s));
     double* y = zy;
     launch_random_vector(s, n, next_key(c), y);
-    launch_lanczos_init(s, n, ld, W, 0, y, ld, 1, dout);  // W[:,0] = x / |x|
+    launch_normalize_columns(s, n, ld, W, 0, y, ld, 1, dout);  // W[:,0] = x / |x|
     int w = 1;
     // Block growth.  The candidates of a round (class sums of x, then A_g W for G fresh generic
     // elements) are written right behind the basis, Y = W[:, w : w+m), so that ONE split-K MFMA
@@ -1893,7 +1587,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         first_product_intact = (r_new == 0);  // Cc still holds [W Y]'Y (no second product ran)
         if (r_new <= 0) return r_new;
         if (w + r_new >= wmax) {
-            abs_err = krylov_fallback(c, "module dimension exceeds " + std::to_string(wmax));
+            abs_err = driver_fallback(c, "module dimension exceeds " + std::to_string(wmax));
             return -1;
         }
         abs_err = apply_stacked(m, r_new, st1);
@@ -1918,6 +1612,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         }
     }
     bool have_saved = false;
+    bool module_complete = false;  // an invariance round added nothing
     int64_t saved_ld = 0;
     for (int round = 0; round < 40; ++round) {
         const bool fused = (w <= 64 && d <= 4000);
@@ -1942,6 +1637,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             return abs_err;
         }
         if (got == 0) {
+            module_complete = true;
             // the module is complete: the top block of this round's product, C = W' (A W), IS the
             // compressed generic element W' A W of the round's first element -- keep it for the
             // eigen stage instead of forming another one (one label product + one GEMM saved)
@@ -1949,6 +1645,11 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             have_saved = first_product_intact;  // not if noise-level candidates went through the second step
             break;
         }
+    }
+    if (!module_complete) {  // never diagonalise a module that no round has confirmed invariant
+        tm.end();
+        tm.collect();
+        return driver_fallback(c, "module growth did not close within 40 rounds");
     }
     // columns >= w must be zero for the padded products below
     const int64_t wp = round_up(w, 128);
@@ -2027,7 +1728,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
 }
 
 // eig_driver: 0 auto (module compression when dim(P) is small against n, dense otherwise),
-// 4 dense forced, 5 experimental Krylov, 6 module compression forced, 1-3 rocSOLVER variants.
+// 4 dense forced, 6 module compression forced, 1-3 rocSOLVER variants (comparison only).
 bool compression_eligible(const sdpsr_ctx* c, int64_t n, int64_t d) {
     if (c->opts.eig_driver == 6) return true;
     if (c->opts.eig_driver != 0) return false;
@@ -2050,16 +1751,7 @@ int sdpsr_eigen_decomposition(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_
     c->bd_valid = false;
     EigInfo info;
     PhaseTimer tm(c, false);
-    st = KRYLOV_FALLBACK;
-    if (krylov_eligible(c, n, d)) {
-        std::vector<int32_t> sz;
-        int64_t a1 = 0, a2 = 0;
-        st = krylov_diagonalize(c, n, L, d, atol, info, sz, &a1, &a2, false, tm);
-    }
-    if (st == KRYLOV_FALLBACK) {
-        if (c->opts.eig_driver == 5) return ctx_fail(c, SDPSR_SOLVER_ERROR, "Krylov driver not applicable to this partition (" + c->err + ")");
-        st = eigen_decomposition_device(c, n, L, atol, info, tm);
-    }
+    st = eigen_decomposition_device(c, n, L, atol, info, tm);
     if (st) return st;
     if (neig) *neig = (int32_t)info.ptrs.size() - 1;
     if (nclasses) {
@@ -2080,6 +1772,7 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
     if (st) return st;
     hipStream_t s = c->stream;
     c->bd_valid = false;
+    c->bd_q_valid = false;
     PhaseTimer tm(c, phase_ms != nullptr);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (phase_ms) {
@@ -2100,17 +1793,15 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
     EigInfo info;
     std::vector<int32_t> sizes;
     int64_t S1 = 0, S = 0;
-    st = KRYLOV_FALLBACK;
-    if (krylov_eligible(c, n, d)) st = krylov_diagonalize(c, n, L, d, atol, info, sizes, &S1, &S, true, tm);
-    else if (compression_eligible(c, n, d)) st = compressed_diagonalize(c, n, L, d, atol, info, sizes, S1, S, tm);
-    if (st == KRYLOV_FALLBACK && (c->opts.eig_driver == 5 || c->opts.eig_driver == 6))
+    st = DRIVER_FALLBACK;
+    if (compression_eligible(c, n, d)) st = compressed_diagonalize(c, n, L, d, atol, info, sizes, S1, S, tm);
+    if (st == DRIVER_FALLBACK && c->opts.eig_driver == 6)
         return ctx_fail(c, SDPSR_SOLVER_ERROR, "requested driver not applicable to this partition (" + c->err + ")");
-    const bool used_krylov = (st == SDPSR_OK);
-    if (st != SDPSR_OK && st != KRYLOV_FALLBACK) return st;
-  if (!used_krylov) {
-    st = dense_diagonalize(c, n, L, nullptr, atol, info, sizes, S1, S, tm);
-    if (st) return st;
-  }
+    if (st != SDPSR_OK && st != DRIVER_FALLBACK) return st;
+    if (st == DRIVER_FALLBACK) {
+        st = dense_diagonalize(c, n, L, nullptr, atol, info, sizes, S1, S, tm);
+        if (st) return st;
+    }
 
     dbg_mark("block_diagonalize: diagonalize done");
     // check_block_sizes (src/diagonalize.jl:1-11)
@@ -2121,6 +1812,7 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
     c->bd_sizes = sizes;
     c->bd_sum_s = S1;
     c->bd_sum_sq = S;
+    c->bd_q_valid = true;
     if (nblocks) *nblocks = (int32_t)sizes.size();
     if (sum_sq) *sum_sq = S;
     if (sum_s) *sum_s = S1;
@@ -2152,6 +1844,19 @@ int sdpsr_block_sizes(sdpsr_ctx* c, int32_t* blk_sizes) {
     if (!c || !blk_sizes) return SDPSR_BAD_ARGUMENT;
     if (c->bd_sizes.empty()) return ctx_fail(c, SDPSR_BAD_STATE, "no block diagonalisation available");
     memcpy(blk_sizes, c->bd_sizes.data(), c->bd_sizes.size() * sizeof(int32_t));
+    return SDPSR_OK;
+}
+
+int sdpsr_q_hat(sdpsr_ctx* c, double* Q_hat, int mem) {
+    CHECK_CTX(c);
+    if (!c->bd_q_valid) return ctx_fail(c, SDPSR_BAD_STATE, "no diagonalisation available on this ctx");
+    if (!Q_hat) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    const size_t cnt = (size_t)c->bd_n * c->bd_sum_s;
+    double* Qhat = (double*)ctx_buf(c, "bd_qhat", cnt * 8);
+    if (!Qhat) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, cnt * 8, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SDPSR_OK;
 }
 
@@ -2341,7 +2046,7 @@ int sdpsr_syev_f64(sdpsr_ctx* c, int64_t n, const double* A, double* values, dou
 namespace sdpsr {
 void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t* sig);
 size_t sytrd_workspace_doubles(int64_t n, int64_t ld);
-void launch_sytrd(hipStream_t s, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
+void launch_sytrd(sdpsr_ctx* c, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
 void launch_sytrd_symv_sweep(hipStream_t s, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
 }
 
@@ -2444,12 +2149,12 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         HIP_TRY(c, hipStreamSynchronize(s));
         const int runs = (kind == 5) ? 1 : reps;
         launch_gather_f64_padded(s, n, ld, Lb, 999, A);
-        if (kind == 6) launch_sytrd(s, n, A, ld, dd, dd + n, dd + 2 * n, ws);  // warm-up
+        if (kind == 6) launch_sytrd(c, n, A, ld, dd, dd + n, dd + 2 * n, ws);  // warm-up
         launch_gather_f64_padded(s, n, ld, Lb, 999, A);
         HIP_TRY(c, hipEventRecord(e0, s));
         for (int i = 0; i < runs; ++i) {
             if (kind == 5) launch_sytrd_symv_sweep(s, n, A, ld, dd, dd + n, dd + 2 * n, ws);
-            else launch_sytrd(s, n, A, ld, dd, dd + n, dd + 2 * n, ws);
+            else launch_sytrd(c, n, A, ld, dd, dd + n, dd + 2 * n, ws);
         }
         HIP_TRY(c, hipEventRecord(e1, s));
         HIP_TRY(c, hipEventSynchronize(e1));

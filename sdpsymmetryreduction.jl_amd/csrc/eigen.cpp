@@ -15,8 +15,7 @@
 namespace sdpsr {
 
 size_t sytrd_workspace_doubles(int64_t n, int64_t ld);
-void launch_sytrd(hipStream_t s, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau,
-                  double* ws);
+void launch_sytrd(sdpsr_ctx* c, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
 bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double* w, double* Vtmp, int* info);
 
 static int ensure_handle(sdpsr_ctx* c) {
@@ -68,7 +67,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             // hand-written tridiagonalisation (kernels_sytrd.hip); LAPACK-compatible output
             double* ws = (double*)ctx_buf(c, "eig_sytrd_ws", sytrd_workspace_doubles(n, lda) * sizeof(double));
             if (!ws) return SDPSR_OUT_OF_MEMORY;
-            launch_sytrd(c->stream, n, A, lda, w, E, tau, ws);
+            launch_sytrd(c, n, A, lda, w, E, tau, ws);
             if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "sytrd launch failed");
         }
         if (c->opts.eig_driver == 3)

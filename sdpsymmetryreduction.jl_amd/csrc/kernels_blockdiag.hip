@@ -604,24 +604,26 @@ class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict_
     }
 }
 
+// per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes)
+void blockdiag_set_device_attributes() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<2>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+}
+
 void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out) {
     const int tstride = (int)((d + 1) | 1);
     const size_t lds_small = ((size_t)n + (size_t)4 * 64 * tstride) * sizeof(double);
     if (lds_small <= 150 * 1024) {
-        static bool attr_small = false;
-        if (!attr_small) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr_small = true;
-        }
         int g = (int)((n + 3) / 4);
         if (g > 256) g = 256;  // one resident workgroup per CU, rows in rounds
         class_sums_small_d_kernel<<<g, 256, lds_small, s>>>((int)n, (int)d, tstride, L, x, out);
         return;
     }
     const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     basis_image_rows_kernel<1><<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, 1, L, x, out, 0);
 }
 
@@ -629,14 +631,6 @@ void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S
                                   const uint32_t* L, const double* Qrm, double* T, const int32_t* colA,
                                   const int32_t* colB, double atol, double* out) {
     const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
-    }
     if (S1 % 2 == 0)  // rows of Qrm are 16-byte aligned
         basis_image_rows_kernel<2><<<(unsigned)n, 64, lds, s>>>((int)n, (int)d, (int)S1, L, Qrm, T, 1);
     else

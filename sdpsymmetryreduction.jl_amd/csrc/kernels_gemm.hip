@@ -611,6 +611,25 @@ gemm_tn_dma256_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restri
         }
 }
 
+// Dynamic-LDS limits are a per-device property of a kernel: sdpsr_create() calls this with the
+// ctx's device current, so a process may hold ctxs on several GPUs (no process-global flags).
+template <int KIND>
+static void gemm_set_attributes_kind() {
+    constexpr int KBt = GemmTraits<KIND>::KB;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<KIND>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM * (KBt + 16));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM * 128);
+    if constexpr (KIND == KIND_I8 || KIND == KIND_F32)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma256_kernel<KIND>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM2 * 128);
+}
+void gemm_set_device_attributes() {
+    gemm_set_attributes_kind<KIND_I8>();
+    gemm_set_attributes_kind<KIND_F32>();
+    gemm_set_attributes_kind<KIND_F64>();
+}
+
 template <int KIND>
 static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
                         const typename GemmTraits<KIND>::in_t* A, int64_t lda,
@@ -632,32 +651,14 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
             const int64_t wgs = (nonsym_flag ? t2 * (t2 + 1) / 2 : t2 * (n / BM2)) * batch;
             if (!only128 && m % BM2 == 0 && n % BM2 == 0 && wgs >= 1024) {
                 constexpr size_t lds256 = 2 * 2 * BM2 * 128;  // 128 KiB
-                static bool attr256 = false;
-                if (!attr256) {
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma256_kernel<KIND>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-                    attr256 = true;
-                }
                 dim3 grid2((unsigned)(m / BM2), (unsigned)(n / BM2), (unsigned)batch);
                 gemm_tn_dma256_kernel<KIND><<<grid2, NT2, lds256, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
                 return;
             }
         }
         constexpr size_t lds_dma = 2 * 2 * BM * 128;  // 64 KiB
-        static bool dma_attr_set = false;
-        if (!dma_attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
-            dma_attr_set = true;
-        }
         gemm_tn_dma_kernel<KIND><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
         return;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<KIND>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     gemm_tn_kernel<KIND><<<grid, NT, lds, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
 }

@@ -1,159 +1,16 @@
-// Kernels of the Krylov driver of blockDiagonalize (DESIGN.md "Krylov driver"): the generic
-// element of a symmetric algebra has only k = sum_k s_k distinct eigenvalues (k <= dim(P)), so a
-// Lanczos process with full re-orthogonalisation started from a random vector breaks down after
-// exactly k steps and its Ritz pairs are the k eigenvalues and one generic unit vector of every
-// eigenspace -- everything src/eigen_decomposition.jl:236-348 uses of eigen(A).  All passes
-// are HBM-bound reads of the n x n element (sym_gemv) or small tall-skinny updates.
+// Kernels of the module-compression driver of blockDiagonalize (DESIGN.md "module compression"):
+// Y = A(v) W straight from the labels (label_spmm), tall-times-small products, split-K
+// reductions and the small glue around them; plus helpers shared with the setup stage.
 #include <algorithm>
 #include "sdpsr_internal.h"
 
 namespace sdpsr {
 
-// y = A x for symmetric A (column dots: one wave per column, 16-byte loads).  ld even.
-__global__ void __launch_bounds__(256)
-sym_gemv_kernel(int n, int64_t ld, const double* __restrict__ A, const double* __restrict__ x,
-                double* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) double s_x[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n2 = (n + 1) >> 1;
-    for (int t = tid; t < 2 * n2; t += 256) s_x[t] = (t < n) ? x[t] : 0.0;
-    __syncthreads();
-    const double2* sx2 = reinterpret_cast<const double2*>(s_x);
-    const int nwaves = gridDim.x * 4;
-    for (int k = blockIdx.x * 4 + wave; k < n; k += nwaves) {
-        const double2* c2 = reinterpret_cast<const double2*>(A + (int64_t)k * ld);
-        double a0 = 0, a1 = 0;
-        int t = lane;
-        for (; t + 64 < n2; t += 128) {
-            const double2 u0 = c2[t], u1 = c2[t + 64];
-            const double2 v0 = sx2[t], v1 = sx2[t + 64];
-            a0 = fma(u0.x, v0.x, a0);
-            a0 = fma(u0.y, v0.y, a0);
-            a1 = fma(u1.x, v1.x, a1);
-            a1 = fma(u1.y, v1.y, a1);
-        }
-        for (; t < n2; t += 64) {
-            const double2 u0 = c2[t];
-            const double2 v0 = sx2[t];
-            a0 = fma(u0.x, v0.x, a0);
-            a0 = fma(u0.y, v0.y, a0);
-        }
-        double acc = a0 + a1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-        if (lane == 0) y[k] = acc;
-    }
-}
-void launch_sym_gemv(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* x, double* y) {
-    int nblk = (int)((n + 7) / 8);
-    if (nblk > 1024) nblk = 1024;
-    if (nblk < 1) nblk = 1;
-    const size_t lds = ((size_t)n + 4) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sym_gemv_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set = true;
-    }
-    sym_gemv_kernel<<<nblk, 256, lds, s>>>((int)n, ld, A, x, y);
-}
-
-// ---------------------------------------------------------------------------
-// One Lanczos step of run r = blockIdx.x (classical Gram-Schmidt, twice):
-//   w = W[:, r]; c = H' w; w -= H c (over the t+1 stored vectors), repeated;
-//   alpha = (c1 + c2)[t]; beta = ||w||; H[:, t+1] = w / beta.
-// H_r = H + r * hstride (n x cap, leading dimension ld).  1024 threads; w lives in registers
-// (n <= 16 * 1024).  active[r] == 0 -> nothing to do.
-// ---------------------------------------------------------------------------
 constexpr int LZ_THREADS = 1024;
-
-__global__ void __launch_bounds__(LZ_THREADS)
-lanczos_orth_kernel(int n, int64_t ld, double* __restrict__ H, int64_t hstride, const int* __restrict__ tcur,
-                    const double* __restrict__ W, int64_t ldw, const int* __restrict__ active,
-                    double* __restrict__ alpha_out, double* __restrict__ beta_out, double* __restrict__ nin_out) {
-    const int r = blockIdx.x;
-    if (active && !active[r]) return;
-    extern __shared__ __attribute__((aligned(16))) double s_w[];  // n doubles: the vector being orthogonalised
-    __shared__ double s_c[512];        // coefficients of the current pass (t + 1 <= 512)
-    __shared__ double s_alpha;
-    __shared__ double s_red[LZ_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = tcur[r];
-    double* Hr = H + (int64_t)r * hstride;
-    double sq0 = 0;
-    for (int i = tid; i < n; i += LZ_THREADS) {
-        const double v = W[i + (int64_t)r * ldw];
-        s_w[i] = v;
-        sq0 = fma(v, v, sq0);
-    }
-    if (tid == 0) s_alpha = 0.0;
-    if (nin_out) {  // norm of the incoming vector (rank decisions of the module-compression driver)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq0 += __shfl_down(sq0, o, 64);
-        if (lane == 0) s_red[wave] = sq0;
-        __syncthreads();
-        if (tid == 0) {
-            double tot = 0;
-            for (int q = 0; q < LZ_THREADS / 64; ++q) tot += s_red[q];
-            nin_out[r] = sqrt(tot);
-        }
-    }
-    __syncthreads();
-    for (int pass = 0; pass < 2; ++pass) {
-        // c[h] = H[:,h] . w : one wave per stored vector
-        for (int h = wave; h <= t; h += LZ_THREADS / 64) {
-            const double* hc = Hr + (int64_t)h * ld;
-            double acc = 0;
-            for (int i = lane; i < n; i += 64) acc = fma(hc[i], s_w[i], acc);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-            if (lane == 0) s_c[h] = acc;
-        }
-        __syncthreads();
-        if (tid == 0) s_alpha += s_c[t];
-        // w -= H c : one thread per row, all stored vectors
-        for (int i = tid; i < n; i += LZ_THREADS) {
-            double wv = s_w[i];
-            for (int h = 0; h <= t; ++h) wv = fma(-s_c[h], Hr[(int64_t)h * ld + i], wv);
-            s_w[i] = wv;
-        }
-        __syncthreads();
-    }
-    double sq = 0;
-    for (int i = tid; i < n; i += LZ_THREADS) sq = fma(s_w[i], s_w[i], sq);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
-    if (lane == 0) s_red[wave] = sq;
-    __syncthreads();
-    if (tid == 0) {
-        double tot = 0;
-        for (int k = 0; k < LZ_THREADS / 64; ++k) tot += s_red[k];
-        s_red[0] = sqrt(tot);
-        alpha_out[r] = s_alpha;
-        beta_out[r] = s_red[0];
-    }
-    __syncthreads();
-    const double beta = s_red[0];
-    const double inv = (beta > 0) ? 1.0 / beta : 0.0;
-    double* hn = Hr + (int64_t)(t + 1) * ld;
-    for (int i = tid; i < n; i += LZ_THREADS) hn[i] = s_w[i] * inv;
-}
-void launch_lanczos_orth(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const int* tcur,
-                         double* W, int64_t ldw, const int* active, int nruns, double* alpha_out, double* beta_out,
-                         double* nin_out) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&lanczos_orth_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
-        attr_set = true;
-    }
-    lanczos_orth_kernel<<<nruns, LZ_THREADS, (size_t)n * sizeof(double), s>>>((int)n, ld, H, hstride, tcur, W, ldw, active,
-                                                                            alpha_out, beta_out, nin_out);
-}
 
 // H_r[:, 0] = X[:, r] / ||X[:, r]||, norm0[r] = ||X[:, r]||   (one block per run)
 __global__ void __launch_bounds__(LZ_THREADS)
-lanczos_init_kernel(int n, int64_t ld, double* __restrict__ H, int64_t hstride, const double* __restrict__ X,
+normalize_columns_kernel(int n, int64_t ld, double* __restrict__ H, int64_t hstride, const double* __restrict__ X,
                     int64_t ldx, double* __restrict__ norm0) {
     __shared__ double s_red[LZ_THREADS / 64];
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -177,46 +34,10 @@ lanczos_init_kernel(int n, int64_t ld, double* __restrict__ H, int64_t hstride, 
     double* h0 = H + (int64_t)r * hstride;
     for (int i = tid; i < n; i += LZ_THREADS) h0[i] = X[i + (int64_t)r * ldx] * inv;
 }
-void launch_lanczos_init(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const double* X,
+void launch_normalize_columns(hipStream_t s, int64_t n, int64_t ld, double* H, int64_t hstride, const double* X,
                          int64_t ldx, int nruns, double* norm0) {
     (void)ld;
-    lanczos_init_kernel<<<nruns, LZ_THREADS, 0, s>>>((int)n, ld, H, hstride, X, ldx, norm0);
-}
-
-// gather the current Lanczos vectors into a dense block: V[:, r] = H_r[:, tcur[r]] (0 if inactive)
-__global__ void lanczos_pack_kernel(int n, int64_t ld, const double* __restrict__ H, int64_t hstride,
-                                    const int* __restrict__ tcur, const int* __restrict__ active,
-                                    double* __restrict__ V, int64_t ldv) {
-    const int r = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    V[i + (int64_t)r * ldv] = active[r] ? H[(int64_t)r * hstride + (int64_t)tcur[r] * ld + i] : 0.0;
-}
-void launch_lanczos_pack(hipStream_t s, int64_t n, int64_t ld, const double* H, int64_t hstride, const int* tcur,
-                         const int* active, int nruns, double* V, int64_t ldv) {
-    dim3 g((unsigned)((n + 255) / 256), (unsigned)nruns);
-    lanczos_pack_kernel<<<g, 256, 0, s>>>((int)n, ld, H, hstride, tcur, active, V, ldv);
-}
-
-// out[:, c] = sum_t Hsrc_c[:, t] * S[t + c * lds_],  t < kk[c];  Hsrc_c = H + run[c] * hstride
-__global__ void ritz_combine_kernel(int n, int64_t ld, const double* __restrict__ H, int64_t hstride,
-                                    const int* __restrict__ run, const int* __restrict__ kk,
-                                    const double* __restrict__ S, int lds_, double* __restrict__ out, int64_t ldo) {
-    const int c = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double* Hr = H + (int64_t)run[c] * hstride;
-    const double* sc = S + (int64_t)c * lds_;
-    double acc = 0;
-    const int k = kk[c];
-    for (int t = 0; t < k; ++t) acc = fma(Hr[(int64_t)t * ld + i], sc[t], acc);
-    out[i + (int64_t)c * ldo] = acc;
-}
-void launch_ritz_combine(hipStream_t s, int64_t n, int64_t ld, const double* H, int64_t hstride, const int* run,
-                         const int* kk, const double* S, int lds_, int ncols, double* out, int64_t ldo) {
-    if (ncols <= 0) return;
-    dim3 g((unsigned)((n + 255) / 256), (unsigned)ncols);
-    ritz_combine_kernel<<<g, 256, 0, s>>>((int)n, ld, H, hstride, run, kk, S, lds_, out, ldo);
+    normalize_columns_kernel<<<nruns, LZ_THREADS, 0, s>>>((int)n, ld, H, hstride, X, ldx, norm0);
 }
 
 // deterministic pseudo-random start vector in (-1, 1)

@@ -25,12 +25,19 @@ static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 *
 // fill / randomize / clamp_round
 // ---------------------------------------------------------------------------
 __global__ void fill_f64_kernel(int64_t len, const uint32_t* __restrict__ L,
-                                const double* __restrict__ values, double* __restrict__ M) {
+                                const double* __restrict__ values, uint32_t d, double* __restrict__ M,
+                                uint32_t* __restrict__ bad_flag) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
         uint32_t l = L[e];
+        if (l > d) {  // @assert length(values) == dim(P), src/partitions.jl:69: never read past `values`
+            bad = true;
+            l = 0;
+        }
         M[e] = l ? values[l - 1] : 0.0;
     }
+    if (bad) *bad_flag = 1u;
 }
 
 __global__ void randomize_f64_kernel(int64_t len, const uint32_t* __restrict__ L, uint64_t key,
@@ -49,9 +56,9 @@ __global__ void clamp_round_kernel(int64_t len, double* __restrict__ a, double a
         a[e] = sdpsr_clamp_round(a[e], atol, scale);
 }
 
-void launch_fill_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* values,
-                     double* M) {
-    fill_f64_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, values, M);
+void launch_fill_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* values, int64_t d,
+                     double* M, uint32_t* bad_flag) {
+    fill_f64_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, values, (uint32_t)d, M, bad_flag);
 }
 void launch_randomize_f64(hipStream_t s, int64_t len, const uint32_t* L, uint64_t key,
                           double* M) {
@@ -1012,6 +1019,12 @@ __global__ void reduce_columns_final_kernel(int64_t nchunks, int m, int d, const
     for (int64_t ch = 0; ch < nchunks; ++ch) acc += partial[(ch * d + i) * m + r];
     out[r + i * m] = acc;  // m x d column-major
 }
+// per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes)
+void partition_set_device_attributes() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+}
+
 int64_t reduce_columns_chunk(int64_t len, int64_t m, int64_t d) {
     int64_t chunk = 4096;
     while ((len + chunk - 1) / chunk * d * m * 8 > ((int64_t)64 << 20)) chunk *= 2;
@@ -1024,12 +1037,6 @@ bool launch_reduce_columns(hipStream_t s, int64_t len, int64_t m, int64_t d, con
     if (lds > 60 * 1024) return false;
     const int64_t chunk = reduce_columns_chunk(len, m, d);
     const int64_t nch = (len + chunk - 1) / chunk;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
-    }
     reduce_columns_kernel<<<(unsigned)nch, 64, lds, s>>>(len, chunk, (int)m, (int)d, L, A, partial);
     reduce_columns_final_kernel<<<(unsigned)((m * d + 255) / 256), 256, 0, s>>>(nch, (int)m, (int)d, partial, out);
     return true;

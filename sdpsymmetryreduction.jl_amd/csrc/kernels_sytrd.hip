@@ -18,7 +18,6 @@
 //    triangles) in one tiled kernel.
 // Output is LAPACK-compatible (d, e, tau, reflectors below the subdiagonal of A), so the
 // tridiagonal solve (rocSOLVER stedc) and the back-transformation (ormtr) plug in unchanged.
-#include <mutex>
 #include <cstdlib>
 #include "sdpsr_internal.h"
 
@@ -388,9 +387,8 @@ size_t sytrd_workspace_doubles(int64_t n, int64_t ld) {
     return (size_t)2 * ld * SY_NB + (size_t)n + 2 * SY_NB + 2 * 4096 + 64;
 }
 
-static void sytrd_set_attributes() {
-    static bool attr_set = false;
-    if (attr_set) return;
+// per-device kernel attributes, set by sdpsr_create() with the ctx's device current
+void sytrd_set_device_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<8>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<16>),
@@ -399,7 +397,6 @@ static void sytrd_set_attributes() {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<64>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    attr_set = true;
 }
 
 static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
@@ -427,7 +424,6 @@ static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t l
     int n_vav = 0;
     int cf = 0;  // panel column of the column currently being formed
     const size_t lds_v = ((size_t)n + 4) * sizeof(double);
-    sytrd_set_attributes();
     // column 0: plain form (no panel yet)
     {
         const int nb_form = (n + SY_FROWS - 1) / SY_FROWS;
@@ -519,37 +515,41 @@ void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, 
 // the nodes (order, leading dimension, all pointers); the ctx's buffers are grow-only, so the key
 // is stable across calls.  A few graphs are kept (generic elements alternate between two or
 // three buffers).
-namespace {
+// The cache belongs to the ctx (sdpsr_ctx::sytrd_graphs): no process-global state, and calls on
+// one ctx are serialised by contract, so no lock is needed.
 struct SytrdGraph {
-    int device = -1;
     int64_t n = 0, ld = 0;
     const void *A = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr, *ws = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t last_use = 0;
 };
-SytrdGraph g_sytrd_graphs[6];
-uint64_t g_sytrd_clock = 0;
-std::mutex g_sytrd_mutex;  // distinct ctxs may be driven from distinct host threads
-}  // namespace
+struct SytrdGraphCache {
+    SytrdGraph slots[6];
+    uint64_t clock = 0;
+};
+void sytrd_graph_cache_destroy(SytrdGraphCache* g) {
+    if (!g) return;
+    for (auto& sl : g->slots)
+        if (sl.exec) hipGraphExecDestroy(sl.exec);
+    delete g;
+}
 
-void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
-                  double* ws) {
-    static const bool no_graph = getenv("SDPSR_NO_GRAPH") != nullptr;
+void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
+    hipStream_t s = c->stream;
+    const bool no_graph = getenv("SDPSR_NO_GRAPH") != nullptr;
     if (no_graph || n64 < 64 || n64 > 3072) {  // large orders: the kernels outlast their launches
         launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
         return;
     }
-    std::lock_guard<std::mutex> lock(g_sytrd_mutex);
-    sytrd_set_attributes();
-    int device = 0;
-    (void)hipGetDevice(&device);
-    ++g_sytrd_clock;
+    if (!c->sytrd_graphs) c->sytrd_graphs = new SytrdGraphCache();
+    SytrdGraphCache& gc = *c->sytrd_graphs;
+    ++gc.clock;
     SytrdGraph* slot = nullptr;
-    for (auto& g : g_sytrd_graphs)
-        if (g.exec && g.device == device && g.n == n64 && g.ld == ld && g.A == A && g.d == d && g.e == e && g.tau == tau && g.ws == ws) slot = &g;
+    for (auto& g : gc.slots)
+        if (g.exec && g.n == n64 && g.ld == ld && g.A == A && g.d == d && g.e == e && g.tau == tau && g.ws == ws) slot = &g;
     if (!slot) {
-        SytrdGraph* victim = &g_sytrd_graphs[0];
-        for (auto& g : g_sytrd_graphs)
+        SytrdGraph* victim = &gc.slots[0];
+        for (auto& g : gc.slots)
             if (!g.exec) {
                 victim = &g;
                 break;
@@ -572,7 +572,6 @@ void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, 
             launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
             return;
         }
-        victim->device = device;
         victim->n = n64;
         victim->ld = ld;
         victim->A = A;
@@ -582,7 +581,7 @@ void launch_sytrd(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, 
         victim->ws = ws;
         slot = victim;
     }
-    slot->last_use = g_sytrd_clock;
+    slot->last_use = gc.clock;
     if (hipGraphLaunch(slot->exec, s) != hipSuccess) {
         (void)hipGetLastError();
         launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
@@ -945,6 +944,13 @@ small_syev_jacobi64_kernel(int n, double* __restrict__ Ag, int64_t lda, double* 
     }
 }
 
+void small_syev_set_device_attributes() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+}
+
 bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double* w, double* Vtmp, int* info) {
     if (n < 1 || n > JAC_MAXN) return false;
     size_t lds = (size_t)((n | 1) * n + 8) * sizeof(double);
@@ -953,12 +959,6 @@ bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double*
         int threads = (half * half + 63) / 64 * 64;
         if (threads < 64) threads = 64;
         const size_t lds64 = 2 * (size_t)(mm | 1) * mm * sizeof(double) + (size_t)(mm - 1) * half * sizeof(int) + 64;
-        static bool attr64 = false;
-        if (!attr64) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            attr64 = true;
-        }
         small_syev_jacobi64_kernel<<<1, threads, lds64, s>>>((int)n, A, lda, w, info);
         return true;
     }
@@ -968,12 +968,6 @@ bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double*
     int threads = (int)(((n + 1) / 2) * n + 63) / 64 * 64;
     if (threads > JAC_MAXTHREADS) threads = JAC_MAXTHREADS;
     if (threads < 64) threads = 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
     small_syev_jacobi_kernel<<<1, threads, lds, s>>>((int)n, A, lda, w, Vtmp, info, v_in_lds);
     return true;
 }

@@ -12,7 +12,7 @@
 #include "../../include/sdpsr.h"
 #include "sdpsr_hash.h"
 
-struct rocblas_handle_wrap;  // opaque (eigen.cpp)
+namespace sdpsr { struct SytrdGraphCache; }  // kernels_sytrd.hip
 
 // ---------------------------------------------------------------------------
 // grow-only named device buffers: no hipMalloc inside steady-state loops
@@ -29,7 +29,7 @@ struct sdpsr_ctx {
     sdpsr_opts opts{};
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;  // lazily created: work that overlaps a one-workgroup kernel
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wait = nullptr;
     hipStream_t main_shadow = nullptr;  // the main stream while `stream` temporarily points at side_stream
     bool own_stream = false;
     std::string err;
@@ -40,11 +40,13 @@ struct sdpsr_ctx {
     void* h2d_ring = nullptr;  // pinned ring for small stream-ordered uploads (no sync per upload)
     int h2d_ring_next = 0;
     void* rocblas = nullptr;  // rocblas_handle, created lazily
+    sdpsr::SytrdGraphCache* sytrd_graphs = nullptr;  // captured launch sequences of the tridiagonalisation
     // --- block-diagonalisation state kept between phase 1 and phase 2 ---
     int64_t bd_n = 0, bd_d = 0;
     std::vector<int32_t> bd_sizes;
     int64_t bd_sum_s = 0, bd_sum_sq = 0;
     bool bd_valid = false;
+    bool bd_q_valid = false;  // "bd_qhat" holds Q_hat of the last diagonalize (even when check_block_sizes failed)
     bool bd_labels_owned = false;
     // hash table capacity hint (log2) for the next refine
     int table_log2_hint = 12;
@@ -68,8 +70,8 @@ int ctx_fail(sdpsr_ctx* c, int status, const std::string& msg);
 namespace sdpsr {
 
 // M[e] = values[L[e]-1] (0 -> 0.0)
-void launch_fill_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* values,
-                     double* M);
+void launch_fill_f64(hipStream_t s, int64_t len, const uint32_t* L, const double* values, int64_t d,
+                     double* M, uint32_t* bad_flag);
 // M[e] = uniform(key, L[e])
 void launch_randomize_f64(hipStream_t s, int64_t len, const uint32_t* L, uint64_t key, double* M);
 // in-place clamp+round
@@ -134,7 +136,7 @@ void launch_labels_checksum(hipStream_t s, int64_t len, const uint32_t* L, uint6
 int64_t reduce_columns_chunk(int64_t len, int64_t m, int64_t d);
 bool launch_reduce_columns(hipStream_t s, int64_t len, int64_t m, int64_t d, const uint32_t* L, const double* A,
                            double* partial, double* out);
-// kernels_krylov.hip / setup-stage helpers used across api.cpp
+// kernels_module.hip / setup-stage helpers used across api.cpp
 void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B);
 void launch_tall_times_small(hipStream_t s, int64_t n, int64_t ldi, const double* In, int kk, const double* S,
                              int lds_, int ncols, double alpha, double beta, double* out, int64_t ldo);
@@ -143,6 +145,15 @@ void launch_col_norms2(hipStream_t s, int64_t len, int64_t k, const double* V, d
 void launch_scale_copy(hipStream_t s, int64_t len, const double* v, double alpha, double* out);
 void launch_rank1_update(hipStream_t s, int64_t len, int64_t m, double* R, const double* u, const double* dots);
 void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double* b, double atol, double scale, double* out);
+
+// Kernels with more than 64 KiB of dynamic LDS carry a per-DEVICE attribute: sdpsr_create() sets
+// them all with the ctx's device current (no process-global "already set" flags).
+void gemm_set_device_attributes();
+void blockdiag_set_device_attributes();
+void partition_set_device_attributes();
+void sytrd_set_device_attributes();
+void small_syev_set_device_attributes();
+void sytrd_graph_cache_destroy(SytrdGraphCache* g);
 
 // symmetric-labels check: flag[0] = 1 if some L[i,j] != L[j,i]
 void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag);

@@ -104,3 +104,26 @@ def test_no_gpu_means_an_error_not_a_fallback(pkg):
         pytest.skip("GPU present")
     with pytest.raises(pkg.SdpsrError):
         pkg.Context()
+
+
+def test_no_process_global_state_in_the_library():
+    """sdpsr.h promises ctxs on several devices / host threads: kernel attributes are set per
+    device in sdpsr_create and caches live in the ctx -- no `static bool` guards, no global
+    graph cache, no mutex-protected singletons in the native sources."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "sdpsymmetryreduction.jl_amd", "csrc")
+    bad = []
+    for f in sorted(os.listdir(src)):
+        if not f.endswith((".hip", ".cpp", ".h")):
+            continue
+        txt = open(os.path.join(src, f)).read()
+        for pat in (r"static\s+bool\s+\w*attr", r"\bstd::mutex\b", r"^\s*static\s+\w[\w:<>]*\s+g_\w+", r"\bg_sytrd_"):
+            if re.search(pat, txt, flags=re.M):
+                bad.append((f, pat))
+        # every hipFuncSetAttribute sits in a *_set_device_attributes function
+        for m in re.finditer(r"hipFuncSetAttribute", txt):
+            head = txt[:m.start()]
+            fn = re.findall(r"\n(?:static\s+)?void\s+(\w+)\s*\([^)]*\)\s*\{", head)
+            assert fn and ("set_device_attributes" in fn[-1] or "set_attributes_kind" in fn[-1]), (f, fn[-1:] )
+    assert bad == []

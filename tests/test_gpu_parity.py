@@ -528,3 +528,57 @@ def test_error_paths(pkg, problems, golden):
         L = golden["er3_P"]
         bd = pkg.blockDiagonalize(pkg.Partition(int(L.max()), L.copy()), ctx=ctx)
         assert sorted(bd.blkSizes) == list(golden["er3_blk"])
+
+
+# ------------------------------------------------ ctx contract (include/sdpsr.h:20-25)
+def test_two_contexts_from_two_threads(pkg, golden):
+    """Distinct ctxs may be driven from distinct host threads (no process-global state: kernel
+    attributes per device in sdpsr_create, graph cache inside the ctx)."""
+    import threading
+    res, errs = {}, []
+
+    def work(tag, name, seed):
+        try:
+            L = golden[f"{name}_P"]
+            with pkg.Context(seed=seed) as ctx:
+                for _ in range(3):
+                    bd = pkg.blockDiagonalize(pkg.Partition(int(L.max()), L.copy()), ctx=ctx)
+                    assert sorted(bd.blkSizes) == list(golden[f"{name}_blk"])
+                x = np.random.default_rng(seed).random((200, 200))
+                x = x + x.T
+                w = np.empty(200)
+                v = np.empty(200 * 200)
+                ctx.check(ctx._lib.sdpsr_syev_f64(ctx._h, 200, C.c_void_p(_fl(x, np.float64).ctypes.data),
+                                                  C.c_void_p(w.ctypes.data), C.c_void_p(v.ctypes.data), pkg.MEM_HOST))
+                res[tag] = np.allclose(w, np.linalg.eigvalsh(x), atol=1e-10)
+        except Exception as e:  # noqa: BLE001
+            errs.append((tag, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i, nm, 10 + i)) for i, nm in enumerate(["er5", "er7", "esc16j", "er3"])]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert errs == []
+    assert all(res[i] for i in range(4))
+
+
+def test_device_inputs_from_an_async_torch_kernel(pkg, problems, golden):
+    """MEM_DEVICE arguments produced by torch kernels that may still be running when the call is
+    made: the wrapper orders ctx's stream behind torch's current stream (sdpsr_wait_stream), and
+    every entry point returns with its outputs complete."""
+    import torch
+    Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(7))
+    n, CL, X0L, U = pkg.admissible_setup(Cv, A, b)
+    dev = torch.device("cuda:0")
+    big = torch.randn(4096, 4096, device=dev)
+    with pkg.Context(seed=5) as ctx:
+        for rep in range(3):
+            junk = big @ big  # keeps torch's stream busy for a while
+            tCL = torch.from_numpy(CL).to(dev) + junk[0, 0] * 0.0  # queued behind the GEMM
+            tX0 = torch.from_numpy(X0L).to(dev) * 1.0
+            tU = torch.from_numpy(np.asfortranarray(U).ravel(order="F").copy()).to(dev).view(U.shape[1], -1).t()
+            P = pkg.admissible_subspace(None, None, None, ctx=ctx, setup=(n, tCL, tX0, tU))
+            assert P.nparts == 18
+            assert np.array_equal(P.matrix.cpu().numpy().astype(np.uint32), golden["er7_P"])
+            del junk
