@@ -220,6 +220,20 @@ int sdpsr_block_images(sdpsr_ctx* ctx, double* blks, double* Q_hat, double* phas
    isomorphism classes. */
 int sdpsr_eigen_decomposition(sdpsr_ctx* ctx, int64_t n, const uint32_t* P, int64_t d,
                               double atol, int32_t* neig, int32_t* nclasses, int mem);
+/* Batched small-N mode: `count` independent runs of eigen_decomposition(P, A; atol) on ONE
+   partition, each with its own pair of generic elements -- the shape of the reference's
+   robustness pin (test/numerical_issues.jl:85-94: 10 000 runs on a 64 x 64 partition, none may
+   throw).  For n <= 64 one workgroup handles one run (Jacobi eigensolver, Q'AQ, block norms,
+   Otsu threshold, union-find and __isconsistent all inside the workgroup) and all CUs work in
+   parallel; larger n goes through the single-problem path run by run.
+   values: NULL (fresh draws from ctx's generator) or 2*count*d doubles in `mem` -- run r uses
+           values[(2r)*d ...] as the class values of element #1 and values[(2r+1)*d ...] of #2
+           (n <= 64 only; lets a caller replay given elements);
+   status/neig/nclasses: host arrays of `count` ints, each may be NULL.
+   Returns SDPSR_OK when every run is OK, else the status of the first failing run. */
+int sdpsr_eigen_decomposition_batched(sdpsr_ctx* ctx, int64_t n, const uint32_t* P, int64_t d, double atol,
+                                      int64_t count, const double* values, int32_t* status, int32_t* neig,
+                                      int32_t* nclasses, int mem);
 /* Symmetric eigendecomposition used by the path (eigen(A), :246): ascending values,
    orthonormal vectors (column-major n x n, overwrites nothing of A). */
 int sdpsr_syev_f64(sdpsr_ctx* ctx, int64_t n, const double* A, double* values, double* vectors,

@@ -492,3 +492,29 @@ def eigen_decomposition(P, atol=None, ctx=None):
     nc = C.c_int32(0)
     ctx.check(ctx._lib.sdpsr_eigen_decomposition(ctx._h, n, _ptr(lab), P.nparts, float(atol), C.byref(ne), C.byref(nc), mem))
     return ne.value, nc.value
+
+
+def eigen_decomposition_batched(P, count, atol=None, values=None, ctx=None, raise_on_failure=True):
+    """``count`` independent runs of ``eigen_decomposition(P, A; atol)`` on one partition
+    (test/numerical_issues.jl:85-94 runs 10 000 of them): one workgroup per run on the device.
+    ``values``: optional array (count, 2, dim(P)) of class values for the two generic elements of
+    every run.  Returns (status, neig, nclasses) int32 arrays; raises the first failure like the
+    reference would unless ``raise_on_failure`` is False."""
+    n = P.shape[0]
+    atol = 1e-12 * n if atol is None else atol
+    ctx = _ctx(ctx)
+    lab, mem = _labels_arg(P)
+    ctx.wait_for(lab)
+    vals = None
+    if values is not None:
+        vals = np.ascontiguousarray(values, dtype=np.float64).reshape(count, 2, P.nparts)
+        if mem != L.MEM_HOST:
+            raise ValueError("explicit values need host-resident labels")
+    st = np.zeros(count, dtype=np.int32)
+    ne = np.zeros(count, dtype=np.int32)
+    nc = np.zeros(count, dtype=np.int32)
+    rc = ctx._lib.sdpsr_eigen_decomposition_batched(ctx._h, n, _ptr(lab), P.nparts, float(atol), int(count), _ptr(vals),
+                                                    _ptr(st), _ptr(ne), _ptr(nc), mem)
+    if rc != 0 and (raise_on_failure or rc not in (2, 9)):
+        ctx.check(rc)
+    return st, ne, nc

@@ -358,12 +358,15 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
         return SDPSR_HIP_ERROR;
     }
     c->own_stream = true;
+    if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || c->num_cus < 1)
+        c->num_cus = 256;
     // per-device kernel attributes (dynamic LDS above 64 KiB); cheap and idempotent
     gemm_set_device_attributes();
     blockdiag_set_device_attributes();
     partition_set_device_attributes();
     sytrd_set_device_attributes();
     small_syev_set_device_attributes();
+    batched_set_device_attributes();
     if (hipGetLastError() != hipSuccess) {
         hipStreamDestroy(c->stream);
         delete c;
@@ -1759,6 +1762,75 @@ int sdpsr_eigen_decomposition(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_
         std::sort(roots.begin(), roots.end());
         *nclasses = (int32_t)(std::unique(roots.begin(), roots.end()) - roots.begin());
     }
+    return SDPSR_OK;
+}
+
+int sdpsr_eigen_decomposition_batched(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double atol,
+                                      int64_t count, const double* values, int32_t* status, int32_t* neig,
+                                      int32_t* nclasses, int mem) {
+    CHECK_CTX(c);
+    if (!P || n < 1 || d < 0 || count < 1 || count > (int64_t)1 << 24 || !(atol > 0))
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = check_len(c, n * n);
+    if (st) return st;
+    const uint32_t* L = in_dev(c, "bd_labels", P, (size_t)n * n, mem, &st);
+    if (st) return st;
+    c->bd_valid = false;
+    std::vector<int32_t> h_st(count, 0), h_ne(count, 0), h_nc(count, 0);
+    if (n <= 64) {
+        // one workgroup per run, matrices in LDS (kernels_batched.hip)
+        hipStream_t s = c->stream;
+        uint32_t* flag = (uint32_t*)ctx_buf(c, "bd_flag", 64);
+        int32_t* dout = (int32_t*)ctx_buf(c, "be_out", (size_t)count * 3 * 4);
+        if (!flag || !dout) return SDPSR_OUT_OF_MEMORY;
+        const double* dvals = nullptr;
+        if (values) {
+            dvals = in_dev(c, "be_values", values, (size_t)2 * count * std::max<int64_t>(d, 1), mem, &st);
+            if (st) return st;
+        }
+        launch_check_symmetric(s, n, L, flag);
+        launch_eigdec_batched64(s, n, d, count, L, dvals, c->seed, c->stream_counter, atol, dout, dout + count,
+                                dout + 2 * count, c->num_cus);
+        c->stream_counter += 2 * (uint64_t)count;
+        HIP_TRY(c, hipGetLastError());
+        int32_t* hp = (int32_t*)ctx_pinned(c, (size_t)count * 3 * 4 + 64);
+        if (!hp) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
+        HIP_TRY(c, hipMemcpyAsync(hp, flag, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(hp + 16, dout, (size_t)count * 3 * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (hp[0])
+            return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
+                            "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
+        memcpy(h_st.data(), hp + 16, (size_t)count * 4);
+        memcpy(h_ne.data(), hp + 16 + count, (size_t)count * 4);
+        memcpy(h_nc.data(), hp + 16 + 2 * count, (size_t)count * 4);
+    } else {
+        // larger orders: the runs go through the single-problem path one after the other
+        if (values) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "explicit class values are supported for n <= 64 only");
+        for (int64_t r = 0; r < count; ++r) {
+            EigInfo info;
+            PhaseTimer tm(c, false);
+            const int e = eigen_decomposition_device(c, n, L, atol, info, tm);
+            if (e != SDPSR_OK && e != SDPSR_NUMERICAL_INCONSISTENCY && e != SDPSR_SOLVER_ERROR) return e;
+            h_st[r] = e;
+            if (e == SDPSR_OK) {
+                h_ne[r] = (int32_t)info.ptrs.size() - 1;
+                std::vector<int> roots(info.kpart);
+                std::sort(roots.begin(), roots.end());
+                h_nc[r] = (int32_t)(std::unique(roots.begin(), roots.end()) - roots.begin());
+            }
+        }
+    }
+    if (status) memcpy(status, h_st.data(), (size_t)count * 4);
+    if (neig) memcpy(neig, h_ne.data(), (size_t)count * 4);
+    if (nclasses) memcpy(nclasses, h_nc.data(), (size_t)count * 4);
+    for (int64_t r = 0; r < count; ++r)
+        if (h_st[r] != SDPSR_OK) {
+            const char* what = h_st[r] == SDPSR_NUMERICAL_INCONSISTENCY
+                                   ? "eigen_decomposition: the K-partition seems inconsistent with eigenspaces. Decrease atol, or simply try again."
+                                   : "eigensolver did not converge";
+            return ctx_fail(c, h_st[r], "run " + std::to_string(r) + ": " + what);
+        }
     return SDPSR_OK;
 }
 

@@ -24,6 +24,7 @@ struct DevBuf {
 
 struct sdpsr_ctx {
     int device = 0;
+    int num_cus = 256;
     uint64_t seed = 0;
     uint64_t stream_counter = 0;  // fresh RNG stream per randomize call
     sdpsr_opts opts{};
@@ -153,6 +154,11 @@ void blockdiag_set_device_attributes();
 void partition_set_device_attributes();
 void sytrd_set_device_attributes();
 void small_syev_set_device_attributes();
+void batched_set_device_attributes();
+// kernels_batched.hip: `count` runs of eigen_decomposition on one partition of order n <= 64
+void launch_eigdec_batched64(hipStream_t s, int64_t n, int64_t d, int64_t count, const uint32_t* L, const double* values,
+                             uint64_t seed, uint64_t stream_base, double atol, int32_t* status, int32_t* neig,
+                             int32_t* nclasses, int num_cus);
 void sytrd_graph_cache_destroy(SytrdGraphCache* g);
 
 // symmetric-labels check: flag[0] = 1 if some L[i,j] != L[j,i]

@@ -231,3 +231,37 @@ def grid_qap_instance(rows=5, cols=6, seed=0, symmetric_flow=True):
         perms = [idx.ravel(), idx[::-1, :].ravel(), idx[:, ::-1].ravel(), idx[::-1, ::-1].ravel()]
         flow = sum(flow[np.ix_(p, p)] for p in perms)
     return flow, dist
+
+
+# ---------------------------------------------------------------------------
+# theta'-type SDPs whose Jordan closure is a known product scheme (bench workloads that need
+# several refinement rounds: the loop starts from {diagonal, edges, non-edges})
+# ---------------------------------------------------------------------------
+def cartesian_with_complete_adjacency(base_adj, k):
+    """Cartesian product G [] K_k: (a,u) ~ (b,v) iff (a ~ b and u = v) or (a = b and u != v).
+    Vertex (a, u) has index a*k + u (first index slow, as in ``kron_labels``)."""
+    base_adj = np.asarray(base_adj, dtype=np.float64)
+    m = base_adj.shape[0]
+    return np.kron(base_adj, np.eye(k)) + np.kron(np.eye(m), np.ones((k, k)) - np.eye(k))
+
+
+def cycle_adjacency(m):
+    i = np.arange(m)
+    d = np.abs(i[:, None] - i[None, :])
+    return (np.minimum(d, m - d) == 1).astype(np.float64)
+
+
+def theta_prime_product_problem(base_adj, base_labels, k, seed=0):
+    """theta' SDP (test/sd_problems.jl:22-26 form) of the Cartesian product ``base [] K_k`` under a
+    seeded vertex permutation, together with the canonical labels of the product scheme
+    ``base_labels (x) {I, J-I}_k`` under the same permutation -- the partition the Jordan
+    reduction has to arrive at when ``base_labels`` is the closure of the base problem.
+    Returns (C, A, b, labels, dim)."""
+    adj = cartesian_with_complete_adjacency(base_adj, k)
+    n = adj.shape[0]
+    p = np.random.default_rng(seed).permutation(n)
+    adj = adj[np.ix_(p, p)]
+    L = kron_labels(np.asarray(base_labels, dtype=np.int64), complete_scheme_labels(k))[np.ix_(p, p)]
+    L, d = canonical_labels(L)
+    C, A, b = theta_prime_problem(adj)
+    return C, A, b, L, d
