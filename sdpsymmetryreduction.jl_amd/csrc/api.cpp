@@ -367,6 +367,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
     sytrd_set_device_attributes();
     small_syev_set_device_attributes();
     batched_set_device_attributes();
+    backtransform_set_device_attributes();
     if (hipGetLastError() != hipSuccess) {
         hipStreamDestroy(c->stream);
         delete c;

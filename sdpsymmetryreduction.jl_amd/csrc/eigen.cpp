@@ -17,6 +17,60 @@ namespace sdpsr {
 size_t sytrd_workspace_doubles(int64_t n, int64_t ld);
 void launch_sytrd(sdpsr_ctx* c, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
 bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double* w, double* Vtmp, int* info);
+void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
+void launch_bt_extract_panel(hipStream_t s, int64_t n, int64_t ld, const double* A, int64_t j0, int64_t r0, double* Vp,
+                             double* VpT);
+void launch_bt_larft(hipStream_t s, const double* G, const double* tau, int64_t j0, int64_t n, double* T);
+void launch_gemm_tn_f64_sub(hipStream_t s, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                            int64_t ldb, double* C, int64_t ldc);
+
+// C (m x n, dense: ldc == m) = A' B with the K range split over workgroups when the output alone
+// would leave most CUs idle; partial tiles are summed in fixed order.
+static int bt_gemm_splitk(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                          int64_t ldb, double* C) {
+    const int64_t tiles = (m / 128) * (n / 128);
+    int Z = 1;
+    while (tiles * Z < 256 && (k / (2 * Z)) >= 128 && (k % (2 * Z * 16)) == 0) Z *= 2;
+    if (Z == 1) {
+        launch_gemm_tn_f64(c->stream, m, n, k, A, lda, B, ldb, C, m, 1, 0, 0, 0);
+        return SDPSR_OK;
+    }
+    double* P = (double*)ctx_buf(c, "bt_partials", (size_t)Z * m * n * 8);
+    if (!P) return SDPSR_OUT_OF_MEMORY;
+    const int64_t kz = k / Z;
+    launch_gemm_tn_f64(c->stream, m, n, kz, A, lda, B, ldb, P, m, Z, kz, kz, m * n);
+    launch_splitk_reduce(c->stream, m * n, Z, m * n, P, C);
+    return SDPSR_OK;
+}
+
+// Z <- Q Z with Q = H_0 ... H_{n-2} from the tridiagonalisation (reflectors below the subdiagonal of
+// A, tau): compact-WY blocks of 128 reflectors, last block first, every product on the fp64
+// matrix cores (kernels_backtransform.hip has the plan).  Z: ld x ld, zero padded.
+static int backtransform_device(sdpsr_ctx* c, int64_t n, const double* A, int64_t ld, const double* tau, double* Z) {
+    hipStream_t s = c->stream;
+    double* Vp = (double*)ctx_buf(c, "bt_vp", (size_t)ld * 128 * 8);
+    double* VpT = (double*)ctx_buf(c, "bt_vpt", (size_t)ld * 128 * 8);
+    double* X = (double*)ctx_buf(c, "bt_x", (size_t)ld * 128 * 8);
+    double* W = (double*)ctx_buf(c, "bt_w", (size_t)ld * 128 * 8);
+    double* G = (double*)ctx_buf(c, "bt_g", (size_t)128 * 128 * 8);
+    double* T = (double*)ctx_buf(c, "bt_t", (size_t)128 * 128 * 8);
+    if (!Vp || !VpT || !X || !W || !G || !T) return SDPSR_OUT_OF_MEMORY;
+    const int64_t nblk = (n - 1 + 127) / 128;
+    for (int64_t b = nblk - 1; b >= 0; --b) {
+        const int64_t j0 = 128 * b, r0 = j0, m = ld - r0;
+        launch_bt_extract_panel(s, n, ld, A, j0, r0, Vp, VpT);
+        int st = bt_gemm_splitk(c, 128, 128, m, Vp + r0, ld, Vp + r0, ld, G);  // G = V'V
+        if (st) return st;
+        launch_bt_larft(s, G, tau, j0, n, T);
+        // X[:, r] = (V T)[r, :]':  X = T' V' as 128 x m (rows r0..)
+        launch_gemm_tn_f64(s, 128, m, 128, T, 128, VpT + r0 * 128, 128, X + r0 * 128, 128, 1, 0, 0, 0);
+        st = bt_gemm_splitk(c, 128, ld, m, Vp + r0, ld, Z + r0, ld, W);  // W = V' Z
+        if (st) return st;
+        launch_gemm_tn_f64_sub(s, m, ld, 128, X + r0 * 128, 128, W, 128, Z + r0, ld);  // Z -= (V T) W
+    }
+    if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation launch failed");
+    return SDPSR_OK;
+}
 
 static int ensure_handle(sdpsr_ctx* c) {
     if (!c->rocblas) {
@@ -57,9 +111,13 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
         if (rs != rocblas_status_success)
             return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dsyevd status " + std::to_string(rs));
     } else {
-        double* Z = (double*)ctx_buf(c, "eig_Z", (size_t)n * n * sizeof(double));
+        // own path (eig_driver 0 / 4): hand-written tridiagonalisation, rocSOLVER stedc, own
+        // compact-WY back-transformation.  eig_driver 2 / 3: rocSOLVER sytrd / steqr + ormtr (comparison).
+        const bool own = (c->opts.eig_driver == 0 || c->opts.eig_driver >= 4) && (lda % 128) == 0;
+        const int64_t ldz = own ? lda : n;
+        double* Z = (double*)ctx_buf(c, "eig_Z", (size_t)ldz * ldz * sizeof(double));
         if (!Z) return SDPSR_OUT_OF_MEMORY;
-        if (c->opts.eig_driver == 2 || (lda & 1)) {
+        if (!own) {
             rs = rocsolver_dsytrd(h, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)lda, w, E, tau);
             if (rs != rocblas_status_success)
                 return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dsytrd status " + std::to_string(rs));
@@ -69,19 +127,26 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             if (!ws) return SDPSR_OUT_OF_MEMORY;
             launch_sytrd(c, n, A, lda, w, E, tau, ws);
             if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "sytrd launch failed");
+            if (hipMemsetAsync(Z, 0, (size_t)ldz * ldz * sizeof(double), c->stream) != hipSuccess)
+                return ctx_fail(c, SDPSR_HIP_ERROR, "memset of the eigenvector buffer failed");
         }
         if (c->opts.eig_driver == 3)
-            rs = rocsolver_dsteqr(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)n, info);
+            rs = rocsolver_dsteqr(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)ldz, info);
         else
-            rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)n, info);
+            rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)ldz, info);
         if (rs != rocblas_status_success)
             return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver tridiagonal solver status " + std::to_string(rs));
-        rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                              (rocblas_int)n, (rocblas_int)n, A, (rocblas_int)lda, tau, Z,
-                              (rocblas_int)n);
-        if (rs != rocblas_status_success)
-            return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dormtr status " + std::to_string(rs));
-        if (hipMemcpy2DAsync(A, lda * sizeof(double), Z, n * sizeof(double), n * sizeof(double), n,
+        if (own) {
+            const int bst = backtransform_device(c, n, A, lda, tau, Z);
+            if (bst) return bst;
+        } else {
+            rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                  (rocblas_int)n, (rocblas_int)n, A, (rocblas_int)lda, tau, Z,
+                                  (rocblas_int)ldz);
+            if (rs != rocblas_status_success)
+                return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver_dormtr status " + std::to_string(rs));
+        }
+        if (hipMemcpy2DAsync(A, lda * sizeof(double), Z, ldz * sizeof(double), n * sizeof(double), n,
                              hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             return ctx_fail(c, SDPSR_HIP_ERROR, "copy of eigenvectors failed");
     }

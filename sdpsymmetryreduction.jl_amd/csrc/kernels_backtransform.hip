@@ -1,0 +1,94 @@
+// Back-transformation of the symmetric eigensolver: eigenvectors of A = Q T Q' are Q Z with Z the
+// eigenvectors of the tridiagonal T (third phase of eigen(A), src/eigen_decomposition.jl:246;
+// LAPACK dormtr).  Q = H_0 H_1 ... H_{n-2} is applied in blocks of 128 reflectors in compact-WY
+// form, Q_b = I - V_b T_b V_b', last block first, and every O(n^3) step is a product on the fp64
+// matrix cores (gemm_tn_dma_kernel<f64>, kernels_gemm.hip):
+//     G   = V_b' V_b                  Gram matrix of the panel            (split-K)
+//     T_b = larft(G, tau)             one workgroup, LDS
+//     X   = (V_b T_b)' as rows        128 x m, one small product
+//     W   = V_b' Z                    128 x n                             (split-K)
+//     Z  -= X' W                      m x n, K = 128, read-modify-write epilogue
+// The kernels here are the glue: panel extraction in the two operand layouts and the T factor.
+#include "sdpsr_internal.h"
+
+namespace sdpsr {
+
+constexpr int BT_KB = 128;  // reflectors per block
+
+// Vp (ld x 128 column-major) and VpT (ld x 128 row-major) <- block of reflectors j0 .. j0+127
+// stored LAPACK-style below the subdiagonal of A: v_j = [0 .. 0, 1 (row j+1), A[j+2.., j]].
+// Reflectors past n-2 do not exist: zero columns.  Rows r0 .. ld-1 are written (r0 multiple of 128).
+__global__ void __launch_bounds__(256)
+bt_extract_panel_kernel(int n, int64_t ld, const double* __restrict__ A, int j0, int r0, double* __restrict__ Vp,
+                        double* __restrict__ VpT) {
+    __shared__ double tile[64][65];
+    // tile of 64 rows x 64 panel columns
+    const int rb = r0 + blockIdx.x * 64, cb = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int r = rb + tx, c = cb + cc, j = j0 + c;
+        double v = 0.0;
+        if (r < n && j <= n - 2) {
+            if (r == j + 1) v = 1.0;
+            else if (r > j + 1) v = A[r + (int64_t)j * ld];
+        }
+        Vp[r + (int64_t)c * ld] = v;
+        tile[cc][tx] = v;
+    }
+    __syncthreads();
+    for (int rr = ty; rr < 64; rr += 4) VpT[(int64_t)(rb + rr) * BT_KB + cb + tx] = tile[tx][rr];
+}
+
+// T (128 x 128, column-major, upper triangular) from the Gram matrix G = V'V and tau (dlarft,
+// forward / columnwise):  T[j,j] = tau_j,  T[0:j, j] = -tau_j * T[0:j, 0:j] * G[0:j, j].
+// One workgroup; T and the needed part of G live in LDS (2 x 128 KiB would not fit: the strictly
+// upper triangle of G is packed).  Thread i owns row i of T.
+__global__ void __launch_bounds__(128)
+bt_larft_kernel(const double* __restrict__ G, const double* __restrict__ tau, int j0, int n, double* __restrict__ T) {
+    extern __shared__ double sm[];
+    double* sT = sm;                    // 128 x 128, ld 129 (row i read by thread i: conflict-free)
+    double* sg = sT + 128 * 129;        // current column of G (128)
+    __shared__ double s_tau[128];
+    const int i = threadIdx.x;
+    for (int e = i; e < 128 * 129; e += 128) sT[e] = 0.0;
+    {
+        const int j = j0 + i;
+        s_tau[i] = (j <= n - 2) ? tau[j] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < 128; ++j) {
+        sg[i] = (i < j) ? G[i + (int64_t)j * 128] : 0.0;
+        __syncthreads();
+        const double tj = s_tau[j];
+        double acc = 0.0;
+        if (i < j) {
+            // (T[0:j,0:j] * g)[i] = sum_{k >= i} T[i,k] g[k]  (T upper triangular)
+            for (int k = i; k < j; ++k) acc = fma(sT[i * 129 + k], sg[k], acc);
+            acc = -tj * acc;
+        }
+        __syncthreads();
+        if (i < j) sT[i * 129 + j] = acc;
+        if (i == j) sT[i * 129 + j] = tj;
+    }
+    __syncthreads();
+    for (int e = i; e < 128 * 128; e += 128) {
+        const int c = e >> 7, r = e & 127;
+        T[r + (int64_t)c * 128] = sT[r * 129 + c];
+    }
+}
+
+void backtransform_set_device_attributes() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (128 * 129 + 128) * 8);
+}
+
+void launch_bt_extract_panel(hipStream_t s, int64_t n, int64_t ld, const double* A, int64_t j0, int64_t r0, double* Vp,
+                             double* VpT) {
+    dim3 grid((unsigned)((ld - r0) / 64), 2);
+    bt_extract_panel_kernel<<<grid, 256, 0, s>>>((int)n, ld, A, (int)j0, (int)r0, Vp, VpT);
+}
+void launch_bt_larft(hipStream_t s, const double* G, const double* tau, int64_t j0, int64_t n, double* T) {
+    bt_larft_kernel<<<1, 128, (128 * 129 + 128) * 8, s>>>(G, tau, (int)j0, (int)n, T);
+}
+
+}  // namespace sdpsr

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(NT)
 gemm_tn_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag, int64_t lda,
                const typename GemmTraits<KIND>::in_t* __restrict__ Bg, int64_t ldb,
                typename GemmTraits<KIND>::out_t* __restrict__ Cg, int64_t ldc, int64_t strideA,
-               int64_t strideB, int64_t strideC, const uint32_t* __restrict__ nonsym_flag) {
+               int64_t strideB, int64_t strideC, const uint32_t* __restrict__ nonsym_flag, int cmode) {
     typedef GemmTraits<KIND> TR;
     typedef typename TR::in_t in_t;
     typedef typename TR::out_t out_t;
@@ -220,17 +220,34 @@ gemm_tn_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag
             __syncthreads();
         }
         // D[jj][ii]: ii = lane & 15, jj = (lane >> 4) + 4 * reg
+        if (cmode == 0) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                const int64_t ii = i0 + wi * 64 + ti * 16 + r16;
+                for (int ti = 0; ti < 4; ++ti) {
+                    const int64_t ii = i0 + wi * 64 + ti * 16 + r16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t jj = j0 + wj * 64 + tj * 16 + g + 4 * r;
-                    C[ii + jj * ldc] = acc[tj][ti][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t jj = j0 + wj * 64 + tj * 16 + g + 4 * r;
+                        C[ii + jj * ldc] = acc[tj][ti][r];
+                    }
                 }
+        } else {  // C -= A'B: batches of 16 independent loads, then the stores
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                out_t cv[4][4];
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cv[ti][r] = C[(i0 + wi * 64 + ti * 16 + r16) + (j0 + wj * 64 + tj * 16 + g + 4 * r) * ldc];
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        C[(i0 + wi * 64 + ti * 16 + r16) + (j0 + wj * 64 + tj * 16 + g + 4 * r) * ldc] = cv[ti][r] - acc[tj][ti][r];
             }
+        }
     }
 }
 
@@ -251,7 +268,7 @@ __global__ void __launch_bounds__(NT)
 gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag, int64_t lda,
                    const typename GemmTraits<KIND>::in_t* __restrict__ Bg, int64_t ldb,
                    typename GemmTraits<KIND>::out_t* __restrict__ Cg, int64_t ldc, int64_t strideA, int64_t strideB,
-                   int64_t strideC, const uint32_t* __restrict__ nonsym_flag) {
+                   int64_t strideC, const uint32_t* __restrict__ nonsym_flag, int cmode) {
     typedef typename GemmTraits<KIND>::in_t in_t;
     typedef typename GemmTraits<KIND>::out_t out_t;
     constexpr int ES = sizeof(in_t);
@@ -441,17 +458,34 @@ gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        if (cmode == 0) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                const int64_t ii = i0 + wi * 64 + ti * 16 + r16;
+                for (int ti = 0; ti < 4; ++ti) {
+                    const int64_t ii = i0 + wi * 64 + ti * 16 + r16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t jj = j0 + wj * 64 + tj * 16 + g + 4 * r;
-                    C[ii + jj * ldc] = acc[tj][ti][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t jj = j0 + wj * 64 + tj * 16 + g + 4 * r;
+                        C[ii + jj * ldc] = acc[tj][ti][r];
+                    }
                 }
+        } else {  // C -= A'B: batches of 16 independent loads, then the stores
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                out_t cv[4][4];
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cv[ti][r] = C[(i0 + wi * 64 + ti * 16 + r16) + (j0 + wj * 64 + tj * 16 + g + 4 * r) * ldc];
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        C[(i0 + wi * 64 + ti * 16 + r16) + (j0 + wj * 64 + tj * 16 + g + 4 * r) * ldc] = cv[ti][r] - acc[tj][ti][r];
             }
+        }
     }
 }
 
@@ -635,7 +669,8 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
                         const typename GemmTraits<KIND>::in_t* A, int64_t lda,
                         const typename GemmTraits<KIND>::in_t* B, int64_t ldb,
                         typename GemmTraits<KIND>::out_t* C, int64_t ldc, int batch,
-                        int64_t strideA, int64_t strideB, int64_t strideC, const uint32_t* nonsym_flag = nullptr) {
+                        int64_t strideA, int64_t strideB, int64_t strideC, const uint32_t* nonsym_flag = nullptr,
+                        int cmode = 0) {
     constexpr int KB = GemmTraits<KIND>::KB;
     constexpr size_t lds = 2 * 2 * BM * (KB + 16);
     dim3 grid((unsigned)(m / BM), (unsigned)(n / BN), (unsigned)batch);
@@ -657,10 +692,10 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
             }
         }
         constexpr size_t lds_dma = 2 * 2 * BM * 128;  // 64 KiB
-        gemm_tn_dma_kernel<KIND><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
+        gemm_tn_dma_kernel<KIND><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag, cmode);
         return;
     }
-    gemm_tn_kernel<KIND><<<grid, NT, lds, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
+    gemm_tn_kernel<KIND><<<grid, NT, lds, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag, cmode);
 }
 
 void launch_gemm_tn_i8(hipStream_t s, int64_t m, int64_t n, int64_t k, const int8_t* A,
@@ -677,6 +712,11 @@ void launch_gemm_tn_f64(hipStream_t s, int64_t m, int64_t n, int64_t k, const do
                         int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                         int batch, int64_t strideA, int64_t strideB, int64_t strideC) {
     launch_gemm<KIND_F64>(s, m, n, k, A, lda, B, ldb, C, ldc, batch, strideA, strideB, strideC);
+}
+// C -= A' * B (the compact-WY updates of the back-transformation)
+void launch_gemm_tn_f64_sub(hipStream_t s, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                            int64_t ldb, double* C, int64_t ldc) {
+    launch_gemm<KIND_F64>(s, m, n, k, A, lda, B, ldb, C, ldc, 1, 0, 0, 0, nullptr, 1);
 }
 
 // C = X'X with only the lower-triangle tiles computed while *nonsym_flag == 0 (device-side

@@ -2,151 +2,309 @@
 // (first phase of eigen(A), src/eigen_decomposition.jl:246; LAPACK dsytrd/dlatrd, lower).
 //
 // Design (MI355X-first, not a translation of dlatrd's BLAS-2 call sequence):
-//  * the full symmetric trailing matrix is kept (both triangles), so the big product
-//    p = A v of every column is a set of contiguous column dots: one wave per column,
-//    16-byte loads, v staged once per workgroup in LDS, no atomics, no cross-workgroup
-//    reduction for p (bitwise reproducible);
+//  * only the LOWER triangle of the trailing matrix is stored, read and updated.  The big
+//    product p = A v of every column reads each stored entry ONCE and uses it twice
+//    (p_r += a_rc v_c and p_c += a_rc v_r): half the HBM bytes of a full-matrix product, and the
+//    two triangles can never drift apart in rounding.  Tiles of 128 rows x 64 columns, a
+//    workgroup walks down a 64-column strip; the "direct" sums (rows of the tile) leave per
+//    tile, the "transposed" sums (columns of the strip) stay in registers for the whole walk.
+//    Every partial sum goes to its own slot (no atomics, bitwise reproducible); the next
+//    launch adds them up;
 //  * two launches per column, both spread over the whole chip:
-//      form_kernel (j):   finish W(:, j-1) from the column dots (corrections with the panel
-//                         V, W; the v'Av term comes from per-workgroup partials), then form
-//                         the updated column a_j = A(:,j) - V W(j,:)' - W V(j,:)' and its
-//                         partial squared norms;
+//      form_kernel (j):   sum the partial products of column j-1, finish W(:, j-1) (corrections
+//                         with the panel V, W), then form the updated column
+//                         a_j = A(:,j) - V W(j,:)' - W V(j,:)' and its partial squared norms;
 //      symv_kernel (j):   every workgroup redundantly finishes the reflector scalars
-//                         (beta, tau, scale) from the partial norms, builds v in LDS and
-//                         computes its share of p = A v, W'v, V'v and v'p;
-//  * after NB columns the trailing matrix gets the rank-2NB update A -= V W' + W V' (both
-//    triangles) in one tiled kernel.
+//                         (beta, tau, scale) from the partial norms and computes its share of
+//                         p = A v, W'v, V'v and v'p  (v is never materialised: v_r = a_rj * scale);
+//    a kernel boundary (~1.5 us) is the cheapest chip-wide synchronisation on this part, cheaper
+//    than any in-kernel grid barrier (4-5 us), so the launches are captured into a hipGraph once
+//    per shape and replayed;
+//  * the panel [V | W] is kept row-major (64 doubles per row), which is at once the coalesced
+//    layout for the per-row corrections and the K-contiguous operand layout of the MFMA kernel;
+//  * after NB = 32 columns the trailing matrix gets the rank-2NB update A -= V W' + W V' on the
+//    matrix cores: v_mfma_f64_16x16x4_f64, 128 x 128 tiles of the lower triangle, K = 64, both
+//    operands streamed global -> LDS directly (same staging as kernels_gemm.hip).
 // Output is LAPACK-compatible (d, e, tau, reflectors below the subdiagonal of A), so the
-// tridiagonal solve (rocSOLVER stedc) and the back-transformation (ormtr) plug in unchanged.
+// tridiagonal solve (rocSOLVER stedc) and the back-transformation plug in unchanged.
 #include <cstdlib>
 #include "sdpsr_internal.h"
 #include "jacobi64.h"
 
 namespace sdpsr {
 
-constexpr int SY_NB = 32;       // panel width
+constexpr int SY_NB = 32;            // panel width
+constexpr int SY_PW = 2 * SY_NB;     // doubles per panel row: [V(r, 0..NB) | W(r, 0..NB)]
 constexpr int SY_THREADS = 256;
+constexpr int SY_TR = 128;           // tile rows of the symmetric product
+constexpr int SY_TC = 64;            // strip width (tile columns)
+constexpr int SY_FROWS = 64;         // rows per workgroup of the form kernel
+constexpr int SY_MAXSEG = 40;        // segments of a strip (rows of the transposed-partials buffer)
+constexpr int SY_MAXVAV = 4096;      // slots of per-workgroup v'Av partials
 
 struct SytrdArgs {
-    double* A;        // n x n, leading dimension ld (even), full symmetric on entry
+    double* A;          // n x n, leading dimension ld (multiple of 128), lower triangle referenced
     int64_t ld;
     int n;
-    double* Vp;       // ld x NB panel of reflectors (explicit, v[j+1] = 1)
-    double* Wp;       // ld x NB panel W
-    double* p0;       // n: A v
-    double* g1;       // NB: W' v
-    double* g2;       // NB: V' v
+    double* PT;         // ld x SY_PW, row-major panel
+    double* Pdir;       // (ld / 64) x ld: direct partial products, one row per strip
+    double* Ptr;        // SY_MAXSEG x ld: transposed partial products, one row per segment
+    double* Gpart;      // (ld / 64 + 1) x SY_PW: partial panel dots [V'v | W'v], one row per 64 matrix rows
     double* part_norm;  // per form-workgroup partial sum of a[r]^2, r >= j+2
-    double* part_vav;   // per symv-workgroup partial of v' (A v)
+    double* part_vav;   // per symv-workgroup partial of v'(A v)
+    double* scal;       // [0] tau, [1] beta, [2] scale of the reflector in flight
     double* d;
     double* e;
     double* tau;
 };
 
+// geometry of the symv launch of column j (shared by the launch and by the form kernel that sums
+// its partials)
+struct SymvGeom {
+    int S0;      // first strip with a column > j
+    int nstr;    // strips S0 .. S0 + nstr - 1
+    int SEG;     // tiles per workgroup
+    int maxseg;  // segments of the longest strip
+    int G;       // panel-dot workgroups (0 when the panel is empty)
+    int grid;    // nstr * maxseg tile workgroups (those past a strip's last segment idle) + G
+};
+static SymvGeom symv_geometry(int n, int j, int cf) {
+    SymvGeom g;
+    const int nt128 = (n + SY_TR - 1) / SY_TR;
+    const int nstrips = (n + SY_TC - 1) / SY_TC;
+    g.S0 = (j + 1) / SY_TC;
+    g.nstr = nstrips - g.S0;
+    long tiles = 0;
+    for (int S = g.S0; S < nstrips; ++S) tiles += nt128 - (S >> 1);
+    int seg = (int)((tiles + 383) / 384);  // ~1.5 workgroups per CU, each streaming `seg` tiles back to back
+    if (seg < 1) seg = 1;
+    if (seg > 8) seg = 8;
+    g.SEG = seg;
+    g.maxseg = (nt128 - (g.S0 >> 1) + seg - 1) / seg;
+    const int m = n - j - 1;
+    g.G = cf > 0 ? (m + 63) / 64 : 0;  // 64 rows per panel-dot workgroup
+    g.grid = g.nstr * g.maxseg + g.G;
+    return g;
+}
+
 // ---------------------------------------------------------------------------
-// form_kernel: rows r in [j, n); a workgroup owns SY_FROWS = 64 rows, its 4 waves split the
-// panel columns (c = wave, wave + 4, ...) so that the 2 x cf strided panel reads of a row are
-// spread over four waves and issued in batches; partial sums meet in LDS.
-//   do_finish: column jf = j-1 (panel column cf) gets its W column.
+// form_kernel: rows r in [j, n); a workgroup owns SY_FROWS = 64 rows.
+//   do_finish: column jf = j-1 (panel column cf) gets its W column: the partial products of
+//              symv(jf) are summed here (geometry S0 / SEG / G of that launch).
 //   do_form:   column j is updated with the finished panel columns and its norm partials
 //              are produced.  n_vav = number of part_vav entries written by symv(jf).
 // ---------------------------------------------------------------------------
-constexpr int SY_FROWS = 64;
-
 __global__ void __launch_bounds__(SY_THREADS)
-sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_vav) {
-    __shared__ double s_g1[SY_NB], s_g2[SY_NB], s_wrow[SY_NB + 1], s_vrow[SY_NB + 1];
-    __shared__ double s_part[4][2][SY_FROWS];
-    __shared__ double s_scal[2];  // tau, alpha2
+sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_vav, int S0, int SEG, int G) {
+    __shared__ double s_raw[SY_PW], s_Gf[SY_PW], s_Mf[SY_PW], s_graw[4][SY_PW];
+    __shared__ double s_psum[4][SY_FROWS], s_sf[SY_FROWS], s_sm[SY_FROWS];
+    __shared__ double s_scal[4];  // tau, alpha2, p0[j], sf of row j
+    __shared__ double s_vavw[4];
     const int tid = threadIdx.x;
     const int lane = tid & 63, q = tid >> 6;
     const int64_t ld = a.ld;
     const int n = a.n;
     const int jf = j - 1;
-    const int r = j + blockIdx.x * SY_FROWS + lane;
+    const int rbase = j + blockIdx.x * SY_FROWS;
+    const int r = rbase + lane;
+    const int nt128 = (n + SY_TR - 1) / SY_TR;
 
-    // independent loads first (they overlap the reductions below)
-    double pre_v = 0, pre_p0 = 0, pre_x = 0;
+    // ---- independent loads first (every global load of this kernel is issued before the first
+    // barrier: a dependent load costs a memory round trip on the critical path of the column)
+    const double pre_tau = do_finish ? a.scal[0] : 0.0, pre_scale = do_finish ? a.scal[2] : 0.0;
+    double pre_raw = 0, pre_x = 0;
     if (q == 0 && r < n) {
-        if (do_finish) {
-            pre_v = a.Vp[r + (int64_t)cf * ld];
-            pre_p0 = a.p0[r];
-        }
+        if (do_finish) pre_raw = a.A[r + (int64_t)jf * ld];
         if (do_form) pre_x = a.A[r + (int64_t)j * ld];
     }
-    double pv[SY_NB / 4], pw[SY_NB / 4];
-#pragma unroll
-    for (int u = 0; u < SY_NB / 4; ++u) {
-        const int c = q + 4 * u;
-        const bool ok = (r < n) && (c < cf);
-        pv[u] = ok ? a.Vp[r + (int64_t)c * ld] : 0.0;
-        pw[u] = ok ? a.Wp[r + (int64_t)c * ld] : 0.0;
-    }
-
     if (do_finish) {
-        if (tid < cf) {
-            s_g1[tid] = a.g1[tid];
-            s_g2[tid] = a.g2[tid];
-        }
-        if (q == 1) {  // wave 1: fixed-shape tree reductions (bitwise reproducible)
-            double vav = 0;
-            for (int b = lane; b < n_vav; b += 64) vav += a.part_vav[b];
-            double gg = (lane < cf) ? a.g1[lane] * a.g2[lane] : 0.0;
+        // partial products of row r (and, by wave 3 afterwards, of row j): wave q takes every
+        // fourth slot; loads are coalesced along the rows and issued in predicated batches of 8
+        // (a loop with one load per trip serialises the memory latency)
+        double ps = 0;
+        if (r < n) {
+            const int Sr = r / SY_TC;
+            const int cnt = (Sr >= S0 + q) ? (Sr - S0 - q) / 4 + 1 : 0;
+            for (int b0 = 0; b0 < cnt; b0 += 16) {
+                double tv[16];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                vav += __shfl_down(vav, o, 64);
-                gg += __shfl_down(gg, o, 64);
+                for (int u = 0; u < 16; ++u) {
+                    const bool ok = b0 + u < cnt;
+                    const int S = S0 + q + 4 * (ok ? b0 + u : 0);
+                    const double x = a.Pdir[(int64_t)S * ld + r];
+                    tv[u] = ok ? x : 0.0;
+                }
+                ps += (((tv[0] + tv[1]) + (tv[2] + tv[3])) + ((tv[4] + tv[5]) + (tv[6] + tv[7]))) +
+                      (((tv[8] + tv[9]) + (tv[10] + tv[11])) + ((tv[12] + tv[13]) + (tv[14] + tv[15])));
             }
+            const int nseg = (nt128 - (Sr >> 1) + SEG - 1) / SEG;
+            const int cnt2 = (nseg > q) ? (nseg - 1 - q) / 4 + 1 : 0;
+            for (int b0 = 0; b0 < cnt2; b0 += 4) {
+                double tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = b0 + u < cnt2;
+                    const int sg = q + 4 * (ok ? b0 + u : 0);
+                    const double x = a.Ptr[(int64_t)sg * ld + r];
+                    tv[u] = ok ? x : 0.0;
+                }
+                ps += (tv[0] + tv[1]) + (tv[2] + tv[3]);
+            }
+        }
+        s_psum[q][lane] = ps;
+        // panel dots [V'v | W'v]: 256 threads sum the G partial vectors, four slots per panel entry
+        {
+            const int k = tid & (SY_PW - 1), part = tid >> 6;
+            double g = 0;
+            for (int b0 = part; b0 < G; b0 += 16) {
+                double tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int b = b0 + 4 * u;
+                    const double x = a.Gpart[(b < G ? b : 0) * SY_PW + k];
+                    tv[u] = (b < G) ? x : 0.0;
+                }
+                g += (tv[0] + tv[1]) + (tv[2] + tv[3]);
+            }
+            s_graw[part][k] = g;
+        }
+    }
+    if (do_form && tid < SY_PW)  // row j of the panel with the halves swapped: [W(j,:) | V(j,:)]
+        s_Mf[tid] = ((tid & (SY_NB - 1)) < cf) ? a.PT[(int64_t)j * SY_PW + (tid ^ SY_NB)] : 0.0;
+    // v'Av partials: all 256 threads, independent loads issued before the first barrier
+    double vav = 0;
+    if (do_finish) {
+        for (int b0 = tid; b0 < n_vav; b0 += SY_THREADS * 8) {
+            double tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + SY_THREADS * u;
+                const double x = a.part_vav[b < n_vav ? b : 0];
+                tv[u] = (b < n_vav) ? x : 0.0;
+            }
+            vav += ((tv[0] + tv[1]) + (tv[2] + tv[3])) + ((tv[4] + tv[5]) + (tv[6] + tv[7]));
+        }
+    }
+    // row j: product partials (wave 3) -- also independent of everything above
+    double psj = 0;
+    if (do_finish && q == 3) {
+        const int Sj = j / SY_TC;
+        const int nsegj = (nt128 - (Sj >> 1) + SEG - 1) / SEG;
+        const bool ok1 = S0 + lane <= Sj, ok2 = lane < nsegj;
+        const double x1 = a.Pdir[(int64_t)(ok1 ? S0 + lane : S0) * ld + j];
+        const double x2 = a.Ptr[(int64_t)(ok2 ? lane : 0) * ld + j];
+        psj = (ok1 ? x1 : 0.0) + (ok2 ? x2 : 0.0);
+    }
+    // the 16 panel rows of this wave: 4 lanes per row, 16 consecutive panel entries per lane (128
+    // bytes); the wave reads 8 KiB contiguous.  Row j (needed by all rows) goes to wave 2's lanes.
+    const int prow = lane >> 2, pq = lane & 3;  // row within the wave's 16, quarter of the panel row
+    double2 ptv[8], ptj[8];
+    if (cf > 0) {
+        const int rr = rbase + q * (SY_FROWS / 4) + prow;
+        const double2* src = reinterpret_cast<const double2*>(a.PT + (int64_t)(rr < n ? rr : j) * SY_PW + 16 * pq);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ptv[u] = src[u];
+        if (q == 2 && do_finish) {
+            const double2* sj = reinterpret_cast<const double2*>(a.PT + (int64_t)j * SY_PW + 16 * pq);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ptj[u] = sj[u];
+        }
+    }
+    if (do_finish) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vav += __shfl_down(vav, o, 64);
+        if (lane == 0) s_vavw[q] = vav;
+    }
+    __syncthreads();
+    if (do_finish && tid < SY_PW) s_raw[tid] = (s_graw[0][tid] + s_graw[1][tid]) + (s_graw[2][tid] + s_graw[3][tid]);
+    __syncthreads();
+    if (do_finish) {
+        // multiplier of PT[r][k] in  V(r,:) (W'v) + W(r,:) (V'v):  the other half's dot
+        if (tid < SY_PW) s_Gf[tid] = ((tid & (SY_NB - 1)) < cf) ? s_raw[tid ^ SY_NB] : 0.0;
+        if (q == 1) {  // fixed-shape tree reductions (bitwise reproducible)
+            double gg = (lane < cf) ? s_raw[lane] * s_raw[lane + SY_NB] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gg += __shfl_down(gg, o, 64);
             if (lane == 0) {
-                const double tau = a.tau[jf];
+                const double vav = (s_vavw[0] + s_vavw[1]) + (s_vavw[2] + s_vavw[3]);
+                const double tau = pre_tau;
                 const double dot = tau * (vav - 2.0 * gg);  // p'v with p = tau (A v - V g1 - W g2)
                 s_scal[0] = tau;
                 s_scal[1] = -0.5 * tau * dot;
             }
         }
-    }
-    if (do_form && tid < cf) {  // rows of the finished panel columns (before this launch)
-        s_wrow[tid] = a.Wp[j + (int64_t)tid * ld];
-        s_vrow[tid] = a.Vp[j + (int64_t)tid * ld];
-    }
-    __syncthreads();
-    if (do_finish && do_form && tid == 0) {
-        // row j of the W column that this launch finishes: needed by every row of the form part
-        double s = 0;
-        for (int c = 0; c < cf; ++c) s += s_vrow[c] * s_g1[c] + s_wrow[c] * s_g2[c];
-        const double vj = a.Vp[j + (int64_t)cf * ld];
-        s_wrow[cf] = s_scal[0] * (a.p0[j] - s) + s_scal[1] * vj;
-        s_vrow[cf] = vj;
-    }
-
-    double sf = 0, sm = 0;
+        if (q == 3) {  // row j: needed by every row of the form part
 #pragma unroll
-    for (int u = 0; u < SY_NB / 4; ++u) {
-        const int c = q + 4 * u;
-        if (c < cf) {
-            if (do_finish) sf += pv[u] * s_g1[c] + pw[u] * s_g2[c];
-            if (do_form) sm += pv[u] * s_wrow[c] + pw[u] * s_vrow[c];
+            for (int o = 32; o > 0; o >>= 1) psj += __shfl_down(psj, o, 64);
+            if (lane == 0) s_scal[2] = psj;
         }
     }
-    s_part[q][0][lane] = sf;
-    s_part[q][1][lane] = sm;
+    __syncthreads();
+    // ---- panel dots of the 64 rows
+    if (cf > 0) {
+        const int rr = rbase + q * (SY_FROWS / 4) + prow;
+        double sf = 0, sm = 0, sfj = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k0 = 16 * pq + 2 * u;
+            if (do_finish) {
+                sf = fma(ptv[u].x, s_Gf[k0], sf);
+                sf = fma(ptv[u].y, s_Gf[k0 + 1], sf);
+            }
+            if (do_form) {
+                sm = fma(ptv[u].x, s_Mf[k0], sm);
+                sm = fma(ptv[u].y, s_Mf[k0 + 1], sm);
+            }
+            if (q == 2 && do_finish) {
+                sfj = fma(ptj[u].x, s_Gf[k0], sfj);
+                sfj = fma(ptj[u].y, s_Gf[k0 + 1], sfj);
+            }
+        }
+        if (rr >= n) {
+            sf = 0;
+            sm = 0;
+        }
+        sf += __shfl_xor(sf, 1, 64);
+        sm += __shfl_xor(sm, 1, 64);
+        sfj += __shfl_xor(sfj, 1, 64);
+        sf += __shfl_xor(sf, 2, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        sfj += __shfl_xor(sfj, 2, 64);
+        if (pq == 0) {
+            s_sf[q * (SY_FROWS / 4) + prow] = sf;
+            s_sm[q * (SY_FROWS / 4) + prow] = sm;
+        }
+        if (q == 2 && do_finish && lane == 0) s_scal[3] = sfj;
+    } else {
+        if (tid < SY_FROWS) {
+            s_sf[tid] = 0.0;
+            s_sm[tid] = 0.0;
+        }
+        if (tid == 0) s_scal[3] = 0.0;
+    }
     __syncthreads();
     if (q != 0) return;
     double sq = 0;
     if (r < n) {
-        sf = s_part[0][0][lane] + s_part[1][0][lane] + s_part[2][0][lane] + s_part[3][0][lane];
-        sm = s_part[0][1][lane] + s_part[1][1][lane] + s_part[2][1][lane] + s_part[3][1][lane];
         double wnew = 0, v = 0;
         if (do_finish) {
-            v = pre_v;
-            wnew = s_scal[0] * (pre_p0 - sf) + s_scal[1] * v;
-            a.Wp[r + (int64_t)cf * ld] = wnew;
+            const double tau = s_scal[0], alpha2 = s_scal[1], scale = pre_scale;
+            v = (r == jf + 1) ? 1.0 : pre_raw * scale;
+            const double p0 = s_psum[0][lane] + s_psum[1][lane] + s_psum[2][lane] + s_psum[3][lane];
+            wnew = tau * (p0 - s_sf[lane]) + alpha2 * v;
+            a.PT[(int64_t)r * SY_PW + cf] = v;
+            a.PT[(int64_t)r * SY_PW + SY_NB + cf] = wnew;
             // LAPACK storage of the finished reflector: v below the subdiagonal of column jf
             if (r >= jf + 2) a.A[r + (int64_t)jf * ld] = v;
         }
         if (do_form) {
             double x = pre_x;
-            if (do_finish) sm += v * s_wrow[cf] + wnew * s_vrow[cf];
+            double sm = s_sm[lane];
+            if (do_finish) {
+                // row j of the column that this launch finishes: V(j, cf) = v_jf[jf+1] = 1
+                const double wj = s_scal[0] * (s_scal[2] - s_scal[3]) + s_scal[1];
+                sm += v * wj + wnew;
+            }
             x -= sm;
             a.A[r + (int64_t)j * ld] = x;
             if (r == j) a.d[j] = x;
@@ -161,38 +319,66 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
 }
 
 // ---------------------------------------------------------------------------
-// symv_kernel(j): reflector of column j (panel column cf), then column dots.
-//   work items: trailing columns k in [j+1, n) -> p0[k];  cf columns of Wp -> g1;  cf columns
-//   of Vp -> g2.  n_norm = number of part_norm entries written by form(j).
+// symv_kernel(j): reflector scalars of column j, then the symmetric product on the lower triangle.
+//   1-D grid: workgroup b < nstr * maxseg is segment b % maxseg of strip S0 + b / maxseg (workgroups
+//   past the strip's last segment idle); the last G workgroups are the panel dots.
 // ---------------------------------------------------------------------------
-template <int SY_MAXV>  // rows of column j held in registers per thread: n <= SY_MAXV * 256
-__global__ void __launch_bounds__(SY_THREADS)
-sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm) {
-    extern __shared__ __attribute__((aligned(16))) double s_v[];  // rows r0 .. n (r0 even)
-    __shared__ double s_bcast[3];
-    __shared__ double s_red[SY_THREADS / 64];
+__global__ void __launch_bounds__(SY_THREADS, 2)
+sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm, int S0, int SEG, int nstr, int maxseg, int G) {
+    __shared__ double s_y[2][4][SY_TR];
+    __shared__ double s_vr[2][SY_TR];
+    __shared__ double s_red[4];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar column bases
     const int64_t ld = a.ld;
     const int n = a.n;
-    const int r0 = (j + 1) & ~1;  // even start so that 16-byte loads are aligned
-    const int len = n - r0;       // entries of s_v
-    // raw column j (unscaled) first, so that these loads overlap the norm reduction
-    double raw[SY_MAXV];
-    const int nper = (len + SY_THREADS - 1) / SY_THREADS;
+    const double* __restrict__ colj = a.A + (int64_t)j * ld;
+    const int nt128 = (n + SY_TR - 1) / SY_TR;
+    const int ntile_wg = nstr * maxseg;
+    const bool tile_wg = (int)blockIdx.x < ntile_wg;
+    const int sy = tile_wg ? (int)blockIdx.x / maxseg : 0;
+    const int sx = tile_wg ? (int)blockIdx.x - sy * maxseg : (int)blockIdx.x - ntile_wg;  // segment / dot index
+    const int S = S0 + sy;
+    const int Ib = (S >> 1) + sx * SEG;
+    int Ie = Ib + SEG;
+    if (Ie > nt128) Ie = nt128;
+    const bool has_tiles = tile_wg && Ib < nt128;
+    const bool dot_wg = !tile_wg && sx < G;
+    const int col0 = SY_TC * S;
+
+    // ---- every load that does not depend on the reflector scalars is issued first: the first
+    // tile, the raw column entries of its rows and of the strip's columns, the norm partials
+    double2 x[16];
+    double2 rr = {0.0, 0.0};
+    double raw_c = 0.0;
+    if (has_tiles) {
+        const unsigned voff = (unsigned)(SY_TR * Ib + 2 * lane) * 8u;  // per-lane byte offset; column bases stay scalar
+        const char* __restrict__ cbase = reinterpret_cast<const char*>(a.A + (int64_t)(col0 + 16 * w) * ld);
 #pragma unroll
-    for (int u = 0; u < SY_MAXV; ++u) {
-        const int t = tid + u * SY_THREADS;
-        raw[u] = (u < nper && t < len && r0 + t >= j + 2) ? a.A[(r0 + t) + (int64_t)j * ld] : 0.0;
+        for (int cc = 0; cc < 16; ++cc) x[cc] = *reinterpret_cast<const double2*>(cbase + (int64_t)cc * ld * 8 + voff);
+        rr = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(colj) + voff);
+        if (lane < 16) raw_c = colj[col0 + 16 * w + lane];
+    } else if (dot_wg) {
+        // panel dots [V'v | W'v]: 64 rows per workgroup, 16 per wave, lane = panel entry
+        const int rb = j + 1 + sx * 64 + w * 16;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r2 = rb + u;
+            const int rs = r2 < n ? r2 : j;
+            x[u].x = a.PT[(int64_t)rs * SY_PW + lane];  // (the tile registers double as panel-row / raw-entry pairs)
+            x[u].y = colj[rs];
+        }
     }
-    if (wave == 0) {
+    // reflector scalars: every wave reduces the norm partials itself (same loads, same fixed-shape
+    // tree: bitwise the same result in every wave and workgroup) -- no LDS broadcast, no barrier
+    double scale;
+    {
         double xn2 = 0;
         for (int b = lane; b < n_norm; b += 64) xn2 += a.part_norm[b];
+        const double alpha = colj[j + 1];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) xn2 += __shfl_down(xn2, o, 64);
-      if (lane == 0) {
-        const double alpha = a.A[(j + 1) + (int64_t)j * ld];
-        double beta, tau, scale;
+        for (int o = 32; o > 0; o >>= 1) xn2 += __shfl_xor(xn2, o, 64);
+        double beta, tau;
         if (xn2 == 0.0) {  // dlarfg: H = I
             tau = 0.0;
             beta = alpha;
@@ -202,268 +388,336 @@ sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm) {
             tau = (beta - alpha) / beta;
             scale = 1.0 / (alpha - beta);
         }
-        s_bcast[0] = beta;
-        s_bcast[1] = tau;
-        s_bcast[2] = scale;
-        if (blockIdx.x == 0) {
+        if (blockIdx.x == 0 && tid == 0) {
             a.e[j] = beta;
             a.tau[j] = tau;
-        }
-      }
-    }
-    __syncthreads();
-    const double scale = s_bcast[2];
-#pragma unroll
-    for (int u = 0; u < SY_MAXV; ++u) {
-        const int t = tid + u * SY_THREADS;
-        if (u < nper && t < len) {
-            const int r = r0 + t;
-            double v;
-            if (r <= j) v = 0.0;
-            else if (r == j + 1) v = 1.0;
-            else v = raw[u] * scale;
-            s_v[t] = v;
-            if (blockIdx.x == 0 && r > j) a.Vp[r + (int64_t)cf * ld] = v;
+            a.scal[0] = tau;
+            a.scal[1] = beta;
+            a.scal[2] = scale;
         }
     }
-    if ((len & 1) && tid == 0) s_v[len] = 0.0;  // pad for the double2 reads
-    __syncthreads();
-
-    const int ncols = n - (j + 1);
-    const int nwork = ncols + 2 * cf;
-    const int wpb = SY_THREADS / 64;
+    // v_r = 0 (r <= j), 1 (r = j+1), a_rj * scale (below): never materialised
+    auto vval = [&](int r, double raw) -> double { return r <= j ? 0.0 : (r == j + 1 ? 1.0 : raw * scale); };
     double vav = 0;
-    const int len2 = (len + 1) >> 1;  // double2 elements
-    const double2* sv2 = reinterpret_cast<const double2*>(s_v);
-    auto col_ptr = [&](int w) -> const double2* {
-        const double* col;
-        if (w < ncols) col = a.A + (int64_t)(j + 1 + w) * ld;
-        else if (w < ncols + cf) col = a.Wp + (int64_t)(w - ncols) * ld;
-        else col = a.Vp + (int64_t)(w - ncols - cf) * ld;
-        return reinterpret_cast<const double2*>(col + r0);
-    };
-    auto emit = [&](int w, double acc) {
-        if (w < ncols) {
-            a.p0[j + 1 + w] = acc;
-            vav += acc * s_v[(j + 1 + w) - r0];
-        } else if (w < ncols + cf) {
-            a.g1[w - ncols] = acc;
-        } else {
-            a.g2[w - ncols - cf] = acc;
+    if (has_tiles) {
+        // v of the wave's 16 columns: computed by lanes 0..15, read back lane by lane (scalar operands)
+        double vc_l = 0.0;
+        if (lane < 16) {
+            const int cidx = col0 + 16 * w + lane;
+            vc_l = (cidx < n) ? vval(cidx, raw_c) : 0.0;
         }
-    };
-    // a wave walks two columns at a time: four 16-byte loads in flight per lane, and every v
-    // value read from LDS serves both columns.  (The tail double2 of an odd-length column
-    // reads one element past row n-1: ld is even and > n there, and the matching s_v pad is 0.)
-    const int nwaves = gridDim.x * wpb;
-    const int npairs = (nwork + 1) >> 1;
-    for (int pr = blockIdx.x * wpb + wave; pr < npairs; pr += nwaves) {
-        const int w0 = 2 * pr, w1 = (2 * pr + 1 < nwork) ? 2 * pr + 1 : 2 * pr;
-        const double2* c0 = col_ptr(w0);
-        const double2* c1 = col_ptr(w1);
-        double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-        int t = lane;
-        for (; t + 64 < len2; t += 128) {
-            const double2 x0 = c0[t], x1 = c0[t + 64];
-            const double2 y0 = c1[t], y1 = c1[t + 64];
-            const double2 v0 = sv2[t], v1 = sv2[t + 64];
-            a00 = fma(x0.x, v0.x, a00);
-            a00 = fma(x0.y, v0.y, a00);
-            a01 = fma(x1.x, v1.x, a01);
-            a01 = fma(x1.y, v1.y, a01);
-            a10 = fma(y0.x, v0.x, a10);
-            a10 = fma(y0.y, v0.y, a10);
-            a11 = fma(y1.x, v1.x, a11);
-            a11 = fma(y1.y, v1.y, a11);
-        }
-        for (; t < len2; t += 64) {
-            const double2 x0 = c0[t];
-            const double2 y0 = c1[t];
-            const double2 v0 = sv2[t];
-            a00 = fma(x0.x, v0.x, a00);
-            a00 = fma(x0.y, v0.y, a00);
-            a10 = fma(y0.x, v0.x, a10);
-            a10 = fma(y0.y, v0.y, a10);
-        }
-        double acc0 = a00 + a01, acc1 = a10 + a11;
+        double vcol[16];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            acc0 += __shfl_down(acc0, o, 64);
-            acc1 += __shfl_down(acc1, o, 64);
+        for (int cc = 0; cc < 16; ++cc) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(vc_l), cc);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(vc_l), cc);
+            vcol[cc] = __hiloint2double(hi, lo);
         }
-        if (lane == 0) {
-            emit(w0, acc0);
-            if (w1 != w0) emit(w1, acc1);
+        double z[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) z[cc] = 0.0;
+        // two register sets: the loads of tile I+1 are in flight while tile I is consumed
+        double2 xn[16];
+        double2 rrn = {0.0, 0.0};
+        const char* __restrict__ cbase = reinterpret_cast<const char*>(a.A + (int64_t)(col0 + 16 * w) * ld);
+        auto consume = [&](int I, int buf, const double2 (&xx)[16], const double2 rrr) {
+            const int row0 = SY_TR * I + 2 * lane;
+            const double vr0 = (row0 < n) ? vval(row0, rrr.x) : 0.0;
+            const double vr1 = (row0 + 1 < n) ? vval(row0 + 1, rrr.y) : 0.0;
+            double y0 = 0, y1 = 0;
+            if (SY_TR * I >= col0 + SY_TC) {  // tile strictly below the diagonal
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    const double vcc = vcol[cc];
+                    y0 = fma(xx[cc].x, vcc, y0);
+                    y1 = fma(xx[cc].y, vcc, y1);
+                    z[cc] = fma(xx[cc].x, vr0, z[cc]);
+                    z[cc] = fma(xx[cc].y, vr1, z[cc]);
+                }
+            } else {  // the tile meets the diagonal: rows >= columns for the direct part, > for the transposed
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    const int cidx = col0 + 16 * w + cc;
+                    const double vcc = vcol[cc];
+                    const double x0 = (row0 >= cidx) ? xx[cc].x : 0.0;
+                    const double x1 = (row0 + 1 >= cidx) ? xx[cc].y : 0.0;
+                    y0 = fma(x0, vcc, y0);
+                    y1 = fma(x1, vcc, y1);
+                    z[cc] = fma((row0 > cidx) ? xx[cc].x : 0.0, vr0, z[cc]);
+                    z[cc] = fma((row0 + 1 > cidx) ? xx[cc].y : 0.0, vr1, z[cc]);
+                }
+            }
+            s_y[buf][w][2 * lane] = y0;
+            s_y[buf][w][2 * lane + 1] = y1;
+            if (w == 0) {
+                s_vr[buf][2 * lane] = vr0;
+                s_vr[buf][2 * lane + 1] = vr1;
+            }
+            __syncthreads();
+            if (tid < SY_TR) {
+                const double tot = (s_y[buf][0][tid] + s_y[buf][1][tid]) + (s_y[buf][2][tid] + s_y[buf][3][tid]);
+                a.Pdir[(int64_t)S * ld + SY_TR * I + tid] = tot;
+                vav = fma(tot, s_vr[buf][tid], vav);
+            }
+        };
+        auto fetch = [&](int I, double2 (&xx)[16], double2& rrr) {
+            const unsigned voff = (unsigned)(SY_TR * I + 2 * lane) * 8u;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) xx[cc] = *reinterpret_cast<const double2*>(cbase + (int64_t)cc * ld * 8 + voff);
+            rrr = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(colj) + voff);
+        };
+        for (int I = Ib; I < Ie; I += 2) {
+            if (I + 1 < Ie) fetch(I + 1, xn, rrn);
+            consume(I, 0, x, rr);
+            if (I + 1 < Ie) {
+                if (I + 2 < Ie) fetch(I + 2, x, rr);
+                consume(I + 1, 1, xn, rrn);
+            }
         }
+        // transposed sums: reduce-scatter over the 64 lanes (rows), 16 columns per lane
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int half = 8 >> st, step = 32 >> st;
+            const bool upper = (lane & step) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const double send = upper ? z[i] : z[i + half];
+                const double keep = upper ? z[i + half] : z[i];
+                z[i] = keep + __shfl_xor(send, step, 64);
+            }
+        }
+        z[0] += __shfl_xor(z[0], 2, 64);
+        z[0] += __shfl_xor(z[0], 1, 64);
+        {
+            const int cc = (((lane >> 5) & 1) << 3) | (((lane >> 4) & 1) << 2) | (((lane >> 3) & 1) << 1) | ((lane >> 2) & 1);
+            const double vsel = __shfl(vc_l, cc, 64);  // all lanes active: the source lanes 0..15 must be
+            if ((lane & 3) == 0) {
+                a.Ptr[(int64_t)sx * ld + col0 + 16 * w + cc] = z[0];
+                vav = fma(z[0], vsel, vav);
+            }
+        }
+    } else if (dot_wg) {
+        const int rb = j + 1 + sx * 64 + w * 16;
+        double acc = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r2 = rb + u;
+            acc = fma(x[u].x, (r2 < n) ? vval(r2, x[u].y) : 0.0, acc);
+        }
+        s_y[0][w][lane] = acc;
+        __syncthreads();
+        if (tid < SY_PW)
+            a.Gpart[sx * SY_PW + tid] = (s_y[0][0][tid] + s_y[0][1][tid]) + (s_y[0][2][tid] + s_y[0][3][tid]);
     }
-    if (lane == 0) s_red[wave] = vav;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vav += __shfl_down(vav, o, 64);
+    if (lane == 0) s_red[w] = vav;
     __syncthreads();
-    if (tid == 0) a.part_vav[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tid == 0) a.part_vav[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
 // ---------------------------------------------------------------------------
-// rank-2NB update of the trailing matrix:
-//   A[r, s] -= sum_c V[r,c] W[s,c] + W[r,c] V[s,c],   r, s >= j1
-// Only tiles with r-tile >= s-tile are computed; every value is written to (r,s) AND (s,r), so
-// the trailing matrix stays bitwise symmetric.  (That matters: the column-dot symv reads
-// A(:,k) where the algebra means row k; with two independently rounded triangles the
-// mismatch, of the size of eps * |A| at the deflation panel, is re-injected at every later
-// column and the tridiagonalisation of a highly degenerate matrix loses ~5 digits.)
-// 64 x 64 tile per workgroup, 4 x 4 outputs per thread, panels staged in LDS.
+// rank-2NB update of the trailing matrix on the matrix cores:
+//   A[r, s] -= sum_c V[r,c] W[s,c] + W[r,c] V[s,c],   r >= s >= j1   (lower triangle only)
+// = PT[r, :] . rot(PT[s, :]) with the halves of the second row swapped.  One workgroup = one
+// 128 x 128 tile (4 waves x 64 x 64, v_mfma_f64_16x16x4_f64), K = 64 in four 128-byte K-tiles,
+// operands global -> LDS directly with the source-side XOR swizzle of kernels_gemm.hip.
 // ---------------------------------------------------------------------------
+typedef double sy_v2d __attribute__((ext_vector_type(2)));
+typedef double sy_v4d __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void sy_lds_void_t;
+typedef const __attribute__((address_space(1))) void sy_gbl_void_t;
+
 __global__ void __launch_bounds__(SY_THREADS)
-sytrd_syr2k_kernel(SytrdArgs a, int j1, int cnt, int ntile) {
-    constexpr int CH = 16;  // panel columns staged per pass (4 x 16 x 64 doubles = 32 KiB)
-    __shared__ double sVr[CH][64], sWr[CH][64], sVs[CH][64], sWs[CH][64];
-    // linear tile index -> (bx >= by) of the lower triangle of tiles
-    int by = 0, bx = blockIdx.x;
-    {
-        // row-wise enumeration: tiles (bx, by) with by <= bx, index = bx*(bx+1)/2 + by
-        int t = blockIdx.x;
-        int x = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((x + 1) * (x + 2) / 2 <= t) ++x;
-        while (x * (x + 1) / 2 > t) --x;
-        bx = x;
-        by = t - x * (x + 1) / 2;
-    }
-    (void)ntile;
+sytrd_syr2k_mfma_kernel(SytrdArgs a, int j1, int T0) {
+    constexpr int KB = 128;        // bytes of K per row per tile
+    constexpr int OPB = 128 * KB;  // 16 KiB per operand tile
+    constexpr int ROWB = SY_PW * 8;  // bytes per panel row (512)
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
-    const int64_t ld = a.ld;
-    const int n = a.n;
-    const int rb = j1 + bx * 64, sb = j1 + by * 64;
-    const int tr = (tid & 15) * 4, ts = (tid >> 4) * 4;
-    double acc[4][4];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = wave >> 1;
+    int bi, bj;
+    {
+        const int t = blockIdx.x;
+        int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (row * (row + 1) / 2 > t) --row;
+        while ((row + 1) * (row + 2) / 2 <= t) ++row;
+        bi = row;
+        bj = t - row * (row + 1) / 2;
+    }
+    const int i0 = 128 * (T0 + bi), j0 = 128 * (T0 + bj);
+    const char* Ab = reinterpret_cast<const char*>(a.PT) + (int64_t)i0 * ROWB;
+    const char* Bb = reinterpret_cast<const char*>(a.PT) + (int64_t)j0 * ROWB;
+    int srcA[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int r = 8 * (wave * 4 + s) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        srcA[s] = r * ROWB + c * 16;
+    }
+    auto issue = [&](int buf, int kt) {
+        const int kbA = kt * KB;
+        const int kbB = (kt * KB + SY_NB * 8) & (ROWB - 1);  // second operand: halves swapped
+        char* base = smem + buf * 2 * OPB + (wave * 4) * 1024;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            __builtin_amdgcn_global_load_lds((sy_gbl_void_t*)(Ab + srcA[s] + kbA), (sy_lds_void_t*)(base + s * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((sy_gbl_void_t*)(Bb + srcA[s] + kbB), (sy_lds_void_t*)(base + OPB + s * 1024), 16, 0, 0);
+        }
+    };
+    constexpr int nk = ROWB / KB;  // 4
+    sy_v4d acc[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
-    for (int c0 = 0; c0 < cnt; c0 += CH) {
-        const int cc = (cnt - c0 < CH) ? cnt - c0 : CH;
-        __syncthreads();
-        for (int t = tid; t < 64 * cc; t += SY_THREADS) {
-            const int c = t / 64, q = t % 64;
-            const int rr = rb + q, ss = sb + q;
-            sVr[c][q] = (rr < n) ? a.Vp[rr + (int64_t)(c0 + c) * ld] : 0.0;
-            sWr[c][q] = (rr < n) ? a.Wp[rr + (int64_t)(c0 + c) * ld] : 0.0;
-            sVs[c][q] = (ss < n) ? a.Vp[ss + (int64_t)(c0 + c) * ld] : 0.0;
-            sWs[c][q] = (ss < n) ? a.Wp[ss + (int64_t)(c0 + c) * ld] : 0.0;
-        }
-        __syncthreads();
-        for (int c = 0; c < cc; ++c) {
-            double vr[4], wr[4], vs[4], ws[4];
+        for (int y = 0; y < 4; ++y)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                vr[x] = sVr[c][tr + x];
-                wr[x] = sWr[c][tr + x];
-                vs[x] = sVs[c][ts + x];
-                ws[x] = sWs[c][ts + x];
+            for (int r = 0; r < 4; ++r) acc[x][y][r] = 0.0;
+    const int r16 = lane & 15, g = lane >> 4;
+    int rowA[4], rowB[4], swA[4], swB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        rowA[t] = wi * 64 + t * 16 + r16;
+        rowB[t] = wj * 64 + t * 16 + r16;
+        swA[t] = (rowA[t] >> 1) & 7;
+        swB[t] = (rowB[t] >> 1) & 7;
+    }
+    // the tile of A that will be updated is requested first of all (64 entries per lane; one wave
+    // per SIMD, so the registers are there): its latency hides behind the whole product
+    const int64_t ld = a.ld;
+    const int n = a.n;
+    double cv[4][4][4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const int ii = i0 + wi * 64 + ti * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = j0 + wj * 64 + tj * 16 + g + 4 * r;
+                const bool ok = ii >= jj && jj >= j1 && ii < n;
+                cv[tj][ti][r] = ok ? a.A[ii + (int64_t)jj * ld] : 0.0;
+            }
+        }
+    // K = 64 is only four K-tiles: all of them are requested up front (4 x 32 KiB of LDS) and
+    // consumed behind counted waits, so the workgroup pays the global -> LDS latency once
+#pragma unroll
+    for (int kt = 0; kt < nk; ++kt) issue(kt, kt);
+#pragma unroll
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (kt == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (kt == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* tA = smem + kt * 2 * OPB;
+        const char* tB = tA + OPB;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            sy_v2d fi[4], fj[4];
+            const int ch = 4 * q + g;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fi[t] = *reinterpret_cast<const sy_v2d*>(tA + rowA[t] * KB + ((ch ^ swA[t]) << 4));
+                fj[t] = *reinterpret_cast<const sy_v2d*>(tB + rowB[t] * KB + ((ch ^ swB[t]) << 4));
             }
 #pragma unroll
-            for (int y = 0; y < 4; ++y)
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x][y] = fma(vr[x], ws[y], fma(wr[x], vs[y], acc[x][y]));
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti)
+                        acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[tj][e], fi[ti][e], acc[tj][ti], 0, 0, 0);
         }
     }
+    // D[jj][ii]: ii = lane & 15 (row of A, contiguous), jj = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
-        const int s = sb + ts + y;
-        if (s >= n) continue;
+    for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int r = rb + tr + x;
-            if (r >= n || r < s) continue;  // diagonal tiles: lower part only
-            const double val = a.A[r + (int64_t)s * ld] - acc[x][y];
-            a.A[r + (int64_t)s * ld] = val;
-            if (r != s) a.A[s + (int64_t)r * ld] = val;
+        for (int ti = 0; ti < 4; ++ti) {
+            const int ii = i0 + wi * 64 + ti * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = j0 + wj * 64 + tj * 16 + g + 4 * r;
+                if (ii >= jj && jj >= j1 && ii < n) a.A[ii + (int64_t)jj * ld] = cv[tj][ti][r] - acc[tj][ti][r];
+            }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------
-// host driver.  A: n x n, ld even and >= n + (n odd ? 1 : 0) so that the 16-byte column
-// reads of the symv kernel stay inside the allocation (callers pad ld to a multiple of 128).
-// ws: Vp, Wp (ld*NB each), p0 (n), g1/g2 (NB), part_norm/part_vav (<= 4096 each).
+// host driver.  A: n x n inside an ld x ld allocation, ld a multiple of 128 (tiles read whole
+// 128-row / 64-column blocks; entries outside the lower triangle of the leading n x n part are
+// read but never used).
 // ---------------------------------------------------------------------------
 size_t sytrd_workspace_doubles(int64_t n, int64_t ld) {
-    return (size_t)2 * ld * SY_NB + (size_t)n + 2 * SY_NB + 2 * 4096 + 64;
+    (void)n;
+    return (size_t)ld * SY_PW + (size_t)(ld / SY_TC + 1) * ld + (size_t)SY_MAXSEG * ld + (size_t)(ld / 64 + 1) * SY_PW +
+           (size_t)(ld / SY_FROWS + 8) + SY_MAXVAV + 64;
+}
+
+static SytrdArgs sytrd_args(int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
+    SytrdArgs a;
+    a.A = A;
+    a.ld = ld;
+    a.n = (int)n;
+    a.PT = ws;
+    a.Pdir = a.PT + ld * SY_PW;
+    a.Ptr = a.Pdir + (ld / SY_TC + 1) * ld;
+    a.Gpart = a.Ptr + (size_t)SY_MAXSEG * ld;
+    a.part_norm = a.Gpart + (ld / 64 + 1) * SY_PW;
+    a.part_vav = a.part_norm + (ld / SY_FROWS + 8);
+    a.scal = a.part_vav + SY_MAXVAV;
+    a.d = d;
+    a.e = e;
+    a.tau = tau;
+    return a;
 }
 
 // per-device kernel attributes, set by sdpsr_create() with the ctx's device current
 void sytrd_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<8>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<16>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<32>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_symv_kernel<64>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_syr2k_mfma_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+}
+
+static void launch_symv(hipStream_t s, const SytrdArgs& a, int j, int cf, int n_norm, const SymvGeom& g) {
+    sytrd_symv_kernel<<<(unsigned)g.grid, SY_THREADS, 0, s>>>(a, j, cf, n_norm, g.S0, g.SEG, g.nstr, g.maxseg, g.G);
 }
 
 static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
                                 double* ws) {
     const int n = (int)n64;
-    SytrdArgs a;
-    a.A = A;
-    a.ld = ld;
-    a.n = n;
-    a.Vp = ws;
-    a.Wp = a.Vp + ld * SY_NB;
-    a.p0 = a.Wp + ld * SY_NB;
-    a.g1 = a.p0 + n;
-    a.g2 = a.g1 + SY_NB;
-    a.part_norm = a.g2 + SY_NB;
-    a.part_vav = a.part_norm + 4096;
-    a.d = d;
-    a.e = e;
-    a.tau = tau;
+    SytrdArgs a = sytrd_args(n64, A, ld, d, e, tau, ws);
     hipMemsetAsync(ws, 0, sytrd_workspace_doubles(n, ld) * sizeof(double), s);
     if (n == 1) {
         hipMemcpyAsync(d, A, sizeof(double), hipMemcpyDeviceToDevice, s);
         return;
     }
-    int n_vav = 0;
     int cf = 0;  // panel column of the column currently being formed
-    const size_t lds_v = ((size_t)n + 4) * sizeof(double);
     // column 0: plain form (no panel yet)
-    {
-        const int nb_form = (n + SY_FROWS - 1) / SY_FROWS;
-        sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, 0, 0, 0, 1, 0);
-    }
+    sytrd_form_kernel<<<(n + SY_FROWS - 1) / SY_FROWS, SY_THREADS, 0, s>>>(a, 0, 0, 0, 1, 0, 0, 1, 0);
     for (int j = 0; j <= n - 2; ++j) {
-        // reflector of column j + column dots
+        // reflector of column j + symmetric product
         const int n_norm = (n - j + SY_FROWS - 1) / SY_FROWS;
-        const int nwork = (n - j - 1) + 2 * cf;
-        int nblk = (nwork + 7) / 8;  // one column pair per wave
-        if (nblk > 512) nblk = 512;
-        if (nblk < 1) nblk = 1;
-        const int rows_left = n - j;
-        if (rows_left <= 8 * SY_THREADS)
-            sytrd_symv_kernel<8><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
-        else if (rows_left <= 16 * SY_THREADS)
-            sytrd_symv_kernel<16><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
-        else if (rows_left <= 32 * SY_THREADS)
-            sytrd_symv_kernel<32><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
-        else
-            sytrd_symv_kernel<64><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
-        n_vav = nblk;
+        const SymvGeom g = symv_geometry(n, j, cf);
+        launch_symv(s, a, j, cf, n_norm, g);
+        const int n_vav = g.grid;
         const int jn = j + 1;
-        const int rows = n - jn;
-        const int nb_form = (rows + SY_FROWS - 1) / SY_FROWS;
+        const int nb_form = (n - jn + SY_FROWS - 1) / SY_FROWS;
         if (cf + 1 < SY_NB && jn <= n - 1) {
             // finish W(:, cf) and form column j+1 inside the same panel
-            sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, cf, 1, 1, n_vav);
+            sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, cf, 1, 1, n_vav, g.S0, g.SEG, g.G);
             ++cf;
         } else {
             // panel complete: finish W, update the trailing matrix, start a new panel
-            sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, cf, 1, 0, n_vav);
-            const int cnt = cf + 1;
-            const int tr = n - jn;
-            if (tr > 0) {
-                const int nt = (tr + 63) / 64;
-                sytrd_syr2k_kernel<<<nt * (nt + 1) / 2, SY_THREADS, 0, s>>>(a, jn, cnt, nt);
-                sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, 0, 0, 1, 0);
+            sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, cf, 1, 0, n_vav, g.S0, g.SEG, g.G);
+            if (n - jn > 0 && cf + 1 == SY_NB) {
+                const int T0 = jn / 128;
+                const int nt = (n + 127) / 128 - T0;
+                sytrd_syr2k_mfma_kernel<<<nt * (nt + 1) / 2, SY_THREADS, 128 * 1024, s>>>(a, jn, T0);
             }
+            if (n - jn > 0) sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, 0, 0, 1, 0, 0, 1, 0);
             cf = 0;
         }
     }
@@ -474,44 +728,17 @@ static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t l
 void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e,
                              double* tau, double* ws) {
     const int n = (int)n64;
-    SytrdArgs a;
-    a.A = A;
-    a.ld = ld;
-    a.n = n;
-    a.Vp = ws;
-    a.Wp = a.Vp + ld * SY_NB;
-    a.p0 = a.Wp + ld * SY_NB;
-    a.g1 = a.p0 + n;
-    a.g2 = a.g1 + SY_NB;
-    a.part_norm = a.g2 + SY_NB;
-    a.part_vav = a.part_norm + 4096;
-    a.d = d;
-    a.e = e;
-    a.tau = tau;
+    SytrdArgs a = sytrd_args(n64, A, ld, d, e, tau, ws);
     hipMemsetAsync(ws, 0, sytrd_workspace_doubles(n, ld) * sizeof(double), s);
-    const size_t lds_v = ((size_t)n + 4) * sizeof(double);
     for (int j = 0; j <= n - 2; ++j) {
         const int cf = j % SY_NB;
         const int n_norm = (n - j + SY_FROWS - 1) / SY_FROWS;
-        const int nwork = (n - j - 1) + 2 * cf;
-        int nblk = (nwork + 7) / 8;
-        if (nblk > 512) nblk = 512;
-        if (nblk < 1) nblk = 1;
-        const int rows_left = n - j;
-        if (rows_left <= 8 * SY_THREADS)
-            sytrd_symv_kernel<8><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
-        else if (rows_left <= 16 * SY_THREADS)
-            sytrd_symv_kernel<16><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
-        else if (rows_left <= 32 * SY_THREADS)
-            sytrd_symv_kernel<32><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
-        else
-            sytrd_symv_kernel<64><<<nblk, SY_THREADS, lds_v, s>>>(a, j, cf, n_norm);
+        launch_symv(s, a, j, cf, n_norm, symv_geometry(n, j, cf));
     }
 }
 
-
-// For n up to a few thousand the ~2n + n/32 launches of the tridiagonalisation are shorter than
-// the cost of launching them (2-3 us of kernel against 4-5 us of launch): the launch sequence of
+// Most of the ~2n + n/32 launches of the tridiagonalisation are shorter than the cost of
+// launching them from the host (2-4 us of kernel against 3-5 us of launch): the launch sequence of
 // one problem shape is captured once into a hipGraph and replayed.  Key = every value baked into
 // the nodes (order, leading dimension, all pointers); the ctx's buffers are grow-only, so the key
 // is stable across calls.  A few graphs are kept (generic elements alternate between two or
@@ -538,7 +765,7 @@ void sytrd_graph_cache_destroy(SytrdGraphCache* g) {
 void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
     hipStream_t s = c->stream;
     const bool no_graph = getenv("SDPSR_NO_GRAPH") != nullptr;
-    if (no_graph || n64 < 64 || n64 > 3072) {  // large orders: the kernels outlast their launches
+    if (no_graph || n64 < 64) {
         launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
         return;
     }

@@ -155,6 +155,7 @@ void partition_set_device_attributes();
 void sytrd_set_device_attributes();
 void small_syev_set_device_attributes();
 void batched_set_device_attributes();
+void backtransform_set_device_attributes();
 // kernels_batched.hip: `count` runs of eigen_decomposition on one partition of order n <= 64
 void launch_eigdec_batched64(hipStream_t s, int64_t n, int64_t d, int64_t count, const uint32_t* L, const double* values,
                              uint64_t seed, uint64_t stream_base, double atol, int32_t* status, int32_t* neig,

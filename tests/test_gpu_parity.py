@@ -155,7 +155,7 @@ def test_square_f64_and_gemm_tn(pkg, gpu_ctx, n):
 def test_syev_matches_lapack(pkg, gpu_ctx):
     lib = pkg.load_library()
     rng = np.random.default_rng(1)
-    for n in (1, 2, 3, 33, 64, 65, 200, 777):
+    for n in (1, 2, 3, 33, 64, 65, 129, 130, 191, 200, 257, 777, 1100):
         A = rng.standard_normal((n, n))
         A = np.asfortranarray((A + A.T) / 2)
         w = np.zeros(n)
@@ -182,6 +182,26 @@ def test_syev_degenerate_spectrum_residual(pkg, problems, gpu_ctx):
     assert np.abs(A @ V - V * w).max() <= 1e-13 * scale * 8
     assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
     assert np.allclose(w, np.linalg.eigvalsh(A), atol=1e-12 * scale)
+
+
+def test_syev_n4096_degenerate_and_generic(pkg, problems, gpu_ctx):
+    """The dense driver at the headline order: (i) the generic element of the 34-class scheme
+    (34 distinct eigenvalues with multiplicities ~128: deflation after the first panels),
+    (ii) a generic symmetric matrix.  Residual, orthogonality and eigenvalues against LAPACK."""
+    lib = pkg.load_library()
+    n = 4096
+    Ls, d = problems.synthetic_jordan_partition(n, seed=2)
+    A1 = np.asfortranarray(np.concatenate([[0.0], np.random.default_rng(0).random(d)])[Ls])
+    G = np.random.default_rng(4).standard_normal((n, n))
+    A2 = np.asfortranarray((G + G.T) / 2)
+    for A in (A1, A2):
+        w = np.zeros(n)
+        V = np.zeros((n, n), order="F")
+        gpu_ctx.check(lib.sdpsr_syev_f64(gpu_ctx._h, n, C.c_void_p(A.ctypes.data), C.c_void_p(w.ctypes.data), C.c_void_p(V.ctypes.data), 0))
+        scale = np.abs(w).max()
+        assert np.abs(A @ V - V * w).max() <= 2e-12 * scale
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-11
+        assert np.allclose(w, np.linalg.eigvalsh(A), atol=1e-11 * scale)
 
 
 # ------------------------------------------------------------------ the whole path
