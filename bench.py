@@ -2,21 +2,33 @@
 """bench.py -- reductions/s of the Jordan-reduction hot path on MI355X.
 
 One "step" = one reduction = admissible_subspace (device loop) + blockDiagonalize
-(eigen_decomposition + irreducible_decomposition + basis_image) of BASELINE.json
-configs[3]: a synthetic Jordan algebra of order N = 4096 with 34 basis matrices (symmetric
-circulant scheme on Z_32 (x) {I, J-I} on 128 points, conjugated by a seeded permutation),
-wrapped as an SDP.  Inputs (C_L, X0_L, U) are resident in HBM before the timed region; the
-host-side setup stage (src/partitions.jl:117-142) is outside the hot path.
+(eigen_decomposition + irreducible_decomposition + basis_image) of BASELINE.json configs[3]:
+a synthetic Jordan algebra of order N = 4096 with 34 basis matrices.  Inputs (C_L, X0_L, U) are
+resident in HBM before the timed region; the setup stage (src/partitions.jl:117-142) is outside
+the hot path.
 
-N ranks (one per GPU): every rank runs an independent random restart of the same reduction
-(its own seed), the ranks agree on the partition with allreduce(MIN)/allreduce(MAX) over the
-label matrix (RCCL), then each rank block-diagonalises.  value = restarts finished by all
-ranks per second ("weak": per-GPU work is fixed).
+Three instances of configs[3] are measured; `value` is the first, the other two are reported in
+`workloads` of the same JSON line (each with reductions/s, iteration count, per-phase ms):
+  closed_scheme     the 34-class scheme circulant(Z_32) (x) {I, J-I}_128 handed over as the SDP
+                    data itself (C takes a distinct value per class): the loop confirms the
+                    closure in ONE iteration, all blocks have size 1;
+  theta_c32xk128    theta'-type SDP (C = ones, A = [adjacency; I], test/sd_problems.jl:22-26 form)
+                    of the Cartesian product C_32 [] K_128: the loop starts from {diagonal, edges,
+                    non-edges} and needs 5 iterations to reach the same 34-class scheme;
+  theta_er7xk72     the same construction on ER(7) [] K_72, N = 4104: 5 iterations, 36 classes,
+                    NON-commutative algebra, blocks [2,2,2,2,3] twice.
+
+N ranks (one per GPU): every rank runs an independent random restart of the same reduction (its
+own seed), the ranks agree on the partition (128-bit checksums all-gathered; labels travel only
+on disagreement), then each rank block-diagonalises.  value = restarts finished by all ranks per
+second ("weak": per-GPU work is fixed).
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes as C
+import csv
+import glob
 import json
 import os
 import sys
@@ -31,11 +43,12 @@ FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 FP64_MFMA_PEAK_TF = 78.6    # public MI355X spec (fp64 matrix); not in the local guide
 I8_MFMA_PEAK_TOPS = 5000.0  # ~2x bf16 dense (MI355X_MICROARCH.md matrix-core table)
 HBM_PEAK_GBS = 8000.0
+ATOL = 1.4901161193847656e-08
 
 
 def cpu_baseline(pr, n_sample, seed):
-    """The CPU oracle (NumPy/SciPy restatement, NOT Julia) timed on a bounded sample: one full
-    reduction of the same generator at order n_sample."""
+    """The CPU oracle (NumPy/SciPy restatement, NOT Julia) timed on the host cores: one full
+    reduction of the headline workload's generator at order n_sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sdpsr_oracle as O
     try:
@@ -55,6 +68,47 @@ def cpu_baseline(pr, n_sample, seed):
     return {"adm_s": t1 - t0, "bd_s": t2 - t1, "threads": thr, "n": n_sample, "dim": int(d)}
 
 
+def rocprof_average_us(pattern):
+    """Average duration (us) of a kernel in this round's committed rocprofv3 --kernel-trace --stats
+    summary of the default bench command (profiles/r02_bench_n4096_kernel_stats.csv), or None."""
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_n4096_kernel_stats*.csv")))[-1]
+        for row in csv.DictReader(open(path)):
+            if pattern in row["Name"]:
+                return round(float(row["AverageNs"]) / 1e3, 2)
+    except Exception:
+        pass
+    return None
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch from this round's separate rocprofv3 --pmc passes (FETCH_SIZE x 2 +
+    WRITE_SIZE, MI355X_MICROARCH.md HBM section), or None when the pass is not in profiles/."""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        return round(pj[key]["traffic_bytes_per_launch"]), "profiles/r02_pmc.json:" + key
+    except Exception:
+        return None, None
+
+
+class Workload:
+    """One instance: device-resident inputs of the loop + expectations for the checks."""
+
+    def __init__(self, pkg, dev, name, note, Cv, A, b, labels, d, blocks):
+        import torch
+        self.name, self.note = name, note
+        n, CL, X0L, U = pkg.admissible_setup(Cv, A, b)
+        self.n, self.d, self.blocks = n, int(d), sorted(blocks)
+        self.r = U.shape[1]
+        self.tCL = torch.from_numpy(CL).to(dev)
+        self.tX0 = torch.from_numpy(X0L).to(dev)
+        self.tU = torch.from_numpy(np.ascontiguousarray(U.T)).to(dev) if self.r else None  # (r, n^2): rows = columns of U
+        self.tP = torch.empty(n * n, dtype=torch.int32, device=dev)
+        self.golden = torch.from_numpy(np.ascontiguousarray(labels.ravel(order="F")).astype(np.int32)).to(dev)
+        self.blk_buf = {}
+        self.dev = dev
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,9 +116,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--mode", default="i8", choices=["i8", "f32", "f64"])
-    ap.add_argument("--cpu-n", type=int, default=2048, help="order of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-n", type=int, default=-1, help="order of the CPU-baseline reduction (-1 = the headline order, 0 = skip)")
     ap.add_argument("--eig-driver", type=int, default=0, help="0 auto (module compression when dim(P) << n), 4 dense eigensolver forced")
     ap.add_argument("--skip-roofline", action="store_true", help="only the timed steps (clean rocprofv3 kernel statistics)")
+    ap.add_argument("--workload", default="closed_scheme", choices=["closed_scheme", "theta_c32xk128", "theta_er7xk72"],
+                    help="instance run in the timed region (the other two are measured after it, rank 0)")
     args = ap.parse_args()
 
     import torch
@@ -91,131 +147,173 @@ def main():
             dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-
     n = args.n
-    Ls, d = pr.synthetic_jordan_partition(n, seed=1)
-    Cv, A, b = pr.partition_as_sdp(Ls, seed=1)
-    n_, CL, X0L, U = pkg.admissible_setup(Cv, A, b)
-    r = U.shape[1]
-    tCL = torch.from_numpy(CL).to(dev)
-    tX0 = torch.from_numpy(X0L).to(dev)
-    tU = torch.from_numpy(np.ascontiguousarray(U.T)).to(dev) if r else None  # (r, n^2) rows = columns of U
-    tP = torch.empty(n * n, dtype=torch.int32, device=dev)
-    golden = torch.from_numpy(np.ascontiguousarray(Ls.ravel(order="F")).astype(np.int32)).to(dev)
+
+    def build(name):
+        if name == "closed_scheme":
+            Ls, d = pr.synthetic_jordan_partition(n, seed=1)
+            Cv, A, b = pr.partition_as_sdp(Ls, seed=1)
+            return Workload(pkg, dev, name, f"partition_as_sdp of circulant Z_32 (x) K_{n // 32} (already closed)", Cv, A, b, Ls, d, [1] * d)
+        if name == "theta_c32xk128":
+            k = n // 32
+            Cv, A, b, Ls, d = pr.theta_prime_product_problem(pr.cycle_adjacency(32), pr.symmetric_circulant_labels(32), k, seed=1)
+            return Workload(pkg, dev, name, f"theta' SDP of C_32 [] K_{k} (C = ones, A = [adjacency; I])", Cv, A, b, Ls, d, [1] * d)
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_partitions.npz"))["er7_P"].astype(np.int64)
+        Cv, A, b, Ls, d = pr.theta_prime_product_problem(pr.er_graph_adjacency(7), gold, 72, seed=1)
+        return Workload(pkg, dev, name, "theta' SDP of ER(7) [] K_72, N = 4104, non-commutative", Cv, A, b, Ls, d, [2, 2, 2, 2, 3] * 2)
+
     mode = {"i8": L.SQUARE_I8, "f32": L.SQUARE_F32, "f64": L.SQUARE_F64}[args.mode]
     ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode, eig_driver=args.eig_driver)
-    lib = ctx._lib
-    atol = 1.4901161193847656e-08
-    blk_buf = {}
-    phase = np.zeros(L.T_COUNT)
-    iters_total = 0
 
     def vp(t):
         return C.c_void_p(t.data_ptr()) if t is not None else None
 
-    def one_step(check=False, collective=True):
-        nonlocal iters_total, ctx
+    class Acc:
+        def __init__(self):
+            self.phase = np.zeros(L.T_COUNT)
+            self.iters = 0
+
+    def one_step(w, acc, cx, check=False, collective=True):
+        lib = cx._lib
         dd = C.c_int64(0)
         it = C.c_int32(0)
         ms = (C.c_double * L.T_COUNT)()
-        lib = ctx._lib
-        ctx.check(lib.sdpsr_admissible_subspace(ctx._h, n, vp(tCL), vp(tX0), vp(tU), r, atol, vp(tP), C.byref(dd),
-                                                C.byref(it), C.cast(ms, C.c_void_p), L.MEM_DEVICE))
-        iters_total += it.value
+        cx.check(lib.sdpsr_admissible_subspace(cx._h, w.n, vp(w.tCL), vp(w.tX0), vp(w.tU), w.r, ATOL, vp(w.tP), C.byref(dd),
+                                               C.byref(it), C.cast(ms, C.c_void_p), L.MEM_DEVICE))
+        acc.iters += it.value
         for i in range(L.T_COUNT):
-            phase[i] += ms[i]
+            acc.phase[i] += ms[i]
         if world > 1 and collective:
             # agree the partition across the restarts (canonical labels: equal w.p. 1): 128-bit
             # checksums computed on the device are all-gathered; the 64 MiB label matrix itself
             # only travels (MIN/MAX all-reduce) if they differ
-            words = pkg.partition_checksum(tP, ctx=ctx)
+            words = pkg.partition_checksum(w.tP, ctx=cx)
             if not pkg.parallel.checksums_agree(words, device=dev):
-                lo = tP.clone()
-                hi = tP.clone()
+                lo = w.tP.clone()
+                hi = w.tP.clone()
                 dist.all_reduce(lo, op=dist.ReduceOp.MIN)
                 dist.all_reduce(hi, op=dist.ReduceOp.MAX)
                 if not bool((lo == hi).all()):
                     raise RuntimeError("ranks disagree on the partition")
         if check:
-            assert dd.value == d and bool((tP == golden).all()), "partition differs from the generator's closure"
+            assert dd.value == w.d and bool((w.tP == w.golden).all()), "partition differs from the generator's closure"
         nb = C.c_int32(0)
         ssq = C.c_int64(0)
         ss = C.c_int64(0)
         ms1 = (C.c_double * L.T_COUNT)()
-        ctx.check(lib.sdpsr_block_diagonalize(ctx._h, n, vp(tP), dd.value, atol, C.byref(nb), C.byref(ssq), C.byref(ss),
-                                              C.cast(ms1, C.c_void_p), L.MEM_DEVICE))
+        cx.check(lib.sdpsr_block_diagonalize(cx._h, w.n, vp(w.tP), dd.value, ATOL, C.byref(nb), C.byref(ssq), C.byref(ss),
+                                             C.cast(ms1, C.c_void_p), L.MEM_DEVICE))
         key = (dd.value, ssq.value)
-        if key not in blk_buf:
-            blk_buf[key] = torch.empty(max(1, dd.value * ssq.value), dtype=torch.float64, device=dev)
+        if key not in w.blk_buf:
+            w.blk_buf[key] = torch.empty(max(1, dd.value * ssq.value), dtype=torch.float64, device=dev)
         ms2 = (C.c_double * L.T_COUNT)()
-        ctx.check(lib.sdpsr_block_images(ctx._h, vp(blk_buf[key]), None, C.cast(ms2, C.c_void_p), L.MEM_DEVICE))
+        cx.check(lib.sdpsr_block_images(cx._h, vp(w.blk_buf[key]), None, C.cast(ms2, C.c_void_p), L.MEM_DEVICE))
         for i in range(1, L.T_COUNT):
-            phase[i] += ms1[i] + ms2[i]
+            acc.phase[i] += ms1[i] + ms2[i]
         if check:
-            assert nb.value == d, (nb.value, d)  # commutative scheme: d blocks of size 1
+            sizes = np.zeros(nb.value, dtype=np.int32)
+            cx.check(lib.sdpsr_block_sizes(cx._h, sizes.ctypes.data_as(C.c_void_p)))
+            assert sorted(int(s) for s in sizes) == w.blocks, (sorted(sizes), w.blocks)
         return nb.value
 
-    def fence():
-        nonlocal ctx
-        ctx.synchronize()
+    def retrying(fn):
+        """blockDiagonalize is randomized; the reference's answer to NumericalInconsistency /
+        DimensionMismatch is "try again" (src/eigen_decomposition.jl:264-270) -- counted, not hidden."""
+        for attempt in range(5):
+            try:
+                return fn(), attempt
+            except (pkg.NumericalInconsistency, pkg.DimensionMismatch):
+                continue
+        raise RuntimeError("five consecutive randomized failures")
+
+    def fence(cx):
+        cx.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def phases(acc, steps):
+        return {k: round(acc.phase[i] / steps, 3) for k, i in
+                (("project", L.T_PROJECT), ("square", L.T_SQUARE), ("refine", L.T_REFINE), ("eigen", L.T_EIGEN),
+                 ("iso_QtAQ", L.T_ISO), ("irreducible", L.T_IRRED), ("basis_image", L.T_IMAGE))}
+
+    # ---- the timed region: K reductions of the headline instance ----
+    w0 = build(args.workload)
+    acc = Acc()
     for _ in range(args.warmup):
-        one_step(check=True)
-    phase[:] = 0
-    iters_total = 0
-    fence()
+        retrying(lambda: one_step(w0, acc, ctx, check=True))
+    acc = Acc()
+    retries = 0
+    fence(ctx)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step()
-    fence()
+        _, rt = retrying(lambda: one_step(w0, acc, ctx))
+        retries += rt
+    fence(ctx)
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    phase_timed = phase.copy()  # snapshots of the timed region only
-    iters_timed = iters_total
-    one_step(check=True)  # results still correct after the timed region
+    acc_timed = acc
+    retrying(lambda: one_step(w0, Acc(), ctx, check=True))  # results still correct after the timed region
 
-    # the same reduction with the dense eigensolver forced (hand-written tridiagonalisation on the
-    # full n x n element): reported beside the default driver, never as `value`
+    def measure(w, cx, steps):
+        """rank 0 only, no collectives: reductions/s of another instance / driver"""
+        a = Acc()
+        retrying(lambda: one_step(w, a, cx, check=True, collective=False))
+        retrying(lambda: one_step(w, a, cx, check=True, collective=False))
+        a = Acc()
+        cx.synchronize()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        rts = 0
+        for _ in range(steps):
+            _, rt = retrying(lambda: one_step(w, a, cx, collective=False))
+            rts += rt
+        cx.synchronize()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t) / steps
+        return {"value": round(1.0 / el, 3), "unit": "reductions/s", "ms_per_step": round(el * 1e3, 3), "steps": steps,
+                "N": w.n, "dim": w.d, "blocks": w.blocks if len(set(w.blocks)) > 1 else f"{len(w.blocks)} x size {w.blocks[0]}",
+                "iterations_per_reduction": a.iters / steps, "randomized_retries": rts, "phase_ms_per_step": phases(a, steps),
+                "instance": w.note}
+
+    workloads = {args.workload: {"value": round(args.steps * world / dt, 3), "unit": "reductions/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                                 "steps": args.steps, "N": w0.n, "dim": w0.d, "blocks": f"{len(w0.blocks)} x size {w0.blocks[0]}" if len(set(w0.blocks)) == 1 else w0.blocks,
+                                 "iterations_per_reduction": acc_timed.iters / max(1, args.steps), "randomized_retries": retries,
+                                 "phase_ms_per_step": phases(acc_timed, args.steps), "instance": w0.note, "timed_region": True}}
     variants = {}
-    if rank == 0 and not args.skip_roofline and args.eig_driver == 0:
+    kernels = {}
+    roof = None
+    cpu = None
+    if rank == 0 and not args.skip_roofline and args.eig_driver == 0 and n == 4096:
+        for name in ("closed_scheme", "theta_c32xk128", "theta_er7xk72"):
+            if name != args.workload:
+                wk = build(name)
+                workloads[name] = measure(wk, ctx, 10)
+                del wk
+                torch.cuda.empty_cache()
+        # the headline instance with the dense eigensolver forced (hand-written tridiagonalisation,
+        # rocSOLVER stedc, own compact-WY back-transformation on the full n x n generic element)
         ctx_d = pkg.Context(device=local, seed=2000, square_mode=mode, eig_driver=4)
-        saved = ctx
-        ctx = ctx_d
-        lib_d = ctx_d._lib  # noqa: F841
         try:
-            # rank 0 only: no collectives in here (the other ranks are already waiting at the end)
-            one_step(check=True, collective=False)
-            ctx.synchronize()
-            torch.cuda.synchronize()
-            td = time.perf_counter()
-            for _ in range(3):
-                one_step(collective=False)
-            ctx.synchronize()
-            torch.cuda.synchronize()
-            dtd = (time.perf_counter() - td) / 3
-            variants["dense_eigensolver"] = {"value": round(1.0 / dtd, 4), "ms_per_step": round(dtd * 1e3, 3), "steps": 3,
-                                             "note": "eig_driver=4: diagonalize on the full n x n generic element"}
+            variants["dense_eigensolver"] = measure(w0, ctx_d, 3)
+            variants["dense_eigensolver"]["note"] = "eig_driver=4: diagonalize on the full n x n generic element"
         finally:
-            ctx = saved
             ctx_d.close()
 
     # ---- roofline leg: per-launch duration of the hot kernels, HIP events on ctx's stream ----
+    lib = ctx._lib
+
     def prof(kind, nn, aux=0, reps=10):
         v = C.c_double(0)
         ctx.check(lib.sdpsr_profile_kernel(ctx._h, kind, nn, aux, reps, C.byref(v)))
         return v.value
 
-    kernels = {}
-    roof = None
-    cpu = None
     if rank == 0 and not args.skip_roofline:
+        d, r = w0.d, w0.r
         flops = 2.0 * n ** 3
         # the int8 square is launched exactly as the product path launches it: all 4 channels in
         # one launch (so that the HIP-event duration agrees with rocprofv3's average for the kernel)
@@ -224,7 +322,7 @@ def main():
             ms = prof(kind, n, aux=batch)
             ach = batch * flops / (ms * 1e-3) / 1e12
             kernels[name] = {"ms_per_launch": round(ms, 4), "channels_per_launch": batch, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                             "frac": round(ach / peak, 4), "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TF, 4)}
+                             "frac": round(ach / peak, 4), "bound": "mfma", "algorithmic": "2*N^3 per channel, full square"}
         # north-star bar of BASELINE.json: the partition-square step at N = 8192 against the fp32 MFMA
         # peak (>= 40 % asked).  Measured on the fp32 square kernel (same code path as
         # square_mode="f32") and on the default int8 square (4 channels, full launch).
@@ -233,79 +331,80 @@ def main():
             ms8 = prof(1, 8192, aux=1, reps=3)
             a8 = f8 / (ms8 * 1e-3) / 1e12
             kernels["square_f32_n8192"] = {"ms_per_launch": round(ms8, 3), "achieved": round(a8, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                           "frac": round(a8 / FP32_MFMA_PEAK_TF, 4)}
+                                           "frac": round(a8 / FP32_MFMA_PEAK_TF, 4), "bound": "mfma"}
             ms8 = prof(0, 8192, aux=4, reps=3)
             a8 = 4 * f8 / (ms8 * 1e-3) / 1e12
             kernels["square_i8_n8192"] = {"ms_per_launch": round(ms8, 3), "channels_per_launch": 4, "achieved": round(a8, 2), "peak": I8_MFMA_PEAK_TOPS,
-                                          "unit": "TOP/s", "frac": round(a8 / I8_MFMA_PEAK_TOPS, 4),
-                                          "frac_of_fp32_mfma_peak": round(a8 / FP32_MFMA_PEAK_TF, 4)}
-        ms = prof(3, n, aux=d, reps=5)  # refine: 16 B per entry algorithmic (8 value + 4 old + 4 new label)
-        gbs = 16.0 * n * n / (ms * 1e-3) / 1e9
-        kernels["refine"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                                          "unit": "TOP/s", "frac": round(a8 / I8_MFMA_PEAK_TOPS, 4), "bound": "mfma"}
+        # partition refinement (src/partitions.jl:44-66): 16 B per entry algorithmic (8 value + 4 old
+        # + 4 new label), in the three regimes of the configs
+        for cls in sorted({int(d), 3000, n * n // 2}):
+            ms = prof(3, n, aux=cls, reps=5)
+            gbs = 16.0 * n * n / (ms * 1e-3) / 1e9
+            kernels[f"refine_{cls}_classes"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                "bound": "hbm", "algorithmic_bytes": 16 * n * n,
+                                                "rocprof_avg_us": {"refine_insert_kernel": rocprof_average_us("refine_insert_kernel")} if cls == int(d) else None}
         ms = prof(4, n, aux=max(r, 1), reps=5)  # gather+project+signature: (4 + 8r)*2 read + 8 write per entry
         gbs = ((4.0 + 8.0 * max(r, 1)) * 2 + 8.0) * n * n / (ms * 1e-3) / 1e9
-        kernels["project_sig"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        # the kernel that takes the most time inside one reduction: the column-dot (symv) kernel of
-        # the tridiagonalisation, launched once per column j; algorithmic bytes of launch j =
-        # 8*(n-j-1)^2 (the trailing matrix is read once), i.e. 8*(n-1)n(2n-1)/6 / (n-1) on average
+        kernels["project_sig"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm"}
+        # kernels of the default (module-compression) path that weigh most in the rocprofv3 statistics
+        ph = phases(acc_timed, args.steps)
+        S1 = len(w0.blocks)
+        bi_bytes = 4.0 * n * n + 8.0 * (n * n / 2) * S1 + 8.0 * d * n * S1 * 2  # labels + gathered Q-hat rows (L2) + class sums written & read
+        kernels["basis_image"] = {"ms": ph["basis_image"], "bound": "L2 gather", "algorithmic_bytes": round(bi_bytes),
+                                  "achieved": round(bi_bytes / (ph["basis_image"] * 1e-3) / 1e9, 1) if ph["basis_image"] > 0 else None, "unit": "GB/s",
+                                  "note": "phase timer (HIP events) of sdpsr_block_images: rows kernel + blocks kernel; labels 4 B*N^2 from HBM, "
+                                          "N^2/2 gathers of S1*8-byte rows of Q-hat from L2",
+                                  "rocprof_avg_us": {"basis_image_rows_kernel": rocprof_average_us("basis_image_rows_kernel"),
+                                                     "basis_image_blocks_kernel": rocprof_average_us("basis_image_blocks_kernel")}}
+        wdim = min(64, int(d))  # the compressed eigenproblem of the module-compression driver: w = dim <S>x <= dim(P)
+        ms = prof(8, wdim, reps=10)
+        kernels["small_syev_jacobi64"] = {"ms": round(ms, 4), "order": wdim, "bound": "latency (one workgroup, LDS-resident)",
+                                          "rocprof_avg_us": rocprof_average_us("small_syev_jacobi64_kernel")}
+        kernels["label_spmm_sload"] = {"bound": "fp64 FMA", "algorithmic_bytes": 4 * n * n, "rocprof_avg_us": rocprof_average_us("label_spmm_sload_kernel"),
+                                       "note": "Y = A(v) W straight from the labels, 2*N^2*w flop; duration from the committed rocprofv3 summary"}
+        # dense driver: the symmetric-product kernel of the tridiagonalisation, launched once per
+        # column j; algorithmic bytes of launch j = 8 * (n-j-1)^2 / 2 (the LOWER triangle of the
+        # trailing matrix is read once), 8*n*(2n-1)/12 on average
         ms = prof(5, n)
-        avg_bytes = 8.0 * n * (2 * n - 1) / 6.0
+        avg_bytes = 8.0 * n * (2 * n - 1) / 12.0
         gbs = avg_bytes / (ms * 1e-3) / 1e9
+        tr, src = pmc_traffic("sytrd_symv")
         kernels["sytrd_symv"] = {"ms": round(ms, 5), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                 "launches_per_reduction": n - 1}
+                                 "bound": "hbm", "launches_per_reduction": n - 1, "algorithmic_bytes_per_launch": round(avg_bytes), "traffic": tr, "traffic_source": src,
+                                 "note": "dense driver only; back-to-back launches from the host (not graph-replayed): includes host launch cost"}
         ms6 = prof(6, n, reps=2)
-        kernels["sytrd_total"] = {"ms": round(ms6, 3), "note": "whole tridiagonalisation: symv + form + syr2k launches"}
-        # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 +
-        # WRITE_SIZE, tools/pmc_probe.py): bench.py cannot collect PMC counters itself
-        traffic = None
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_sytrd_symv_n{n}.json")))
-            traffic = round(pj["traffic_bytes_per_launch"])
-        except Exception:
-            pass
-        roof_dense = {"kernel": "sytrd_symv_kernel (dense driver: tridiagonalisation column dots, n-1 launches)", "bound": "hbm",
-                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                      "algorithmic_bytes_per_launch": round(avg_bytes)}
-        kernels["sytrd_symv"]["roofline_dense_driver"] = roof_dense
-        # default path: by the rocprofv3 kernel statistics (profiles/) the time of a reduction is
-        # spread over ~15 kernels of comparable weight; the one carrying the O(N^3) work of the path
-        # (and the only MFMA-bound one) is the int8 square: one launch, 4 channels, 2*N^3 integer
-        # ops per channel.  HBM traffic per launch from the committed rocprofv3 --pmc pass
-        # (profiles/r01_pmc_square_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_probe.py).
-        ki8 = kernels["square_i8"]
-        traffic_i8 = None
-        try:
-            if n == 4096:
-                traffic_i8 = round(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_square_gemm.json")))["i8x4_lower"]["traffic_bytes_per_launch"])
-        except Exception:
-            pass
-        # the launch of the product path: labels of a Jordan algebra are symmetric, X'X is
-        # symmetric, only the T(T+1)/2 lower-triangle tiles of the T x T tile grid are computed.
-        # the judged figure is the algorithmic 2*N^3 per square; the executed ops are
-        # reported next to it (executed / algorithmic = (T+1)/(2T)).
+        kernels["sytrd_total"] = {"ms": round(ms6, 3), "note": "whole tridiagonalisation (graph replay): symv + form + MFMA syr2k launches"}
+        # `roofline`: the kernel that carries the O(N^3) work of the default path and its only
+        # MFMA-bound one, launched as the product path launches it: 4 channels, lower-triangle tiles
+        # of the symmetric product.  frac = EXECUTED ops / peak (hardware efficiency); the figure
+        # judged against the algorithmic 2*N^3 per square is reported beside it.
         ms_tri = prof(0, n, aux=104)
         Tt = (n + 127) // 128
         exec_frac = (Tt + 1) / (2.0 * Tt)
         alg_rate = 4 * flops / (ms_tri * 1e-3) / 1e12
+        tr, src = pmc_traffic("i8x4_lower")
+        ki8 = kernels["square_i8"]
         roof = {"kernel": "gemm_tn_dma_kernel<i8> (random squares: 4 channels per launch, lower-triangle tiles of the symmetric product)",
-                "bound": "mfma", "achieved": round(alg_rate, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-                "frac": round(alg_rate / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic_i8,
-                "ms_per_launch": round(ms_tri, 4), "algorithmic_ops_per_launch": 4 * flops,
-                "executed_ops_per_launch": 4 * flops * exec_frac, "executed_rate": round(alg_rate * exec_frac, 2),
-                "executed_frac_of_peak": round(alg_rate * exec_frac / I8_MFMA_PEAK_TOPS, 4),
+                "bound": "mfma", "achieved": round(alg_rate * exec_frac, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                "frac": round(alg_rate * exec_frac / I8_MFMA_PEAK_TOPS, 4), "traffic": tr, "traffic_source": src,
+                "ms_per_launch": round(ms_tri, 4), "executed_ops_per_launch": 4 * flops * exec_frac,
+                "algorithmic_ops_per_launch": 4 * flops, "algorithmic_rate_2N3": round(alg_rate, 2),
+                "algorithmic_frac_2N3": round(alg_rate / I8_MFMA_PEAK_TOPS, 4),
                 "algorithmic_bytes_per_launch": 4 * (n * n + 4 * n * n),
-                "frac_of_fp32_mfma_peak": round(alg_rate / FP32_MFMA_PEAK_TF, 4),
+                "rocprof_avg_us": rocprof_average_us("gemm_tn_dma_kernel<0>"),
                 "full_square_kernel": {"ms_per_launch": ki8["ms_per_launch"], "achieved": ki8["achieved"], "frac": ki8["frac"]},
-                "algorithmic": "2*N^3 int8 multiply-adds (as ops) per channel and square (SURVEY 8d); one launch = 4 channels; "
-                               "algorithmic bytes per launch = channels x (N^2 int8 read + N^2 int32 written)"}
-        if args.cpu_n > 0:
-            cb = cpu_baseline(pr, args.cpu_n, seed=1)
-            scale = (n / cb["n"]) ** 3
-            est = (cb["adm_s"] + cb["bd_s"]) * scale
-            cpu = {"value": round(1.0 / est, 6), "unit": "reductions/s", "cores": cb["threads"], "kind": "port",
-                   "sample": f"one full oracle reduction (NumPy/SciPy restatement, not Julia) at N={cb['n']}, dim {cb['dim']}: "
-                             f"admissible_subspace {cb['adm_s']:.2f} s + blockDiagonalize {cb['bd_s']:.2f} s measured; "
-                             f"value extrapolated to N={n} by (N/{cb['n']})^3 = {scale:.0f}x"}
+                "algorithmic": "2*N^3 int8 multiply-adds (as ops) per channel and square (SURVEY 8d); one launch = 4 channels (the "
+                               "reference does ONE square per iteration: 4 channels are this build's redundancy for 8-bit draws); "
+                               "executed = (T+1)/(2T) of that (lower-triangle tiles); algorithmic bytes per launch = channels x "
+                               "(N^2 int8 read + N^2 int32 written)"}
+        cpu_n = n if args.cpu_n < 0 else args.cpu_n
+        if cpu_n > 0:
+            cb = cpu_baseline(pr, cpu_n, seed=1)
+            tot = cb["adm_s"] + cb["bd_s"]
+            cpu = {"value": round(1.0 / tot, 6), "unit": "reductions/s", "cores": cb["threads"], "kind": "port", "n": cb["n"],
+                   "sample": f"one full oracle reduction (NumPy/SciPy restatement, not Julia) of the headline instance at N={cb['n']}, dim {cb['dim']}: "
+                             f"admissible_subspace {cb['adm_s']:.2f} s + blockDiagonalize {cb['bd_s']:.2f} s, measured (no extrapolation)"}
     total_red = args.steps * world
     if rank == 0:
         out = {
@@ -314,13 +413,11 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"i8": "int8 square (int32 acc) + f64 eigen", "f32": "f32 square + f64 eigen", "f64": "f64"}[args.mode],
             "data": "synthetic",
-            "config": {"workload": f"configs[3]: synthetic Jordan algebra N={n}, {d} basis matrices (circulant Z_32 (x) K_128 scheme, seeded permutation), "
-                                   f"square_mode={args.mode}, 4 channels", "N": n, "dim": int(d), "restarts_per_step": world,
-                       "iterations_per_reduction": iters_timed / max(1, args.steps)},
-            "phase_ms_per_step": {k: round(phase_timed[i] / args.steps, 3) for k, i in
-                                  (("project", L.T_PROJECT), ("square", L.T_SQUARE), ("refine", L.T_REFINE), ("eigen", L.T_EIGEN),
-                                   ("iso_QtAQ", L.T_ISO), ("irreducible", L.T_IRRED), ("basis_image", L.T_IMAGE))},
-            "roofline": roof, "kernels": kernels, "variants": variants, "cpu_baseline": cpu,
+            "config": {"workload": f"configs[3]: synthetic Jordan algebra N={w0.n}, {w0.d} basis matrices, instance '{args.workload}' ({w0.note}), "
+                                   f"square_mode={args.mode}, 4 channels", "N": w0.n, "dim": w0.d, "restarts_per_step": world,
+                       "iterations_per_reduction": acc_timed.iters / max(1, args.steps)},
+            "phase_ms_per_step": phases(acc_timed, args.steps),
+            "workloads": workloads, "roofline": roof, "kernels": kernels, "variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     ctx.close()

@@ -245,8 +245,9 @@ int sdpsr_syev_f64(sdpsr_ctx* ctx, int64_t n, const double* A, double* values, d
    0 = square int8 MFMA (one channel), 1 = square fp32 MFMA, 2 = square / Q'AQ fp64 MFMA,
    3 = partition refine of n*n signatures with `aux` distinct classes,
    4 = fused gather+projection+signature pass with r = aux basis vectors,
-   5 = the tridiagonalisation's column-dot (symv) kernel, one launch per column j = 0..n-2
-       (average over the n-1 launches), 6 = one whole tridiagonalisation of order n.
+   5 = the tridiagonalisation's symmetric-product (symv) kernel, one launch per column j = 0..n-2
+       (average over the n-1 launches), 6 = one whole tridiagonalisation of order n,
+   8 = the one-workgroup Jacobi eigensolver on a random symmetric matrix of order n <= 128.
    ms_per_launch[0] = average milliseconds per launch. */
 int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps,
                          double* ms_per_launch);

@@ -270,11 +270,16 @@ def admissible_setup(C_, A, b, atol=RTOL_DEFAULT):
         raise ValueError("length(C) is not a perfect square")
     Ad = np.asarray(_dense(A), dtype=np.float64)
     if Ad.shape[0] > 0:
-        Q, R, _ = sla.qr(Ad.T, mode="economic", pivoting=True)
+        Q, R, _piv = sla.qr(Ad.T, mode="economic", pivoting=True)
         dg = np.abs(np.diag(R))
         r = int(np.sum(dg > 1e-12 * dg.max())) if dg.size and dg.max() > 0 else 0
         U = np.asfortranarray(Q[:, :r])
-        x0, *_ = np.linalg.lstsq(Ad, np.asarray(b, dtype=np.float64), rcond=None)  # Krylov.craig, :137
+        # min-norm solution of A x = b (Krylov.craig, :137) from the factorisation at hand:
+        # A[piv, :] = R' Q'  =>  x0 = Q_r y with R_rr' y = b[piv][:r]  (a LAPACK gelsd call on an
+        # m x n^2 matrix with n^2 = 16.7M has been seen to crash inside the library)
+        bb = np.asarray(b, dtype=np.float64)[_piv]
+        y = sla.solve_triangular(R[:r, :r], bb[:r], trans="T", lower=False) if r else np.zeros(0)
+        x0 = U @ y
     else:
         U = np.zeros((n * n, 0), order="F")
         x0 = np.zeros(n * n)

@@ -2121,6 +2121,7 @@ void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t
 size_t sytrd_workspace_doubles(int64_t n, int64_t ld);
 void launch_sytrd(sdpsr_ctx* c, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
 void launch_sytrd_symv_sweep(hipStream_t s, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws);
+bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double* w, double* Vtmp, int* info);
 }
 
 extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t aux, int reps,
@@ -2238,6 +2239,27 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         hipEventDestroy(e1);
         HIP_TRY(c, hipGetLastError());
         return SDPSR_OK;
+    } else if (kind == 8) {
+        // one-workgroup Jacobi eigensolver (n <= 128) on a device-resident random symmetric matrix
+        if (n > 128) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "kind 8: n <= 128");
+        double* A = (double*)ctx_buf(c, "prof_x", (size_t)(reps + 1) * n * n * 8);
+        double* wv = (double*)ctx_buf(c, "prof_d", (size_t)n * 8 + 64);
+        double* Vt = (double*)ctx_buf(c, "prof_c", (size_t)n * n * 8);
+        int* info = (int*)ctx_buf(c, "eig_info", 64);
+        if (!A || !wv || !Vt || !info) return SDPSR_OUT_OF_MEMORY;
+        std::vector<double> h((size_t)(reps + 1) * n * n);
+        for (int rp = 0; rp <= reps; ++rp)
+            for (int64_t j2 = 0; j2 < n; ++j2)
+                for (int64_t i2 = 0; i2 <= j2; ++i2) {
+                    const double v = (double)(sdpsr_fmix64((uint64_t)(rp * 7919 + i2 * 131 + j2 * 1000003)) >> 11) * (1.0 / 9007199254740992.0);
+                    h[(size_t)rp * n * n + i2 + j2 * n] = h[(size_t)rp * n * n + j2 + i2 * n] = v;
+                }
+        HIP_TRY(c, hipMemcpyAsync(A, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        launch_small_syev(s, n, A + (size_t)reps * n * n, n, wv, Vt, info);  // warm-up
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) launch_small_syev(s, n, A + (size_t)i * n * n, n, wv, Vt, info);
+        HIP_TRY(c, hipEventRecord(e1, s));
     } else {
         return ctx_fail(c, SDPSR_BAD_ARGUMENT, "unknown kernel kind");
     }

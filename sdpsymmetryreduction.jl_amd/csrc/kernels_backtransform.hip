@@ -41,13 +41,13 @@ bt_extract_panel_kernel(int n, int64_t ld, const double* __restrict__ A, int j0,
 
 // T (128 x 128, column-major, upper triangular) from the Gram matrix G = V'V and tau (dlarft,
 // forward / columnwise):  T[j,j] = tau_j,  T[0:j, j] = -tau_j * T[0:j, 0:j] * G[0:j, j].
-// One workgroup; T and the needed part of G live in LDS (2 x 128 KiB would not fit: the strictly
-// upper triangle of G is packed).  Thread i owns row i of T.
+// One workgroup; T lives in LDS (thread i owns row i, so the recurrence needs no barriers), G
+// passes through LDS 16 columns at a time, prefetched into registers a chunk ahead.
 __global__ void __launch_bounds__(128)
 bt_larft_kernel(const double* __restrict__ G, const double* __restrict__ tau, int j0, int n, double* __restrict__ T) {
     extern __shared__ double sm[];
     double* sT = sm;                    // 128 x 128, ld 129 (row i read by thread i: conflict-free)
-    double* sg = sT + 128 * 129;        // current column of G (128)
+    double* sg = sT + 128 * 129;        // 16 columns of G at a time: sg[c * 128 + i]
     __shared__ double s_tau[128];
     const int i = threadIdx.x;
     for (int e = i; e < 128 * 129; e += 128) sT[e] = 0.0;
@@ -55,22 +55,39 @@ bt_larft_kernel(const double* __restrict__ G, const double* __restrict__ tau, in
         const int j = j0 + i;
         s_tau[i] = (j <= n - 2) ? tau[j] : 0.0;
     }
-    __syncthreads();
-    for (int j = 0; j < 128; ++j) {
-        sg[i] = (i < j) ? G[i + (int64_t)j * 128] : 0.0;
-        __syncthreads();
-        const double tj = s_tau[j];
-        double acc = 0.0;
-        if (i < j) {
-            // (T[0:j,0:j] * g)[i] = sum_{k >= i} T[i,k] g[k]  (T upper triangular)
-            for (int k = i; k < j; ++k) acc = fma(sT[i * 129 + k], sg[k], acc);
-            acc = -tj * acc;
+    // G is read 16 columns ahead into registers (16 independent loads per thread), so the
+    // sequential recurrence never waits on global memory
+    double gnext[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) gnext[c] = G[i + (int64_t)c * 128];
+    for (int jb = 0; jb < 128; jb += 16) {
+        __syncthreads();  // the previous chunk of sg has been consumed
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sg[c * 128 + i] = gnext[c];
+        if (jb + 16 < 128) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) gnext[c] = G[i + (int64_t)(jb + 16 + c) * 128];
         }
         __syncthreads();
-        if (i < j) sT[i * 129 + j] = acc;
-        if (i == j) sT[i * 129 + j] = tj;
+        for (int jc = 0; jc < 16; ++jc) {
+            const int j = jb + jc;
+            const double tj = s_tau[j];
+            const double* gcol = sg + jc * 128;
+            if (i < j) {
+                // (T[0:j,0:j] * g)[i] = sum_{k >= i} T[i,k] g[k]  (T upper triangular); two chains
+                double a0 = 0.0, a1 = 0.0;
+                int k = i;
+                for (; k + 1 < j; k += 2) {
+                    a0 = fma(sT[i * 129 + k], gcol[k], a0);
+                    a1 = fma(sT[i * 129 + k + 1], gcol[k + 1], a1);
+                }
+                if (k < j) a0 = fma(sT[i * 129 + k], gcol[k], a0);
+                sT[i * 129 + j] = -tj * (a0 + a1);  // column j of T is only read by later steps
+            }
+            if (i == j) sT[i * 129 + j] = tj;
+            // no barrier: thread i reads and writes row i of T only; the shared column of G is read-only
+        }
     }
-    __syncthreads();
     for (int e = i; e < 128 * 128; e += 128) {
         const int c = e >> 7, r = e & 127;
         T[r + (int64_t)c * 128] = sT[r * 129 + c];
@@ -79,7 +96,7 @@ bt_larft_kernel(const double* __restrict__ G, const double* __restrict__ tau, in
 
 void backtransform_set_device_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (128 * 129 + 128) * 8);
+                        (128 * 129 + 16 * 128) * 8);
 }
 
 void launch_bt_extract_panel(hipStream_t s, int64_t n, int64_t ld, const double* A, int64_t j0, int64_t r0, double* Vp,
@@ -88,7 +105,7 @@ void launch_bt_extract_panel(hipStream_t s, int64_t n, int64_t ld, const double*
     bt_extract_panel_kernel<<<grid, 256, 0, s>>>((int)n, ld, A, (int)j0, (int)r0, Vp, VpT);
 }
 void launch_bt_larft(hipStream_t s, const double* G, const double* tau, int64_t j0, int64_t n, double* T) {
-    bt_larft_kernel<<<1, 128, (128 * 129 + 128) * 8, s>>>(G, tau, (int)j0, (int)n, T);
+    bt_larft_kernel<<<1, 128, (128 * 129 + 16 * 128) * 8, s>>>(G, tau, (int)j0, (int)n, T);
 }
 
 }  // namespace sdpsr

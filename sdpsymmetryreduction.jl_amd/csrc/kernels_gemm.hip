@@ -263,12 +263,12 @@ gemm_tn_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <int KIND>
+template <int KIND, int CMODE>  // CMODE 0: C = A'B, 1: C -= A'B
 __global__ void __launch_bounds__(NT)
 gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict__ Ag, int64_t lda,
                    const typename GemmTraits<KIND>::in_t* __restrict__ Bg, int64_t ldb,
                    typename GemmTraits<KIND>::out_t* __restrict__ Cg, int64_t ldc, int64_t strideA, int64_t strideB,
-                   int64_t strideC, const uint32_t* __restrict__ nonsym_flag, int cmode) {
+                   int64_t strideC, const uint32_t* __restrict__ nonsym_flag) {
     typedef typename GemmTraits<KIND>::in_t in_t;
     typedef typename GemmTraits<KIND>::out_t out_t;
     constexpr int ES = sizeof(in_t);
@@ -458,7 +458,7 @@ gemm_tn_dma_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (cmode == 0) {
+        if constexpr (CMODE == 0) {
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -652,8 +652,11 @@ static void gemm_set_attributes_kind() {
     constexpr int KBt = GemmTraits<KIND>::KB;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<KIND>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM * (KBt + 16));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND, 0>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM * 128);
+    if constexpr (KIND == KIND_F64)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND, 1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM * 128);
     if constexpr (KIND == KIND_I8 || KIND == KIND_F32)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma256_kernel<KIND>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM2 * 128);
@@ -692,7 +695,13 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
             }
         }
         constexpr size_t lds_dma = 2 * 2 * BM * 128;  // 64 KiB
-        gemm_tn_dma_kernel<KIND><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag, cmode);
+        if constexpr (KIND == KIND_F64) {
+            if (cmode) {
+                gemm_tn_dma_kernel<KIND, 1><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
+                return;
+            }
+        }
+        gemm_tn_dma_kernel<KIND, 0><<<grid, NT, lds_dma, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
         return;
     }
     gemm_tn_kernel<KIND><<<grid, NT, lds, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag, cmode);

@@ -163,3 +163,45 @@ def test_module_compression_driver_agrees_with_dense(pkg, problems, oracle, gold
             for i in range(0, d, max(1, d // 7)):
                 for k in range(len(bd.blkSizes)):
                     assert np.allclose(bd.blks[i][k], ref[i][k], atol=1e-9)
+
+
+def _bench_instance(problems, golden, name):
+    if name == "closed_scheme":
+        L, d = problems.synthetic_jordan_partition(4096, seed=1)
+        Cv, A, b = problems.partition_as_sdp(L, seed=1)
+        return Cv, A, b, L, d, [1] * d, 1
+    if name == "theta_c32xk128":
+        Cv, A, b, L, d = problems.theta_prime_product_problem(problems.cycle_adjacency(32), problems.symmetric_circulant_labels(32), 128, seed=1)
+        return Cv, A, b, L, d, [1] * d, 5
+    Cv, A, b, L, d = problems.theta_prime_product_problem(problems.er_graph_adjacency(7), golden["er7_P"].astype(np.int64), 72, seed=1)
+    return Cv, A, b, L, d, [2, 2, 2, 2, 3] * 2, 5
+
+
+@pytest.mark.parametrize("name", ["closed_scheme", "theta_c32xk128", "theta_er7xk72"])
+def test_bench_instances_n4096(pkg, problems, oracle, golden, name):
+    """The exact instances bench.py times (configs[3] at N = 4096 / 4104), checked against more
+    than themselves: bit-exact partition vs the generator's closure (the theta' instances must get
+    there from {diagonal, edges, non-edges} in 5 iterations), pinned block sizes,
+    blks == Q_k' 1[P==i] Q_k on sampled classes (host products, atol 1e-9), and the spectrum
+    invariant of SURVEY 8c (block eigenvalues of sum_i x_i blks[i][k] = distinct eigenvalues of
+    sum_i x_i 1[P==i], rtol 1e-6) with the full N x N spectrum from LAPACK."""
+    Cv, A, b, L, d, blocks, iters = _bench_instance(problems, golden, name)
+    n = L.shape[0]
+    with pkg.Context(seed=1000) as ctx:
+        P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, host_setup=True)
+        assert P.nparts == d
+        assert np.array_equal(P.matrix, L)
+        assert P.iterations == iters
+        bd = pkg.blockDiagonalize(P, ctx=ctx, retries=3)
+    assert sorted(bd.blkSizes) == sorted(blocks)
+    Q = [np.asarray(q) for q in bd.Q_hat]
+    for i in sorted(set(np.linspace(1, d, 6).astype(int))):
+        M = (L == i).astype(np.float64)
+        for k, q in enumerate(Q):
+            ref = q.T @ (M @ q)
+            ref[np.abs(ref) < 1e-12 * n] = 0.0
+            assert np.allclose(bd.blks[i - 1][k], ref, atol=1e-9), (name, i, k)
+    x = np.random.default_rng(3).random(d)
+    full, blk = oracle.spectrum_invariant(oracle.Partition(d, L), bd.blks, x)
+    assert len(full) == len(blk), (name, len(full), len(blk))
+    assert np.allclose(full, blk, rtol=1e-6, atol=1e-8 * np.abs(full).max())
