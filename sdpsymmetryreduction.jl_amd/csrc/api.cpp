@@ -256,7 +256,33 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
     const int64_t nblk = (len + rb - 1) / rb;
     int attempts = 0;
     bool mispredicted = false;
+    // many-classes regime (problems without symmetry: ~len/2 distinct signatures): a hash table
+    // that large means one global atomic per entry into memory no cache holds; the radix-sort
+    // relabel (kernels_refine_sort.hip) moves ~15x the algorithmic bytes but streams.  Taken when
+    // the previous refinement ended above 2^18 classes, or when a table of 2^20 slots overflows.
+    const bool sort_ok = len >= (int64_t(1) << 18) && len < (int64_t(1) << 31) && !getenv("SDPSR_REFINE_NO_SORT");
+    bool use_sort = sort_ok && (c->table_log2_hint >= 21 || getenv("SDPSR_REFINE_FORCE_SORT"));
     for (;;) {
+        if (use_sort) {
+            const size_t wsb = refine_sorted_workspace_bytes(len);
+            void* wsp = ctx_buf(c, "ref_sort_ws", wsb);
+            uint32_t* counters = (uint32_t*)ctx_buf(c, "ref_counters", refine_counters_bytes());
+            uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
+            if (!wsp || !counters || !h) return SDPSR_OUT_OF_MEMORY;
+            if (!launch_refine_sorted(c->stream, len, sig, labels, wsp, wsb, counters))
+                return ctx_fail(c, SDPSR_HIP_ERROR, "sort-based refinement failed");
+            HIP_TRY(c, hipMemcpyAsync(h, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            if (sym_n > 0 && symflag_dev) {
+                launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);
+                HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (sym_n > 0 && symflag_dev && sym_out) *sym_out = h[8] ? 0 : 1;
+            HIP_TRY(c, hipGetLastError());
+            *nparts = h[2];
+            c->table_log2_hint = std::min(full, std::max(12, ceil_log2((uint64_t)h[2] * 8 + 1)));
+            return SDPSR_OK;
+        }
         const size_t cap = size_t(1) << log2cap;
         RefineWs ws;
         ws.tab_sig = (uint64_t*)ctx_buf(c, "ref_tab_sig", cap * 8);
@@ -285,6 +311,11 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
             continue;
         }
         if (h[1]) {  // table too small for this many classes
+            if (sort_ok) {  // 2^16, 2^20 slots, then the sorted relabel (it wins beyond ~2^18 classes)
+                if (log2cap >= 20) use_sort = true;
+                else log2cap = std::min(full, log2cap < 16 ? 16 : 20);
+                continue;
+            }
             if (log2cap >= full) return ctx_fail(c, SDPSR_HIP_ERROR, "refine hash table overflow at full size");
             // the dimension can jump by orders of magnitude between two refinements (generic
             // problems go from a handful of classes to ~n^2/2 in one step): one large step, then full

@@ -687,7 +687,8 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
             // (one resident workgroup per CU: fewer leave a ragged last round)
             const int64_t t2 = m / BM2;
             const int64_t wgs = (nonsym_flag ? t2 * (t2 + 1) / 2 : t2 * (n / BM2)) * batch;
-            if (!only128 && m % BM2 == 0 && n % BM2 == 0 && wgs >= 1024) {
+            static const int64_t min256 = getenv("SDPSR_GEMM256_MIN_WGS") ? atoll(getenv("SDPSR_GEMM256_MIN_WGS")) : 1024;  // measurement knob
+            if (!only128 && m % BM2 == 0 && n % BM2 == 0 && wgs >= min256) {
                 constexpr size_t lds256 = 2 * 2 * BM2 * 128;  // 128 KiB
                 dim3 grid2((unsigned)(m / BM2), (unsigned)(n / BM2), (unsigned)batch);
                 gemm_tn_dma256_kernel<KIND><<<grid2, NT2, lds256, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);

@@ -132,6 +132,11 @@ uint32_t refine_small_k();
 void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out,
                    const RefineWs& ws);
 
+// kernels_refine_sort.hip: radix-sort relabel for the many-classes regime
+size_t refine_sorted_workspace_bytes(int64_t len);
+bool launch_refine_sorted(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
+                          uint32_t* counters);
+
 void launch_transpose_labels(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* Lt);
 void launch_labels_checksum(hipStream_t s, int64_t len, const uint32_t* L, uint64_t* partial, uint64_t* out);
 int64_t reduce_columns_chunk(int64_t len, int64_t m, int64_t d);

@@ -646,3 +646,36 @@ def test_device_inputs_from_an_async_torch_kernel(pkg, problems, golden):
             assert P.nparts == 18
             assert np.array_equal(P.matrix.cpu().numpy().astype(np.uint32), golden["er7_P"])
             del junk
+
+
+def test_sort_based_refine_matches_oracle(pkg, oracle, monkeypatch):
+    """Radix-sort relabel (many-classes regime, kernels_refine_sort.hip) against the oracle's
+    canonical labels: forced on inputs with few, many and all-distinct classes, a zero class,
+    and through refine! (pairs of labels)."""
+    import os
+    rng = np.random.default_rng(21)
+    n = 640  # n^2 >= 2^18: the sorted path is eligible
+    cases = {
+        "few": rng.integers(0, 7, size=(n, n)).astype(np.float64) * 0.25,
+        "many": rng.integers(0, 150000, size=(n, n)).astype(np.float64),
+        "distinct": rng.permutation(n * n).reshape(n, n).astype(np.float64) + 1.0,
+    }
+    cases["many"][rng.random((n, n)) < 0.1] = 0.0
+    for forced in (True, False):
+        if forced:
+            monkeypatch.setenv("SDPSR_REFINE_FORCE_SORT", "1")
+        else:
+            monkeypatch.delenv("SDPSR_REFINE_FORCE_SORT", raising=False)
+        with pkg.Context(seed=2) as ctx:
+            for name, M in cases.items():
+                P = pkg.Partition.from_matrix(M, ctx=ctx)
+                R = oracle.partition_from_values(M)
+                assert P.nparts == R.nparts, (name, forced)
+                assert np.array_equal(P.matrix, R.matrix), (name, forced)
+            A = rng.integers(0, 900, size=(n, n))
+            B = rng.integers(0, 900, size=(n, n))
+            P1 = pkg.Partition.from_matrix(A, ctx=ctx)
+            P2 = pkg.Partition.from_matrix(B, ctx=ctx)
+            R = oracle.refine(oracle.partition_from_labels(A), oracle.partition_from_labels(B))
+            P3 = pkg.refine(P1, P2, ctx=ctx)
+            assert P3.nparts == R.nparts and np.array_equal(P3.matrix, R.matrix), forced
