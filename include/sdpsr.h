@@ -215,6 +215,25 @@ int sdpsr_q_hat(sdpsr_ctx* ctx, double* Q_hat, int mem);
    blks: d * sum_sq doubles, class-major, then block, each block column-major s_k x s_k.
    Q_hat (optional, may be NULL): n x sum_s column-major, blocks side by side. */
 int sdpsr_block_images(sdpsr_ctx* ctx, double* blks, double* Q_hat, double* phase_ms, int mem);
+/* ---- blockDiagonalize(P; complex = true), src/compat.jl:26-32,46-68 with T = ComplexF64 ---------
+   diagonalize(ComplexF64, P) = desymmetrize (src/diagonalize.jl:26-28) + Murota's decomposition
+   over C + check_block_sizes with sum s_k^2 == dim(P) (:13-23); the partition handed to
+   basis_image is the desymmetrized one (src/compat.jl:54-57).
+   This version covers n <= 64 (every step in single-workgroup kernels; the reference's own
+   complex tests are 3 x 3 and 4 x 4, test/runtests.jl:43-57); larger n: SDPSR_BAD_ARGUMENT.
+   BEHAVIOURAL DIFFERENCE: the generic elements are Hermitian (A + A^H with complex class
+   coefficients) and the eigensolver is a Hermitian Jacobi iteration, where the reference hands a
+   general complex element to eigen(); block sizes and block spectra are the same.
+   P_desym (optional, n x n labels in `mem`) / *d_desym: the desymmetrized partition whose classes
+   index the block images. */
+int sdpsr_block_diagonalize_complex(sdpsr_ctx* ctx, int64_t n, const uint32_t* P, int64_t d, double epsilon,
+                                    uint32_t* P_desym, int64_t* d_desym, int32_t* nblocks, int64_t* sum_sq,
+                                    int64_t* sum_s, int mem);
+int sdpsr_block_sizes_complex(sdpsr_ctx* ctx, int32_t* blk_sizes);
+/* blks: d_desym * sum_sq complex numbers as (re, im) pairs, class-major, then block, each block
+   column-major s_k x s_k.  Q_hat (optional): n x sum_s complex, (re, im) pairs, column-major. */
+int sdpsr_block_images_complex(sdpsr_ctx* ctx, double* blks, double* Q_hat, int mem);
+
 /* eigen_decomposition(P, A; atol), src/eigen_decomposition.jl:236-273: status only
    (test/numerical_issues.jl:91-94), *neig = number of eigenspaces, *nclasses = number of
    isomorphism classes. */

@@ -594,6 +594,115 @@ def block_diagonalize(P: Partition, epsilon=RTOL_DEFAULT, rng=None):
 
 
 # --------------------------------------------------------------------------
+# complex path: blockDiagonalize(P; complex=true) -- src/compat.jl:26-32,46-68 with T = ComplexF64,
+# src/diagonalize.jl:13-28.  Restated literally: a generic element with COMPLEX coefficients
+# (rand(ComplexF64, dim), src/abstract_part.jl:108), the general eigen() of LinearAlgebra
+# (eigenvalues sorted by (real, imag), Julia's default eigsortby), adjoints where the source
+# writes '.  Pinned by test/runtests.jl:43-57.
+# --------------------------------------------------------------------------
+def randomize_complex(P: Partition, rng) -> np.ndarray:
+    vals = rng.random(P.nparts) + 1j * rng.random(P.nparts)
+    table = np.concatenate([[0.0 + 0.0j], vals])
+    return table[P.matrix]
+
+
+def _eigen_complex(A):
+    vals, Q = sla.eig(A)
+    order = np.lexsort((vals.imag, vals.real))  # sortby = λ -> (real(λ), imag(λ))
+    return vals[order], Q[:, order]
+
+
+def eigen_decomposition_complex(P: Partition, atol, rng):
+    """src/eigen_decomposition.jl:236-273 with T = ComplexF64."""
+    A = randomize_complex(P, rng)
+    vals, Q = _eigen_complex(A)
+    ed = make_eigen_decomposition(vals, Q, atol)
+    A = randomize_complex(P, rng)
+    QAQ = Q.conj().T @ A @ Q
+    norms = block_norms_inf(QAQ, ed)
+    thr = otsu_threshold(norms, atol)
+    ne = len(ed)
+    K = IntDisjointSets(ne)
+    for i in range(ne):
+        for j in range(i + 1, ne):
+            if norms[i, j] >= thr:
+                K.union(i, j)
+    if not is_consistent(K):
+        raise NumericalInconsistency("the K-partition seems inconsistent with eigenspaces")
+    return ed, K
+
+
+def irreducible_decomposition_complex(ed, K, P, rng):
+    """src/eigen_decomposition.jl:295-348 with complex matrices (' = adjoint)."""
+    kp = [K.find_root(i) for i in range(len(K))]
+    roots = list(dict.fromkeys(kp))
+    A = randomize_complex(P, rng)
+    Q = ed.vectors
+    P_hat = []
+    for i in roots:
+        Ki = [j for j, r in enumerate(kp) if r == i]
+        assert Ki[0] == i
+        if len(Ki) == 1:
+            P_hat.append(Q[:, ed.ptrs[i]:ed.ptrs[i] + 1].copy())
+            continue
+        QKi = np.hstack([Q[:, ed.rng(j)] for j in Ki])
+        m = ed.dim(i)
+        Pi = np.zeros((QKi.shape[1], QKi.shape[1]), dtype=complex)
+        Pi[:m, :m] = np.eye(m)
+        Qi = Q[:, ed.rng(i)]
+        for nn, j in enumerate(Ki[1:], start=1):
+            Qj = Q[:, ed.rng(j)]
+            blk = (Qi.conj().T @ A @ Qj).conj().T  # block(A, Ei, Ej)'
+            blk = blk / np.linalg.norm(blk[0, :])
+            Pi[nn * m:(nn + 1) * m, nn * m:(nn + 1) * m] = blk
+        P_hat.append(QKi @ Pi if m == 1 else QKi @ Pi[:, 0:m * len(Ki):m])
+    return P_hat
+
+
+def block_diagonalize_complex(P: Partition, epsilon=RTOL_DEFAULT, rng=None):
+    """``blockDiagonalize(ComplexF64, P)`` -- src/compat.jl:46-68.  Returns
+    (blkSizes, blks, Q_hat, desymmetrized partition)."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    Pd = desymmetrize(Partition(P.nparts, P.matrix.copy()), rng=rng)  # src/diagonalize.jl:26-28
+    ed, K = eigen_decomposition_complex(Pd, epsilon, rng)
+    Q_hat = [np.where(np.abs(q) < epsilon, 0, q) for q in irreducible_decomposition_complex(ed, K, Pd, rng)]
+    Pd2 = desymmetrize(Partition(P.nparts, P.matrix.copy()), atol=epsilon, rng=rng)  # src/compat.jl:54-57
+    sizes = [q.shape[1] for q in Q_hat]
+    if sum(s * s for s in sizes) != Pd2.nparts:  # src/diagonalize.jl:13-23
+        raise DimensionMismatch(f"final_dim={sum(s * s for s in sizes)} block_sizes={sizes} expected={Pd2.nparts}")
+    n = P.matrix.shape[0]
+    blks = []
+    for i in range(1, Pd2.nparts + 1):
+        Mi = (Pd2.matrix == i).astype(np.float64)
+        row = []
+        for q in Q_hat:
+            b = q.conj().T @ (Mi @ q)
+            row.append(np.where(np.abs(b) < 1e-12 * n, 0, b))
+        blks.append(row)
+    return sizes, blks, Q_hat, Pd2
+
+
+def spectrum_invariant_complex(P: Partition, blks, x, tol=1e-7):
+    """Complex analogue of ``spectrum_invariant``: distinct eigenvalues (complex) of
+    sum_i x_i 1[P==i] (P need not be symmetric) vs the union of the block spectra; both sorted
+    by (real, imag)."""
+    A = fill(P, x)
+    full = np.linalg.eigvals(A)
+    vals = np.concatenate([np.linalg.eigvals(sum(x[i] * blks[i][k] for i in range(P.nparts))) for k in range(len(blks[0]))])
+
+    def distinct(v):
+        scale = max(1.0, np.abs(v).max())
+        keep = []
+        for z in v[np.lexsort((np.round(v.imag, 9), np.round(v.real, 9)))]:
+            if all(abs(z - k) > tol * scale for k in keep):
+                keep.append(z)
+        keep = np.array(keep)
+        return keep[np.lexsort((np.round(keep.imag, 6), np.round(keep.real, 6)))]
+
+    return distinct(full), distinct(vals)
+
+
+# --------------------------------------------------------------------------
 # spectrum invariant (SURVEY.md 8c): defines "block eigenvalues within 1e-6 rel"
 # --------------------------------------------------------------------------
 def spectrum_invariant(P: Partition, blks, x, tol=1e-7):

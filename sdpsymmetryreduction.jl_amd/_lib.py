@@ -86,6 +86,9 @@ def load_library():
         "sdpsr_q_hat": (C.c_int, [vp, vp, C.c_int]),
         "sdpsr_block_images": (C.c_int, [vp, vp, vp, vp, C.c_int]),
         "sdpsr_eigen_decomposition": (C.c_int, [vp, i64, vp, i64, dbl, pi32, pi32, C.c_int]),
+        "sdpsr_block_diagonalize_complex": (C.c_int, [vp, i64, vp, i64, dbl, vp, pi64, pi32, pi64, pi64, C.c_int]),
+        "sdpsr_block_sizes_complex": (C.c_int, [vp, vp]),
+        "sdpsr_block_images_complex": (C.c_int, [vp, vp, vp, C.c_int]),
         "sdpsr_eigen_decomposition_batched": (C.c_int, [vp, i64, vp, i64, dbl, i64, vp, vp, vp, vp, C.c_int]),
         "sdpsr_syev_f64": (C.c_int, [vp, i64, vp, vp, vp, C.c_int]),
         "sdpsr_profile_kernel": (C.c_int, [vp, C.c_int, i64, i64, C.c_int, C.POINTER(C.c_double)]),

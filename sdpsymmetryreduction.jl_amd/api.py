@@ -397,6 +397,7 @@ unSymmetrize = desymmetrize  # src/compat.jl:70
 # blockDiagonalize
 # ---------------------------------------------------------------------------
 BlockDiagonalization = namedtuple("BlockDiagonalization", ["blkSizes", "blks", "Q_hat", "phase_ms"])
+ComplexBlockDiagonalization = namedtuple("ComplexBlockDiagonalization", ["blkSizes", "blks", "Q_hat", "partition"])
 
 
 def _labels_arg(P):
@@ -414,9 +415,9 @@ def blockDiagonalize(P, verbose=False, epsilon=RTOL_DEFAULT, complex=False, ctx=
     ``retries`` > 0 re-runs the randomized decomposition with fresh generic elements when it ends
     in ``NumericalInconsistency`` / ``DimensionMismatch`` -- what the reference's error texts ask
     the caller to do ("try again"); the default 0 is the reference's behaviour."""
-    if complex:
-        raise NotImplementedError("complex path (desymmetrize + ComplexF64 eigen) is outside the HIP hot path; see DESIGN.md")
     ctx = _ctx(ctx)
+    if complex:
+        return _block_diagonalize_complex(P, verbose, epsilon, ctx, retries)
     for attempt in range(int(retries)):
         try:
             return blockDiagonalize(P, verbose=verbose, epsilon=epsilon, ctx=ctx, retries=0)
@@ -456,6 +457,49 @@ def blockDiagonalize(P, verbose=False, epsilon=RTOL_DEFAULT, complex=False, ctx=
         print(f"[sdpsr] blockDiagonalize: blocks {list(sizes)}; eigen {ms[L.T_EIGEN]:.3f} ms, iso {ms[L.T_ISO]:.3f}, "
               f"irreducible {ms[L.T_IRRED]:.3f}, image {ms[L.T_IMAGE]:.3f}")
     return BlockDiagonalization([int(s) for s in sizes], out, Q, ms)
+
+
+def _block_diagonalize_complex(P, verbose, epsilon, ctx, retries):
+    """``blockDiagonalize(ComplexF64, P)`` (src/compat.jl:46-68, src/diagonalize.jl:13-28): the
+    block images are indexed by the classes of the DESYMMETRIZED partition (src/compat.jl:54-57),
+    returned as ``.partition`` of the result."""
+    for attempt in range(int(retries)):
+        try:
+            return _block_diagonalize_complex(P, verbose, epsilon, ctx, 0)
+        except (NumericalInconsistency, DimensionMismatch):
+            pass
+    n = P.shape[0]
+    lab = _f(np.asarray(P.matrix.cpu() if _is_torch(P.matrix) else P.matrix), np.uint32)
+    Pd = np.empty(n * n, dtype=np.uint32)
+    dd = C.c_int64(0)
+    nb = C.c_int32(0)
+    ssq = C.c_int64(0)
+    ss = C.c_int64(0)
+    ctx.check(ctx._lib.sdpsr_block_diagonalize_complex(ctx._h, n, _ptr(lab), P.nparts, float(epsilon), _ptr(Pd), C.byref(dd),
+                                                       C.byref(nb), C.byref(ssq), C.byref(ss), L.MEM_HOST))
+    sizes = np.zeros(nb.value, dtype=np.int32)
+    ctx.check(ctx._lib.sdpsr_block_sizes_complex(ctx._h, _ptr(sizes)))
+    d = dd.value
+    blks = np.empty(2 * d * ssq.value, dtype=np.float64)
+    qh = np.empty(2 * n * ss.value, dtype=np.float64)
+    ctx.check(ctx._lib.sdpsr_block_images_complex(ctx._h, _ptr(blks), _ptr(qh), L.MEM_HOST))
+    blks = blks.view(np.complex128).reshape(d, ssq.value)
+    qh = qh.view(np.complex128).reshape(n, ss.value, order="F")
+    out = []
+    for i in range(d):
+        row, off = [], 0
+        for s in sizes:
+            row.append(blks[i, off:off + s * s].reshape(s, s, order="F"))
+            off += s * s
+        out.append(row)
+    Q, off = [], 0
+    for s in sizes:
+        Q.append(qh[:, off:off + s])
+        off += s
+    res = ComplexBlockDiagonalization([int(s) for s in sizes], out, Q, Partition(d, Pd.reshape(n, n, order="F")))
+    if verbose:
+        print(f"[sdpsr] blockDiagonalize over ComplexF64: blocks {res.blkSizes}, dim(desymmetrized P) = {d}")
+    return res
 
 
 def diagonalize(P, atol=None, ctx=None):

@@ -399,6 +399,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
     small_syev_set_device_attributes();
     batched_set_device_attributes();
     backtransform_set_device_attributes();
+    complex_set_device_attributes();
     if (hipGetLastError() != hipSuccess) {
         hipStreamDestroy(c->stream);
         delete c;
@@ -1941,6 +1942,167 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
                             std::to_string(d) + " (rounding error: try another epsilon or try again; or the algebra is not block-diagonalizable over the reals)");
     }
     c->bd_valid = true;
+    return SDPSR_OK;
+}
+
+// ---- blockDiagonalize over C (src/compat.jl:26-32,46-68 with T = ComplexF64) ----------------
+int sdpsr_block_diagonalize_complex(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon,
+                                    uint32_t* P_desym, int64_t* d_desym, int32_t* nblocks, int64_t* sum_sq,
+                                    int64_t* sum_s, int mem) {
+    CHECK_CTX(c);
+    if (!P || n < 1 || d < 0 || !(epsilon > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    if (n > 64) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "complex path: this version covers n <= 64 (see sdpsr.h)");
+    const int64_t len = n * n;
+    hipStream_t s = c->stream;
+    c->bdc_valid = false;
+    // diagonalize(ComplexF64, P) desymmetrizes first (src/diagonalize.jl:26-28)
+    uint32_t* L = (uint32_t*)ctx_buf(c, "bdc_labels", len * 4);
+    if (!L) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(L, P, len * 4, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    int64_t dd = d;
+    int st = sdpsr_desymmetrize(c, n, L, &dd, nullptr, SDPSR_MEM_DEVICE);
+    if (st) return st;
+    const double atol = epsilon;
+    double* Hr = (double*)ctx_buf(c, "bdc_hr", len * 8);
+    double* Hi = (double*)ctx_buf(c, "bdc_hi", len * 8);
+    double* Vr = (double*)ctx_buf(c, "bdc_vr", len * 8);
+    double* Vi = (double*)ctx_buf(c, "bdc_vi", len * 8);
+    double* w = (double*)ctx_buf(c, "bdc_w", n * 8);
+    int* info = (int*)ctx_buf(c, "eig_info", 64);
+    if (!Hr || !Hi || !Vr || !Vi || !w || !info) return SDPSR_OUT_OF_MEMORY;
+    // Step 1-2: Hermitian generic element and its eigendecomposition (src/eigen_decomposition.jl:242-254)
+    launch_cx_gather_herm(s, n, L, next_key(c), Hr, Hi);
+    launch_cx_heev(s, n, Hr, Hi, w, Vr, Vi, info);
+    EigInfo ei;
+    ei.vals.resize(n);
+    int hinfo[2] = {0, 0};
+    st = d2h_sync(c, ei.vals.data(), w, n * 8);
+    if (!st) st = d2h_sync(c, hinfo, info, 8);
+    if (st) return st;
+    if (hinfo[0]) return ctx_fail(c, SDPSR_SOLVER_ERROR, "Hermitian Jacobi eigensolver did not converge");
+    ei.ptrs.assign(1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (i == n - 1) {
+            ei.ptrs.push_back((int)n);
+            break;
+        }
+        if (!(std::fabs(ei.vals[i + 1] - ei.vals[i]) <= atol)) ei.ptrs.push_back((int)i + 1);
+    }
+    const int neig = (int)ei.ptrs.size() - 1;
+    std::vector<int32_t> space_of(n);
+    for (int b = 0; b < neig; ++b)
+        for (int i = ei.ptrs[b]; i < ei.ptrs[b + 1]; ++i) space_of[i] = b;
+    // Step 3: second generic element, Q'AQ, block norms, isomorphism classes (:259-262, :201-217)
+    int32_t* dspace = (int32_t*)ctx_buf(c, "bd_space", (size_t)n * 4);
+    unsigned long long* dnorms = (unsigned long long*)ctx_buf(c, "bd_norms", (size_t)neig * neig * 8);
+    if (!dspace || !dnorms) return SDPSR_OUT_OF_MEMORY;
+    st = h2d_sync(c, dspace, space_of.data(), n * 4);
+    if (st) return st;
+    HIP_TRY(c, hipMemsetAsync(dnorms, 0, (size_t)neig * neig * 8, s));
+    launch_cx_gather_herm(s, n, L, next_key(c), Hr, Hi);
+    launch_cx_block_norms(s, n, Hr, Hi, Vr, Vi, dspace, neig, dnorms);
+    std::vector<double> norms((size_t)neig * neig);
+    st = d2h_sync(c, norms.data(), dnorms, (size_t)neig * neig * 8);
+    if (st) return st;
+    auto dimof = [&](int b) { return ei.ptrs[b + 1] - ei.ptrs[b]; };
+    for (int i = 0; i < neig; ++i)
+        for (int j = i; j < neig; ++j) {
+            const double v = (dimof(i) != dimof(j)) ? 0.0 : norms[(size_t)i * neig + j];
+            norms[(size_t)i * neig + j] = norms[(size_t)j * neig + i] = v;
+        }
+    st = isomorphism_classes(c, norms, neig, atol, ei.kpart);
+    if (st) return st;
+    // irreducible_decomposition (:295-348)
+    std::vector<int> roots;
+    std::vector<std::vector<int>> members;
+    class_structure(ei.kpart, roots, members);
+    std::vector<int32_t> sizes(roots.size());
+    int64_t S1 = 0, S = 0;
+    std::vector<int32_t> desc;
+    for (size_t p = 0; p < roots.size(); ++p) {
+        sizes[p] = (int32_t)members[p].size();
+        const int i = roots[p];
+        for (size_t q = 0; q < members[p].size(); ++q) {
+            const int j = members[p][q];
+            const int32_t dsc[6] = {q == 0 ? 0 : 1, (int32_t)ei.ptrs[i], (int32_t)dimof(i), (int32_t)ei.ptrs[j], (int32_t)dimof(j),
+                                    (int32_t)(S1 + (int64_t)q)};
+            desc.insert(desc.end(), dsc, dsc + 6);
+        }
+        S1 += sizes[p];
+        S += (int64_t)sizes[p] * sizes[p];
+    }
+    double* Qhat = (double*)ctx_buf(c, "bdc_qhat", (size_t)2 * n * S1 * 8);
+    int32_t* ddesc = (int32_t*)ctx_buf(c, "bdc_desc", desc.size() * 4);
+    if (!Qhat || !ddesc) return SDPSR_OUT_OF_MEMORY;
+    st = h2d_sync(c, ddesc, desc.data(), desc.size() * 4);
+    if (st) return st;
+    launch_cx_gather_herm(s, n, L, next_key(c), Hr, Hi);  // generic element #3 (:306)
+    launch_cx_irreducible(s, n, Hr, Hi, Vr, Vi, ddesc, (int)S1, atol, Qhat);
+    HIP_TRY(c, hipGetLastError());
+    if (P_desym) HIP_TRY(c, hipMemcpyAsync(P_desym, L, len * 4, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->bdc_n = n;
+    c->bdc_d = dd;
+    c->bdc_sizes = sizes;
+    c->bdc_sum_s = S1;
+    c->bdc_sum_sq = S;
+    if (d_desym) *d_desym = dd;
+    if (nblocks) *nblocks = (int32_t)sizes.size();
+    if (sum_sq) *sum_sq = S;
+    if (sum_s) *sum_s = S1;
+    // check_block_sizes over C: sum s^2 == dim(P) (src/diagonalize.jl:13-23)
+    if (S != dd) {
+        std::string szs;
+        for (int32_t sz : sizes) szs += std::to_string(sz) + " ";
+        return ctx_fail(c, SDPSR_DIMENSION_MISMATCH, "final_dim=" + std::to_string(S) + " block_sizes=[" + szs + "] expected dim(P)=" +
+                                                         std::to_string(dd) + " over ComplexF64 (rounding error: try another epsilon or try again)");
+    }
+    c->bdc_valid = true;
+    return SDPSR_OK;
+}
+
+int sdpsr_block_sizes_complex(sdpsr_ctx* c, int32_t* blk_sizes) {
+    if (!c || !blk_sizes) return SDPSR_BAD_ARGUMENT;
+    if (c->bdc_sizes.empty()) return ctx_fail(c, SDPSR_BAD_STATE, "no complex block diagonalisation available");
+    memcpy(blk_sizes, c->bdc_sizes.data(), c->bdc_sizes.size() * sizeof(int32_t));
+    return SDPSR_OK;
+}
+
+int sdpsr_block_images_complex(sdpsr_ctx* c, double* blks, double* Q_hat, int mem) {
+    CHECK_CTX(c);
+    if (!c->bdc_valid) return ctx_fail(c, SDPSR_BAD_STATE, "sdpsr_block_diagonalize_complex has not succeeded on this ctx");
+    if (!blks) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    hipStream_t s = c->stream;
+    const int64_t n = c->bdc_n, d = c->bdc_d, S1 = c->bdc_sum_s, S = c->bdc_sum_sq;
+    uint32_t* L = (uint32_t*)ctx_buf(c, "bdc_labels", n * n * 4);
+    double* Qhat = (double*)ctx_buf(c, "bdc_qhat", (size_t)2 * n * S1 * 8);
+    int st = SDPSR_OK;
+    double* out = out_dev(c, "bdc_blks", blks, (size_t)2 * d * S, mem, &st);
+    int32_t* ddesc = (int32_t*)ctx_buf(c, "bdc_desc2", (size_t)2 * S * 4);
+    if (st || !L || !Qhat || !ddesc) return st ? st : SDPSR_OUT_OF_MEMORY;
+    std::vector<int32_t> hdesc(2 * (size_t)S);
+    {
+        int64_t o = 0, colbase = 0;
+        for (int32_t sz : c->bdc_sizes) {
+            for (int b2 = 0; b2 < sz; ++b2)
+                for (int a2 = 0; a2 < sz; ++a2) {
+                    hdesc[o] = (int32_t)(colbase + a2);
+                    hdesc[S + o] = (int32_t)(colbase + b2);
+                    ++o;
+                }
+            colbase += sz;
+        }
+    }
+    st = h2d_sync(c, ddesc, hdesc.data(), hdesc.size() * 4);
+    if (st) return st;
+    launch_cx_basis_image(s, n, d, S, L, Qhat, ddesc, ddesc + S, 1e-12 * (double)n, out);
+    HIP_TRY(c, hipGetLastError());
+    st = out_finish(c, blks, out, (size_t)2 * d * S, mem);
+    if (st) return st;
+    if (Q_hat) {
+        HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)2 * n * S1 * 8, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
     return SDPSR_OK;
 }
 

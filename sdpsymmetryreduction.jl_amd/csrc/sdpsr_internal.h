@@ -47,6 +47,10 @@ struct sdpsr_ctx {
     std::vector<int32_t> bd_sizes;
     int64_t bd_sum_s = 0, bd_sum_sq = 0;
     bool bd_valid = false;
+    // complex path (sdpsr_block_diagonalize_complex): its own state, n <= 64
+    int64_t bdc_n = 0, bdc_d = 0, bdc_sum_s = 0, bdc_sum_sq = 0;
+    std::vector<int32_t> bdc_sizes;
+    bool bdc_valid = false;
     bool bd_q_valid = false;  // "bd_qhat" holds Q_hat of the last diagonalize (even when check_block_sizes failed)
     bool bd_labels_owned = false;
     // hash table capacity hint (log2) for the next refine
@@ -161,6 +165,16 @@ void sytrd_set_device_attributes();
 void small_syev_set_device_attributes();
 void batched_set_device_attributes();
 void backtransform_set_device_attributes();
+void complex_set_device_attributes();
+// kernels_complex.hip (complex path of blockDiagonalize, n <= 64; planes re / im, ld = n)
+void launch_cx_gather_herm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, double* Hr, double* Hi);
+void launch_cx_heev(hipStream_t s, int64_t n, const double* Hr, const double* Hi, double* w, double* Vr, double* Vi, int* info);
+void launch_cx_block_norms(hipStream_t s, int64_t n, const double* Hr, const double* Hi, const double* Vr, const double* Vi,
+                           const int32_t* space_of, int neig, unsigned long long* norms);
+void launch_cx_irreducible(hipStream_t s, int64_t n, const double* Hr, const double* Hi, const double* Vr, const double* Vi,
+                           const int32_t* desc, int ncols, double atol, double* Qhat);
+void launch_cx_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S, const uint32_t* L, const double* Qhat,
+                           const int32_t* descA, const int32_t* descB, double atol, double* out);
 // kernels_batched.hip: `count` runs of eigen_decomposition on one partition of order n <= 64
 void launch_eigdec_batched64(hipStream_t s, int64_t n, int64_t d, int64_t count, const uint32_t* L, const double* values,
                              uint64_t seed, uint64_t stream_base, double atol, int32_t* status, int32_t* neig,

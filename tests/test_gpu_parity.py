@@ -679,3 +679,68 @@ def test_sort_based_refine_matches_oracle(pkg, oracle, monkeypatch):
             R = oracle.refine(oracle.partition_from_labels(A), oracle.partition_from_labels(B))
             P3 = pkg.refine(P1, P2, ctx=ctx)
             assert P3.nparts == R.nparts and np.array_equal(P3.matrix, R.matrix), forced
+
+
+# ------------------------------------------------ complex path (src/compat.jl:26-32,54-57)
+def _s3_cayley_labels():
+    import itertools
+    perms = list(itertools.permutations(range(3)))
+    idx = {p: i for i, p in enumerate(perms)}
+
+    def mul(a, b):
+        return tuple(a[b[i]] for i in range(3))
+
+    def inv(a):
+        r = [0] * 3
+        for i, x in enumerate(a):
+            r[x] = i
+        return tuple(r)
+
+    return np.array([[idx[mul(inv(g), h)] + 1 for h in perms] for g in perms])
+
+
+def test_complex_block_diagonalize_pins_and_images(pkg, oracle, gpu_ctx):
+    """test/runtests.jl:43-57 on the device: [1,1,1] for the 4 x 4 partition and for C3 (real
+    request: InvalidDecompositionField); plus the group algebra of S3 (non-symmetric partition,
+    C + C + M_2(C): blocks [1,1,2]).  Checked beyond the sizes: blks == Q_k^H 1[P==i] Q_k with
+    the returned Q_hat, orthonormal columns, and the complex spectrum invariant (block spectra of
+    sum_i x_i blks[i][k] = distinct eigenvalues of sum_i x_i 1[P==i], 1e-6 rel)."""
+    P4 = np.array([[1, 2, 3, 2], [2, 1, 2, 3], [3, 2, 1, 2], [2, 3, 2, 1]])
+    C3 = np.array([[1, 3, 2], [2, 1, 3], [3, 2, 1]])
+    cases = [(P4, [1, 1, 1]), (C3, [1, 1, 1]), (_s3_cayley_labels(), [1, 1, 2])]
+    with pytest.raises(pkg.InvalidDecompositionField):
+        pkg.blockDiagonalize(pkg.Partition.from_matrix(C3, ctx=gpu_ctx), ctx=gpu_ctx)
+    for Lm, expect in cases:
+        P = pkg.Partition.from_matrix(Lm, ctx=gpu_ctx)
+        for rep in range(5):
+            bd = pkg.blockDiagonalize(P, complex=True, ctx=gpu_ctx, retries=2)
+            assert sorted(bd.blkSizes) == expect
+            Pd = bd.partition
+            ref_pd = oracle.desymmetrize(oracle.partition_from_labels(Lm), rng=np.random.default_rng(rep))
+            assert Pd.nparts == ref_pd.nparts and np.array_equal(Pd.matrix, ref_pd.matrix)
+            assert sum(s * s for s in bd.blkSizes) == Pd.nparts
+            for k, q in enumerate(bd.Q_hat):
+                assert np.allclose(q.conj().T @ q, np.eye(q.shape[1]), atol=1e-10)
+                for i in range(Pd.nparts):
+                    M = (np.asarray(Pd.matrix) == i + 1).astype(np.float64)
+                    assert np.allclose(bd.blks[i][k], q.conj().T @ M @ q, atol=1e-10)
+            x = np.random.default_rng(7 + rep).random(Pd.nparts)
+            full, blk = oracle.spectrum_invariant_complex(oracle.Partition(Pd.nparts, np.asarray(Pd.matrix).astype(np.int64)), bd.blks, x)
+            assert len(full) == len(blk)
+            assert np.allclose(full, blk, rtol=1e-6, atol=1e-9)
+
+
+def test_complex_heev_against_lapack_through_block_images(pkg, gpu_ctx):
+    """A commutative non-symmetric scheme of order 63 (cyclic group Z_63: 63 classes, 63 blocks of
+    size 1): exercises the Hermitian Jacobi eigensolver near its size limit."""
+    n = 63
+    i = np.arange(n)
+    Lm = (i[None, :] - i[:, None]) % n + 1
+    P = pkg.Partition.from_matrix(Lm, ctx=gpu_ctx)
+    bd = pkg.blockDiagonalize(P, complex=True, ctx=gpu_ctx, retries=2)
+    assert bd.blkSizes == [1] * n
+    x = np.random.default_rng(3).random(n)
+    A = np.concatenate([[0.0], x])[np.asarray(bd.partition.matrix)]
+    ev = np.array([sum(x[c] * bd.blks[c][k][0, 0] for c in range(n)) for k in range(n)])
+    ref = np.linalg.eigvals(A)
+    assert np.allclose(np.sort_complex(np.round(ev, 8)), np.sort_complex(np.round(ref, 8)), atol=1e-7)

@@ -137,3 +137,17 @@ def test_basis_image_fast_equals_literal(oracle, problems, golden):
     for i in range(P.nparts):
         for k in range(len(Q)):
             assert np.allclose(a[i][k], b[i][k], atol=1e-12)
+
+
+def test_complex_path_pins(oracle):
+    """test/runtests.jl:43-57: blockDiagonalize(P; complex=true).blkSizes == [1,1,1] for the 4 x 4
+    circulant-type partition and for the cyclic group C3 (whose real request must throw
+    InvalidDecompositionField, pinned above)."""
+    P4 = oracle.partition_from_labels(np.array([[1, 2, 3, 2], [2, 1, 2, 3], [3, 2, 1, 2], [2, 3, 2, 1]]))
+    C3 = oracle.partition_from_labels(np.array([[1, 3, 2], [2, 1, 3], [3, 2, 1]]))
+    for P in (P4, C3):
+        for seed in range(3):
+            sizes, blks, Q, Pd = oracle.block_diagonalize_complex(P, rng=np.random.default_rng(seed))
+            assert sizes == [1, 1, 1]
+            full, blk = oracle.spectrum_invariant_complex(Pd, blks, np.random.default_rng(9).random(Pd.nparts))
+            assert len(full) == len(blk) and np.allclose(full, blk, atol=1e-8)
