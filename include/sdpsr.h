@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define SDPSR_VERSION_MAJOR 0
-#define SDPSR_VERSION_MINOR 1
+#define SDPSR_VERSION_MINOR 2
 
 typedef struct sdpsr_ctx sdpsr_ctx;
 
@@ -126,7 +126,10 @@ int sdpsr_partition_from_f64(sdpsr_ctx* ctx, int64_t len, const double* M,
 int sdpsr_partition_from_u32(sdpsr_ctx* ctx, int64_t len, const uint32_t* in,
                              uint32_t* labels, int64_t* nparts, int mem);
 /* refine!(P1, P2), src/partitions.jl:62-66: p1 <- canonical relabel of the pairs
-   (p1, p2); label 0 only where both are 0.  *d1 is updated. */
+   (p1, p2); label 0 only where both are 0.  *d1 is updated.
+   Classes are told apart by a 64-bit mixing hash of the pair (the reference's exact pair code
+   l1 + l2 * (d1 + 1) overflows its label type, src/partitions.jl:63): two distinct pairs collide
+   -- and are merged -- with probability ~ d^2 / 2^65 per call (2e-6 at 8M classes, 3e-17 at 34). */
 int sdpsr_refine(sdpsr_ctx* ctx, int64_t len, uint32_t* p1, int64_t* d1,
                  const uint32_t* p2, int64_t d2, int mem);
 /* Base.:(==)(p::Partition, q::Partition), src/partitions.jl:16-17 (same matrix), as a 128-bit

@@ -143,4 +143,56 @@ function SR.blockDiagonalize(::Type{Float64}, P::HIPPartition, verbose=true;
     return (blkSizes=Int.(sizes), blks=blks)
 end
 
+# ---- diagonalize(Float64, P) (diagonalize.jl:25-40): Q_hat itself ---------------------------
+function SR.diagonalize(::Type{Float64}, P::HIPPartition; verbose=false, atol=1e-12 * size(P, 1))
+    n = size(P, 1); cx = ctx()
+    nb = Ref{Int32}(0); ssq = Ref{Int64}(0); ss = Ref{Int64}(0)
+    st = ccall((:sdpsr_block_diagonalize, libsdpsr), Cint,
+               (Ptr{Cvoid}, Int64, Ptr{UInt32}, Int64, Float64, Ref{Int32}, Ref{Int64}, Ref{Int64}, Ptr{Float64}, Cint),
+               cx.handle, n, P.matrix, P.nparts, atol, nb, ssq, ss, C_NULL, MEM_HOST)
+    st == 3 || check(cx, st)   # check_block_sizes belongs to blockDiagonalize (compat.jl:60), not to diagonalize
+    sizes = Vector{Int32}(undef, nb[])
+    check(cx, ccall((:sdpsr_block_sizes, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{Int32}), cx.handle, sizes))
+    Q = Matrix{Float64}(undef, n, ss[])
+    check(cx, ccall((:sdpsr_q_hat, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), cx.handle, Q, MEM_HOST))
+    offs = cumsum(vcat(0, Int.(sizes)))
+    return [Q[:, offs[k]+1:offs[k+1]] for k in eachindex(sizes)]
+end
+
+# ---- blockDiagonalize(ComplexF64, P) (compat.jl:26-32,54-57; n <= 64 in this library version) ---
+function SR.blockDiagonalize(::Type{ComplexF64}, P::HIPPartition, verbose=true;
+                             epsilon=Base.rtoldefault(Float64))
+    n = size(P, 1); cx = ctx()
+    Pd = Matrix{UInt32}(undef, n, n); dd = Ref{Int64}(0)
+    nb = Ref{Int32}(0); ssq = Ref{Int64}(0); ss = Ref{Int64}(0)
+    check(cx, ccall((:sdpsr_block_diagonalize_complex, libsdpsr), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{UInt32}, Int64, Float64, Ptr{UInt32}, Ref{Int64}, Ref{Int32}, Ref{Int64},
+                     Ref{Int64}, Cint),
+                    cx.handle, n, P.matrix, P.nparts, epsilon, Pd, dd, nb, ssq, ss, MEM_HOST))
+    sizes = Vector{Int32}(undef, nb[])
+    check(cx, ccall((:sdpsr_block_sizes_complex, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{Int32}), cx.handle, sizes))
+    flat = Vector{ComplexF64}(undef, dd[] * ssq[])      # (re, im) pairs = ComplexF64 layout
+    check(cx, ccall((:sdpsr_block_images_complex, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{ComplexF64}, Cint),
+                    cx.handle, flat, C_NULL, MEM_HOST))
+    blks = Vector{Vector{Matrix{ComplexF64}}}(undef, dd[])
+    for i in 1:dd[]
+        off = (i - 1) * ssq[]; blks[i] = Matrix{ComplexF64}[]
+        for s in sizes
+            push!(blks[i], reshape(flat[off+1:off+s*s], Int(s), Int(s))); off += s * s
+        end
+    end
+    return (blkSizes=Int.(sizes), blks=blks)
+end
+
+# ---- test/numerical_issues.jl:85-94 in one call: `count` runs of eigen_decomposition on all CUs ----
+function eigen_decomposition_batched(P::HIPPartition, count::Integer; atol=1e-12 * size(P, 1))
+    n = size(P, 1); cx = ctx()
+    st = Vector{Int32}(undef, count); ne = similar(st); nc = similar(st)
+    check(cx, ccall((:sdpsr_eigen_decomposition_batched, libsdpsr), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{UInt32}, Int64, Float64, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Int32},
+                     Ptr{Int32}, Cint),
+                    cx.handle, n, P.matrix, P.nparts, atol, count, C_NULL, st, ne, nc, MEM_HOST))
+    return (status=st, neig=ne, nclasses=nc)
+end
+
 end # module

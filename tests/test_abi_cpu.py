@@ -12,7 +12,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 25
     for s in names:
         assert hasattr(lib, s), s
-    assert lib.sdpsr_version() == 1
+    assert lib.sdpsr_version() == 2
     assert lib.sdpsr_status_string(3) == b"DIMENSION_MISMATCH"
 
 
