@@ -392,7 +392,7 @@ def main():
                 "algorithmic_ops_per_launch": 4 * flops, "algorithmic_rate_2N3": round(alg_rate, 2),
                 "algorithmic_frac_2N3": round(alg_rate / I8_MFMA_PEAK_TOPS, 4),
                 "algorithmic_bytes_per_launch": 4 * (n * n + 4 * n * n),
-                "rocprof_avg_us": rocprof_average_us("gemm_tn_dma_kernel<0>"),
+                "rocprof_avg_us": rocprof_average_us("gemm_tn_dma_kernel<0,"),
                 "full_square_kernel": {"ms_per_launch": ki8["ms_per_launch"], "achieved": ki8["achieved"], "frac": ki8["frac"]},
                 "algorithmic": "2*N^3 int8 multiply-adds (as ops) per channel and square (SURVEY 8d); one launch = 4 channels (the "
                                "reference does ONE square per iteration: 4 channels are this build's redundancy for 8-bit draws); "

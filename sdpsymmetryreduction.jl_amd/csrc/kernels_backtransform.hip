@@ -75,14 +75,29 @@ bt_larft_kernel(const double* __restrict__ G, const double* __restrict__ tau, in
             const double* gcol = sg + jc * 128;
             if (i < j) {
                 // (T[0:j,0:j] * g)[i] = sum_{k >= i} T[i,k] g[k]  (T upper triangular); two chains
-                double a0 = 0.0, a1 = 0.0;
+                // eight independent LDS load pairs in flight per trip (two waves cannot hide the LDS
+                // latency of a one-load-at-a-time chain), four accumulation chains
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                const double* trow = sT + i * 129;
                 int k = i;
-                for (; k + 1 < j; k += 2) {
-                    a0 = fma(sT[i * 129 + k], gcol[k], a0);
-                    a1 = fma(sT[i * 129 + k + 1], gcol[k + 1], a1);
+                for (; k + 7 < j; k += 8) {
+                    double tv[8], gv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        tv[u] = trow[k + u];
+                        gv[u] = gcol[k + u];
+                    }
+                    a0 = fma(tv[0], gv[0], a0);
+                    a1 = fma(tv[1], gv[1], a1);
+                    a2 = fma(tv[2], gv[2], a2);
+                    a3 = fma(tv[3], gv[3], a3);
+                    a0 = fma(tv[4], gv[4], a0);
+                    a1 = fma(tv[5], gv[5], a1);
+                    a2 = fma(tv[6], gv[6], a2);
+                    a3 = fma(tv[7], gv[7], a3);
                 }
-                if (k < j) a0 = fma(sT[i * 129 + k], gcol[k], a0);
-                sT[i * 129 + j] = -tj * (a0 + a1);  // column j of T is only read by later steps
+                for (; k < j; ++k) a0 = fma(trow[k], gcol[k], a0);
+                sT[i * 129 + j] = -tj * ((a0 + a1) + (a2 + a3));  // column j of T is only read by later steps
             }
             if (i == j) sT[i * 129 + j] = tj;
             // no barrier: thread i reads and writes row i of T only; the shared column of G is read-only
