@@ -528,6 +528,18 @@ typedef double sy_v4d __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void sy_lds_void_t;
 typedef const __attribute__((address_space(1))) void sy_gbl_void_t;
 
+// 16-byte-per-lane global -> LDS DMA through inline asm (see glds16 in kernels_gemm.hip: the
+// builtin makes the compiler drain the VM counter in front of every LDS read, which would void the
+// counted waits below)
+__device__ __forceinline__ void sy_glds16(const void* gsrc, const void* lds_dst_generic) {
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(sy_lds_void_t*)lds_dst_generic);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 __global__ void __launch_bounds__(SY_THREADS)
 sytrd_syr2k_mfma_kernel(SytrdArgs a, int j1, int T0) {
     constexpr int KB = 128;        // bytes of K per row per tile
@@ -563,8 +575,8 @@ sytrd_syr2k_mfma_kernel(SytrdArgs a, int j1, int T0) {
         char* base = smem + buf * 2 * OPB + (wave * 4) * 1024;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            __builtin_amdgcn_global_load_lds((sy_gbl_void_t*)(Ab + srcA[s] + kbA), (sy_lds_void_t*)(base + s * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((sy_gbl_void_t*)(Bb + srcA[s] + kbB), (sy_lds_void_t*)(base + OPB + s * 1024), 16, 0, 0);
+            sy_glds16(Ab + srcA[s] + kbA, base + s * 1024);
+            sy_glds16(Bb + srcA[s] + kbB, base + OPB + s * 1024);
         }
     };
     constexpr int nk = ROWB / KB;  // 4
