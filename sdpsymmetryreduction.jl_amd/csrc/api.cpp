@@ -1446,8 +1446,15 @@ int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen*
 int gemm_tn_splitk(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
                    int64_t ldb, double* C, int64_t ldc) {
     const int64_t tiles = (m / 128) * (n / 128);
+    // K is split over Z workgroups per output tile: the largest divisor of the K-tile count that keeps
+    // >= 128 of K per workgroup and the launch within ~one workgroup per CU (any divisor, not only
+    // powers of two: ld = 4224 = 33 * 128 at N = 4104 has 264 = 8 * 33 K-tiles)
     int Z = 1;
-    while (tiles * Z < 256 && (k / (2 * Z)) >= 128 && (k % (2 * Z * 16)) == 0) Z *= 2;
+    {
+        const int64_t kt = k / 16;
+        for (int64_t z = 1; z <= kt && tiles * z <= 256; ++z)
+            if (kt % z == 0 && k / z >= 128) Z = (int)z;
+    }
     if (Z == 1 || ldc != m) {
         launch_gemm_tn_f64(c->stream, m, n, k, A, lda, B, ldb, C, ldc, 1, 0, 0, 0);
         return SDPSR_OK;
