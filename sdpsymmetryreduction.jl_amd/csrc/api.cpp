@@ -248,8 +248,24 @@ struct PhaseTimer {
 // ---- canonical refinement of a signature array --------------------------------
 // sym_n > 0: the new labels (an sym_n x sym_n matrix) are also checked for symmetry on the device
 // and the verdict rides back with the counters (same synchronisation): *sym_out = 1 if symmetric.
-int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* labels,
+// src: where the signatures come from (sdpsr_internal.h: SigSource).  A computed source is
+// evaluated inside the insert kernel; it is written out as an array (src.sig: len entries of
+// scratch) only for the sort path or when the insert kernel has no instance for it.
+int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32_t* labels,
                       int64_t* nparts, int64_t sym_n = 0, uint32_t* symflag_dev = nullptr, int* sym_out = nullptr) {
+    SigSource src = src_in;
+    auto materialize = [&]() -> bool {
+        if (src.kind == SIG_ARRAY) return true;
+        if (!src.sig) return false;
+        launch_sig_materialize(c->stream, len, src, src.sig);
+        src.kind = SIG_ARRAY;
+        return true;
+    };
+    static const bool no_fuse = getenv("SDPSR_REFINE_NO_FUSE") != nullptr;  // diagnostic: always through the array
+    if ((no_fuse || !sig_source_fusable(src)) && !materialize())
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "refine: signature source needs scratch");
+    uint32_t* slot = (uint32_t*)ctx_buf(c, "ref_slots", (size_t)len * 4);
+    if (!slot) return SDPSR_OUT_OF_MEMORY;
     const int full = std::max(12, ceil_log2((uint64_t)len * 2));
     int log2cap = std::min(full, std::max(12, c->table_log2_hint));
     const int64_t rb = (int64_t)refine_block_entries();
@@ -269,7 +285,8 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
             uint32_t* counters = (uint32_t*)ctx_buf(c, "ref_counters", refine_counters_bytes());
             uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
             if (!wsp || !counters || !h) return SDPSR_OUT_OF_MEMORY;
-            if (!launch_refine_sorted(c->stream, len, sig, labels, wsp, wsb, counters))
+            if (!materialize()) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "refine: signature source needs scratch");
+            if (!launch_refine_sorted(c->stream, len, src.sig, labels, wsp, wsb, counters))
                 return ctx_fail(c, SDPSR_HIP_ERROR, "sort-based refinement failed");
             HIP_TRY(c, hipMemcpyAsync(h, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             if (sym_n > 0 && symflag_dev) {
@@ -295,7 +312,7 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
         ws.log2cap = log2cap;
         ws.nblk = (int)nblk;
         ws.expect_small = (!mispredicted && c->table_log2_hint <= 12) ? 1 : 0;  // hint 12 <=> last dim <= 512
-        launch_refine(c->stream, len, sig, labels, ws);
+        launch_refine(c->stream, len, src, slot, labels, ws);
         uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
         if (!h) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
         HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -326,6 +343,14 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
         c->table_log2_hint = std::min(full, std::max(12, ceil_log2((uint64_t)h[2] * 8 + 1)));
         return SDPSR_OK;
     }
+}
+
+int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* labels,
+                      int64_t* nparts, int64_t sym_n = 0, uint32_t* symflag_dev = nullptr, int* sym_out = nullptr) {
+    SigSource src;
+    src.kind = SIG_ARRAY;
+    src.sig = const_cast<uint64_t*>(sig);
+    return refine_signatures(c, len, src, labels, nparts, sym_n, symflag_dev, sym_out);
 }
 
 int check_len(sdpsr_ctx* c, int64_t len) {
@@ -733,8 +758,14 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     // S = Part(CL); S = refine!(S, Part(X0L))   (:145-146)
     int64_t d = 0;
     tm.begin(SDPSR_T_REFINE);
-    launch_sig_f64_pair(s, len, dCL, dX0, sig);  // both refinements in one canonical relabel
-    st = refine_signatures(c, len, sig, L, &d);
+    {  // both refinements in one canonical relabel; the pair signature is computed inside the insert pass
+        SigSource q;
+        q.kind = SIG_PAIR;
+        q.sig = sig;
+        q.a = dCL;
+        q.b = dX0;
+        st = refine_signatures(c, len, q, L, &d);
+    }
     tm.end();
     if (st) return st;
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -752,12 +783,25 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         tm.begin(SDPSR_T_PROJECT);
         const uint64_t key = next_key(c);
         launch_proj_coef(s, len, r, dU, L, key, nullptr, partial, nblk, coef);
-        launch_proj_apply(s, len, r, dU, L, key, nullptr, coef, atol, scale, 1, Y, sig);
+        const bool int_mode = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
+        SigSource qp;  // integer modes: y = round(x - U coef) exists only inside the insert pass of the refinement
+        qp.sig = sig;
+        if (Y) {
+            launch_proj_apply(s, len, r, dU, L, key, nullptr, coef, atol, scale, 1, Y, sig);
+        } else {
+            qp.kind = SIG_PROJ;
+            qp.U = dU;
+            qp.coef = coef;
+            qp.L = L;
+            qp.r = (int)r;
+            qp.key = key;
+            qp.atol = atol;
+            qp.scale = scale;
+        }
         tm.end();
         tm.begin(SDPSR_T_REFINE);
         int64_t d1 = 0;
-        const bool int_mode = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
-        st = refine_signatures(c, len, sig, L, &d1, int_mode ? n : 0, symflag, &labels_sym);
+        st = refine_signatures(c, len, qp, L, &d1, int_mode ? n : 0, symflag, &labels_sym);
         tm.end();
         if (st) return st;
         // --- random square (:166-174) ---
@@ -774,6 +818,17 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             // the K-contiguous left operand gathered from the transposed labels (same draw).
             const uint32_t* lower = labels_sym ? zero_flag : nullptr;
             const uint32_t* Lleft = L;
+            // signatures of the squares: computed inside the insert pass of the refinement (integer
+            // modes), an array for the fp64 mode
+            SigSource qs;
+            qs.sig = sig;
+            qs.L = L;
+            qs.n = n;
+            qs.ld = ld;
+            qs.T = T;
+            qs.C = Cp;
+            qs.packed = labels_sym;
+            qs.zero_flag = lower;
             if (int_mode && !labels_sym) {
                 uint32_t* Lt = (uint32_t*)ctx_buf(c, "des_lt", len * 4);
                 if (!Lt) return SDPSR_OUT_OF_MEMORY;
@@ -791,7 +846,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
                 } else {
                     launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, lower);
                 }
-                launch_sig_i32(s, n, ld, T, L, (const int32_t*)Cp, sig, lower, labels_sym);
+                qs.kind = SIG_CHAN_I32;
             } else if (mode == SDPSR_SQUARE_F32) {
                 launch_gather_f32(s, n, ld, T, vmax, L, key2, (float*)Xp);
                 if (!labels_sym) {
@@ -802,7 +857,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
                 } else {
                     launch_gemm_tn_f32_sym(s, ld, ld, (const float*)Xp, ld, (float*)Cp, ld, T, ld * ld, ld * ld, lower);
                 }
-                launch_sig_f32(s, n, ld, T, L, (const float*)Cp, sig, lower, labels_sym);
+                qs.kind = SIG_CHAN_F32;
             } else {
                 // reference-literal: the projected element is squared when the projection
                 // step did not refine S (X is overwritten in place at :160-163), a fresh
@@ -824,10 +879,10 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
                 const int64_t lenp = n * (n + 1) / 2;
                 uint32_t* Lp = (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4);
                 if (!Lp) return SDPSR_OUT_OF_MEMORY;
-                st = refine_signatures(c, lenp, sig, Lp, &d2);
+                st = refine_signatures(c, lenp, qs, Lp, &d2);
                 if (!st) launch_unpack_symmetric_labels(s, n, Lp, L);
             } else {
-                st = refine_signatures(c, len, sig, L, &d2);
+                st = refine_signatures(c, len, qs, L, &d2);
             }
             tm.end();
             if (st) return st;
@@ -2497,6 +2552,11 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
     ms_per_launch[0] = (double)ms / reps;
+    if (kind == 8 && aux == 1) {  // diagnostic: sweeps of the last run instead of the time
+        int h[2] = {0, 0};
+        HIP_TRY(c, hipMemcpy(h, ctx_buf(c, "eig_info", 64), 8, hipMemcpyDeviceToHost));
+        ms_per_launch[0] = (double)h[1];
+    }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     return SDPSR_OK;

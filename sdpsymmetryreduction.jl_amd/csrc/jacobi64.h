@@ -155,4 +155,99 @@ __device__ __forceinline__ int jacobi64_sweeps(int n, int m, int ldl, double* __
     return sweep;
 }
 
+// pair kk of round `step` of the round-robin tournament (the same schedule as jacobi64_fill_pairs,
+// from registers: no table load in front of the matrix reads)
+__device__ __forceinline__ void jacobi64_pair(int m1, int step, int kk, int& p, int& q) {
+    int a = step + kk, b = step - kk;
+    if (a >= m1) a -= m1;
+    if (b < 0) b += m1;
+    if (kk == 0) b = m1;
+    p = a < b ? a : b;
+    q = a < b ? b : a;
+}
+
+// Ping-pong variant of jacobi64_sweeps: a tournament step reads (cA, cV) and writes (aA, aV) --
+// every entry of A and of V belongs to exactly one thread per step -- so a step costs ONE barrier
+// instead of two, and nothing but register arithmetic sits in front of its LDS reads.  sA2/sV2:
+// two more m x m buffers (contents irrelevant); s_red: 2 * blockDim/64 doubles.  Results land in sA / sV like jacobi64_sweeps.
+__device__ __forceinline__ int jacobi64_sweeps_pp(int n, int m, int ldl, double* sA, double* sV, double* sA2, double* sV2,
+                                                  double* s_red) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int half = m >> 1, nw = nthr >> 6, m1 = m - 1;
+    const bool active = tid < half * half;
+    const int k1 = active ? tid / half : 0, k2 = active ? tid - k1 * half : 0;
+    const int i0 = 2 * k2;  // rows of V this thread rotates (columns of pair k1)
+    double *cA = sA, *cV = sV, *aA = sA2, *aV = sV2;
+    int sweep = 0;
+    for (; sweep < 40; ++sweep) {
+        double off = 0, dg = 0;
+        for (int e = tid; e < m * m; e += nthr) {
+            const int j = e / m, i = e - j * m;
+            const double v = cA[i + j * ldl];
+            if (i == j) dg = fma(v, v, dg);
+            else off = fma(v, v, off);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            off += __shfl_down(off, o, 64);
+            dg += __shfl_down(dg, o, 64);
+        }
+        if ((tid & 63) == 0) {
+            s_red[tid >> 6] = off;
+            s_red[nw + (tid >> 6)] = dg;
+        }
+        __syncthreads();
+        double s_off = 0, s_diag = 0;
+        for (int k = 0; k < nw; ++k) {
+            s_off += s_red[k];
+            s_diag += s_red[nw + k];
+        }
+        __syncthreads();  // s_red is free again
+        const double tolr = (double)n * 2.220446049250313e-16;
+        if (s_off <= tolr * tolr * (s_diag + s_off) || s_off == 0.0) break;
+        for (int step = 0; step < m1; ++step) {
+            if (active) {
+                int r0, r1, c0, c1;
+                jacobi64_pair(m1, step, k1, r0, r1);
+                jacobi64_pair(m1, step, k2, c0, c1);
+                const int a00 = r0 + c0 * ldl, a01 = r0 + c1 * ldl, a10 = r1 + c0 * ldl, a11 = r1 + c1 * ldl;
+                const int v0a = i0 + r0 * ldl, v0b = i0 + r1 * ldl;
+                const double app = cA[r0 + r0 * ldl], aqq = cA[r1 + r1 * ldl], apq = cA[r0 + r1 * ldl];
+                const double bpp = cA[c0 + c0 * ldl], bqq = cA[c1 + c1 * ldl], bpq = cA[c0 + c1 * ldl];
+                const double x00 = cA[a00], x01 = cA[a01], x10 = cA[a10], x11 = cA[a11];
+                const double va0 = cV[v0a], vb0 = cV[v0b], va1 = cV[v0a + 1], vb1 = cV[v0b + 1];
+                double cr, sr, cc, sc;
+                jacobi_angle(app, aqq, apq, cr, sr);
+                jacobi_angle(bpp, bqq, bpq, cc, sc);
+                const double y00 = cr * x00 - sr * x10, y10 = sr * x00 + cr * x10;
+                const double y01 = cr * x01 - sr * x11, y11 = sr * x01 + cr * x11;
+                aA[a00] = cc * y00 - sc * y01;
+                aA[a01] = sc * y00 + cc * y01;
+                aA[a10] = cc * y10 - sc * y11;
+                aA[a11] = sc * y10 + cc * y11;
+                aV[v0a] = cr * va0 - sr * vb0;
+                aV[v0b] = sr * va0 + cr * vb0;
+                aV[v0a + 1] = cr * va1 - sr * vb1;
+                aV[v0b + 1] = sr * va1 + cr * vb1;
+            }
+            __syncthreads();
+            double* t = cA;
+            cA = aA;
+            aA = t;
+            t = cV;
+            cV = aV;
+            aV = t;
+        }
+    }
+    if (cA != sA) {  // uniform
+        for (int e = tid; e < m * m; e += nthr) {
+            const int j = e / m, i = e - j * m;
+            sA[i + j * ldl] = cA[i + j * ldl];
+            sV[i + j * ldl] = cV[i + j * ldl];
+        }
+    }
+    __syncthreads();
+    return sweep;
+}
+
 }  // namespace sdpsr

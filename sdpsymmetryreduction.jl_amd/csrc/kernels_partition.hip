@@ -473,6 +473,91 @@ void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t*
 }
 
 // ---------------------------------------------------------------------------
+// Signature sources of the insert pass: the refinement either reads a signature array or computes
+// each signature from the data the matching sig_* / proj_apply kernel would have read -- the same
+// device functions, so the same bits -- and the 8 bytes per entry never travel through HBM.
+// ---------------------------------------------------------------------------
+struct SrcArray {
+    const uint64_t* __restrict__ sig;
+    __device__ __forceinline__ uint64_t operator()(int64_t e) const { return __builtin_nontemporal_load(&sig[e]); }
+};
+struct SrcPair {  // sig_f64_pair_kernel
+    const double* __restrict__ a;
+    const double* __restrict__ b;
+    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        const uint64_t ka = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(&a[e]));
+        const uint64_t kb = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(&b[e]));
+        const uint64_t h = sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb);
+        return finish_sig(0u, ka == 0 && kb == 0, h);
+    }
+};
+template <int R>
+struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig only
+    const double* __restrict__ U;
+    const uint32_t* L;  // may alias the label output of the refinement (read before the entry's own write)
+    const double* __restrict__ coef;
+    int64_t len;
+    uint64_t key;
+    double atol, scale;
+    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        const uint32_t l = L[e];
+        double u[R > 0 ? R : 1];
+#pragma unroll
+        for (int k = 0; k < R; ++k) u[k] = __builtin_nontemporal_load(&U[(int64_t)k * len + e]);
+        const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) p = fma(u[k], coef[k], p);
+        const double y = sdpsr_clamp_round(x - p, atol, scale);
+        const uint64_t kb = (uint64_t)__double_as_longlong(y);
+        uint64_t h = 0;
+        if (l != 0 || kb != 0) {
+            h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
+            if (h == 0) h = 1;
+        }
+        return h;
+    }
+};
+template <typename CT, int T>
+struct SrcChan {  // sig_channels_kernel; packed: e runs over the lower triangle column by column
+    int n;
+    int64_t ld;
+    const uint32_t* L;
+    const CT* __restrict__ C;
+    int packed;
+    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        uint32_t i, j;
+        if (packed) {
+            // column j starts at off(j) = j n - j (j - 1) / 2
+            const float t = (float)(2 * n + 1);
+            int jj = (int)((t - sqrtf(fmaxf(t * t - 8.0f * (float)e, 0.0f))) * 0.5f);
+            jj = jj < 0 ? 0 : (jj > n - 1 ? n - 1 : jj);
+            while ((int64_t)jj * n - (int64_t)jj * (jj - 1) / 2 > e) --jj;
+            while (jj + 1 < n && (int64_t)(jj + 1) * n - (int64_t)(jj + 1) * jj / 2 <= e) ++jj;
+            j = (uint32_t)jj;
+            i = j + (uint32_t)(e - ((int64_t)jj * n - (int64_t)jj * (jj - 1) / 2));
+        } else {
+            j = (uint32_t)e / (uint32_t)n;
+            i = (uint32_t)e - j * (uint32_t)n;
+        }
+        const uint32_t l = L[(int64_t)j * n + i];
+        const CT* Cij = C + (int64_t)j * ld + i;
+        int32_t c[T + (T & 1)];
+#pragma unroll
+        for (int t = 0; t < T; ++t) c[t] = (int32_t)__builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
+        if (T & 1) c[T] = 0;
+        uint64_t h = sdpsr_sig_start(l);
+        bool allz = true;
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+            allz = allz && (c[t] == 0) && (c[t + 1] == 0);
+            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[t] | ((uint64_t)(uint32_t)c[t + 1] << 32));
+        }
+        return finish_sig(l, allz, h);
+    }
+};
+
+// ---------------------------------------------------------------------------
 // Canonical refinement of 64-bit signatures.
 //
 //   pass A  every block dedups its REFINE_BLOCK entries in an LDS hash table (sig -> min
@@ -528,14 +613,17 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned 
 // One workgroup dedups INSERT_CHUNK entries in an LDS table before touching the global one.
 // An entry whose LDS probe sequence gets long (many distinct signatures in the chunk) goes to
 // the global table directly instead.
-constexpr int INSERT_PER_THREAD = 16;
-constexpr int INSERT_CHUNK = REFINE_THREADS * INSERT_PER_THREAD;  // 4096 entries
 constexpr int LDS_MAX_PROBES = 24;
 
+// SRC: where the signatures come from (see the Src* functors); INSERT_PER_THREAD entries per
+// thread and chunk (16 for the plain array, 8 for the computed sources: their loads and hashes
+// of one chunk are all live before the first probe)
+template <class SRC, int INSERT_PER_THREAD>
 __global__ void __launch_bounds__(REFINE_THREADS)
-refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
+refine_insert_kernel(int64_t len, const SRC src,
                      uint32_t* __restrict__ slot_out, unsigned long long* __restrict__ tab_sig,
                      uint32_t* __restrict__ tab_min, uint32_t mask, uint32_t* counters) {
+    constexpr int INSERT_CHUNK = REFINE_THREADS * INSERT_PER_THREAD;
     // The LDS table lives across the chunks of a workgroup: a signature is published to the
     // global table only the first time the workgroup meets it (its chunks come in increasing
     // index order, so that chunk also holds the workgroup's smallest index of the class); later
@@ -566,7 +654,7 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
             for (int q = 0; q < INSERT_PER_THREAD; ++q) {
                 const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
                 if (e < len) {
-                    const uint64_t sg = __builtin_nontemporal_load(&sig[e]);
+                    const uint64_t sg = src(e);
                     uint32_t out = NO_SLOT;
                     if (sg) {
                         out = global_find_or_insert(sg, tab_sig, mask, counters);
@@ -585,7 +673,7 @@ refine_insert_kernel(int64_t len, const uint64_t* __restrict__ sig,
 #pragma unroll
         for (int q = 0; q < INSERT_PER_THREAD; ++q) {
             const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-            sgs[q] = (e < len) ? __builtin_nontemporal_load(&sig[e]) : 0ull;
+            sgs[q] = (e < len) ? src(e) : 0ull;
         }
 #pragma unroll
         for (int q = 0; q < INSERT_PER_THREAD; ++q) {
@@ -807,29 +895,90 @@ __global__ void refine_clear_kernel(int64_t cap, unsigned long long* __restrict_
     if (t0 < LIST_OFF) counters[t0] = 0u;
 }
 
-__global__ void refine_label_kernel(int64_t len, uint32_t* __restrict__ slot_inout,
-                                    const uint32_t* __restrict__ tab_lab) {
+// A pass the host is going to repeat (table overflow, or more classes than the one-workgroup
+// ranking was launched for) must leave labels_out alone: a computed signature source may read the
+// old labels from that very array.
+__global__ void refine_label_kernel(int64_t len, const uint32_t* __restrict__ slot, uint32_t* labels_out,
+                                    const uint32_t* __restrict__ tab_lab, const uint32_t* __restrict__ counters,
+                                    int expect_small) {
+    if (counters[1] || (expect_small && counters[0] > SMALL_K)) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
-        uint32_t sl = slot_inout[e];
-        slot_inout[e] = (sl == NO_SLOT) ? 0u : tab_lab[sl];
+        const uint32_t sl = __builtin_nontemporal_load(&slot[e]);
+        labels_out[e] = (sl == NO_SLOT) ? 0u : tab_lab[sl];
     }
 }
 
-void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out,
+template <class SRC, int PER>
+static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SRC& src, uint32_t* slot, const RefineWs& ws,
+                          size_t cap) {
+    const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
+    const int g = (int)(nchunk < g_chunks_cap ? nchunk : g_chunks_cap);
+    refine_insert_kernel<SRC, PER><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
+                                                                (uint32_t)(cap - 1), ws.counters);
+}
+
+template <typename CT>
+static bool launch_insert_chan(hipStream_t s, int gcap, int64_t len, const SigSource& q, uint32_t* slot, const RefineWs& ws,
+                               size_t cap) {
+    const CT* C = (const CT*)q.C;
+    switch (q.T) {
+        case 1: launch_insert<SrcChan<CT, 1>, 8>(s, gcap, len, SrcChan<CT, 1>{(int)q.n, q.ld, q.L, C, q.packed}, slot, ws, cap); return true;
+        case 2: launch_insert<SrcChan<CT, 2>, 8>(s, gcap, len, SrcChan<CT, 2>{(int)q.n, q.ld, q.L, C, q.packed}, slot, ws, cap); return true;
+        case 4: launch_insert<SrcChan<CT, 4>, 8>(s, gcap, len, SrcChan<CT, 4>{(int)q.n, q.ld, q.L, C, q.packed}, slot, ws, cap); return true;
+        case 8: launch_insert<SrcChan<CT, 8>, 4>(s, gcap, len, SrcChan<CT, 8>{(int)q.n, q.ld, q.L, C, q.packed}, slot, ws, cap); return true;
+        default: return false;
+    }
+}
+
+bool sig_source_fusable(const SigSource& q) {
+    switch (q.kind) {
+        case SIG_ARRAY: return true;
+        case SIG_PAIR: return true;
+        case SIG_PROJ: return q.r >= 0 && q.r <= 4;
+        case SIG_CHAN_I32:
+        case SIG_CHAN_F32: return q.T == 1 || q.T == 2 || q.T == 4 || q.T == 8;
+        default: return false;
+    }
+}
+
+// the signature array of a computed source (sort path, or a source the insert kernel has no
+// instance for): the stand-alone kernels
+void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint64_t* sig) {
+    switch (q.kind) {
+        case SIG_PAIR: launch_sig_f64_pair(s, len, q.a, q.b, sig); break;
+        case SIG_PROJ: launch_proj_apply(s, len, q.r, q.U, q.L, q.key, nullptr, q.coef, q.atol, q.scale, 1, nullptr, sig); break;
+        case SIG_CHAN_I32: launch_sig_i32(s, q.n, q.ld, q.T, q.L, (const int32_t*)q.C, sig, q.zero_flag, q.packed); break;
+        case SIG_CHAN_F32: launch_sig_f32(s, q.n, q.ld, q.T, q.L, (const float*)q.C, sig, q.zero_flag, q.packed); break;
+        default: break;
+    }
+}
+
+void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slot, uint32_t* labels_out,
                    const RefineWs& ws) {
     const size_t cap = (size_t)1 << ws.log2cap;
     refine_clear_kernel<<<grid_for((int64_t)cap, 256), 256, 0, s>>>((int64_t)cap, (unsigned long long*)ws.tab_sig,
                                                                    ws.tab_min, ws.counters);
     const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
-    const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
     // 116 VGPRs + 32 KiB of LDS: four workgroups are resident per CU; with few classes (LDS-level
     // work) launch exactly one round of resident workgroups -- a fifth per CU would run alone
     const int per_cu = (ws.log2cap <= 16) ? 4 : 5;  // many classes: bound by the global table, a few more workgroups help
-    const int g = (int)(nchunk < 256 * per_cu ? nchunk : 256 * per_cu);
-    refine_insert_kernel<<<g, REFINE_THREADS, 0, s>>>(len, sig, labels_out,
-                                                      (unsigned long long*)ws.tab_sig, ws.tab_min,
-                                                      (uint32_t)(cap - 1), ws.counters);
+    const int gcap = 256 * per_cu;
+    switch (q.kind) {
+        case SIG_PAIR: launch_insert<SrcPair, 8>(s, gcap, len, SrcPair{q.a, q.b}, slot, ws, cap); break;
+        case SIG_PROJ:
+            switch (q.r) {
+                case 0: launch_insert<SrcProj<0>, 8>(s, gcap, len, SrcProj<0>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
+                case 1: launch_insert<SrcProj<1>, 8>(s, gcap, len, SrcProj<1>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
+                case 2: launch_insert<SrcProj<2>, 8>(s, gcap, len, SrcProj<2>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
+                case 3: launch_insert<SrcProj<3>, 8>(s, gcap, len, SrcProj<3>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
+                default: launch_insert<SrcProj<4>, 8>(s, gcap, len, SrcProj<4>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
+            }
+            break;
+        case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;
+        case SIG_CHAN_F32: launch_insert_chan<float>(s, gcap, len, q, slot, ws, cap); break;
+        default: launch_insert<SrcArray, 16>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap); break;
+    }
     const int g2 = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
     // ws.expect_small: the host predicts <= SMALL_K classes (from the previous refinement) and
     // launches the one-workgroup ranking only; it checks counters[0] afterwards and repeats the
@@ -837,12 +986,12 @@ void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* la
     // anyway, but three empty launches cost ~15 us of a ~150 us refinement)
     refine_small_rank_kernel<<<1, 1024, 0, s>>>(ws.tab_min, ws.tab_lab, ws.counters);
     if (!ws.expect_small) {
-        refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt, ws.counters);
+        refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt, ws.counters);
         refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
-        refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, labels_out, ws.tab_min, ws.blk_cnt,
+        refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt,
                                                          ws.tab_lab, ws.counters);
     }
-    refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, labels_out, ws.tab_lab);
+    refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small);
 }
 
 // ---------------------------------------------------------------------------

@@ -18,7 +18,7 @@
 //                         (beta, tau, scale) from the partial norms and computes its share of
 //                         p = A v, W'v, V'v and v'p  (v is never materialised: v_r = a_rj * scale);
 //    a kernel boundary (~1.5 us) is the cheapest chip-wide synchronisation on this part, cheaper
-//    than any in-kernel grid barrier (4-5 us), so the launches are captured into a hipGraph once
+//    than any in-kernel grid barrier (4-5 us), so the launches are built into a hipGraph once
 //    per shape and replayed;
 //  * the panel [V | W] is kept row-major (64 doubles per row), which is at once the coalesced
 //    layout for the per-row corrections and the K-contiguous operand layout of the MFMA kernel;
@@ -693,46 +693,116 @@ void sytrd_set_device_attributes() {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
-static void launch_symv(hipStream_t s, const SytrdArgs& a, int j, int cf, int n_norm, const SymvGeom& g) {
-    sytrd_symv_kernel<<<(unsigned)g.grid, SY_THREADS, 0, s>>>(a, j, cf, n_norm, g.S0, g.SEG, g.nstr, g.maxseg, g.G);
+// The launch sequence of a tridiagonalisation goes either to a stream or, node by node, into a
+// hipGraph built with the explicit node API.  No stream capture: while ANY stream of the process
+// is capturing, legacy-stream operations of OTHER threads fail with hipErrorStreamCaptureImplicit
+// on this runtime (seen: hipBLASLt's initialisation and rocSOLVER's stedc in a second ctx's thread
+// failing or silently returning wrong eigenvalues while this thread captured).
+struct SytrdEmitter {
+    hipStream_t s = nullptr;
+    hipGraph_t graph = nullptr;  // non-null: add nodes (a linear chain) instead of launching
+    hipGraphNode_t last = nullptr;
+    bool ok = true;
+
+    template <typename... Args>
+    void kernel(const void* fn, unsigned grid, unsigned block, size_t shmem, Args... args) {
+        void* argv[] = {(void*)&args...};
+        if (!graph) {
+            if (hipLaunchKernel(fn, dim3(grid), dim3(block), argv, shmem, s) != hipSuccess) ok = false;
+            return;
+        }
+        hipKernelNodeParams p{};
+        p.func = const_cast<void*>(fn);
+        p.gridDim = dim3(grid);
+        p.blockDim = dim3(block);
+        p.sharedMemBytes = (unsigned)shmem;
+        p.kernelParams = argv;  // copied by the call
+        p.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        if (hipGraphAddKernelNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &p) != hipSuccess) ok = false;
+        else last = node;
+    }
+    void zero(void* dst, size_t bytes) {  // bytes % 4 == 0
+        if (!graph) {
+            if (hipMemsetAsync(dst, 0, bytes, s) != hipSuccess) ok = false;
+            return;
+        }
+        hipMemsetParams m{};
+        m.dst = dst;
+        m.elementSize = 4;
+        m.width = bytes / 4;
+        m.height = 1;
+        m.pitch = bytes;
+        m.value = 0;
+        hipGraphNode_t node = nullptr;
+        if (hipGraphAddMemsetNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &m) != hipSuccess) ok = false;
+        else last = node;
+    }
+    void copy8(void* dst, const void* src) {
+        if (!graph) {
+            if (hipMemcpyAsync(dst, src, 8, hipMemcpyDeviceToDevice, s) != hipSuccess) ok = false;
+            return;
+        }
+        hipGraphNode_t node = nullptr;
+        if (hipGraphAddMemcpyNode1D(&node, graph, last ? &last : nullptr, last ? 1 : 0, dst, src, 8, hipMemcpyDeviceToDevice) != hipSuccess)
+            ok = false;
+        else last = node;
+    }
+};
+
+static void emit_symv(SytrdEmitter& em, const SytrdArgs& a, int j, int cf, int n_norm, const SymvGeom& g) {
+    em.kernel(reinterpret_cast<const void*>(&sytrd_symv_kernel), (unsigned)g.grid, SY_THREADS, 0, a, j, cf, n_norm, g.S0, g.SEG,
+              g.nstr, g.maxseg, g.G);
+}
+static void emit_form(SytrdEmitter& em, unsigned grid, const SytrdArgs& a, int j, int cf, int do_finish, int do_form, int n_vav,
+                      int S0, int SEG, int G) {
+    em.kernel(reinterpret_cast<const void*>(&sytrd_form_kernel), grid, SY_THREADS, 0, a, j, cf, do_finish, do_form, n_vav, S0, SEG, G);
 }
 
-static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
-                                double* ws) {
+static bool emit_sytrd(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
     const int n = (int)n64;
     SytrdArgs a = sytrd_args(n64, A, ld, d, e, tau, ws);
-    hipMemsetAsync(ws, 0, sytrd_workspace_doubles(n, ld) * sizeof(double), s);
+    em.zero(ws, sytrd_workspace_doubles(n, ld) * sizeof(double));
     if (n == 1) {
-        hipMemcpyAsync(d, A, sizeof(double), hipMemcpyDeviceToDevice, s);
-        return;
+        em.copy8(d, A);
+        return em.ok;
     }
     int cf = 0;  // panel column of the column currently being formed
     // column 0: plain form (no panel yet)
-    sytrd_form_kernel<<<(n + SY_FROWS - 1) / SY_FROWS, SY_THREADS, 0, s>>>(a, 0, 0, 0, 1, 0, 0, 1, 0);
+    emit_form(em, (unsigned)((n + SY_FROWS - 1) / SY_FROWS), a, 0, 0, 0, 1, 0, 0, 1, 0);
     for (int j = 0; j <= n - 2; ++j) {
         // reflector of column j + symmetric product
         const int n_norm = (n - j + SY_FROWS - 1) / SY_FROWS;
         const SymvGeom g = symv_geometry(n, j, cf);
-        launch_symv(s, a, j, cf, n_norm, g);
+        emit_symv(em, a, j, cf, n_norm, g);
         const int n_vav = g.grid;
         const int jn = j + 1;
-        const int nb_form = (n - jn + SY_FROWS - 1) / SY_FROWS;
+        const unsigned nb_form = (unsigned)((n - jn + SY_FROWS - 1) / SY_FROWS);
         if (cf + 1 < SY_NB && jn <= n - 1) {
             // finish W(:, cf) and form column j+1 inside the same panel
-            sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, cf, 1, 1, n_vav, g.S0, g.SEG, g.G);
+            emit_form(em, nb_form, a, jn, cf, 1, 1, n_vav, g.S0, g.SEG, g.G);
             ++cf;
         } else {
             // panel complete: finish W, update the trailing matrix, start a new panel
-            sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, cf, 1, 0, n_vav, g.S0, g.SEG, g.G);
+            emit_form(em, nb_form, a, jn, cf, 1, 0, n_vav, g.S0, g.SEG, g.G);
             if (n - jn > 0 && cf + 1 == SY_NB) {
                 const int T0 = jn / 128;
                 const int nt = (n + 127) / 128 - T0;
-                sytrd_syr2k_mfma_kernel<<<nt * (nt + 1) / 2, SY_THREADS, 128 * 1024, s>>>(a, jn, T0);
+                em.kernel(reinterpret_cast<const void*>(&sytrd_syr2k_mfma_kernel), (unsigned)(nt * (nt + 1) / 2), SY_THREADS,
+                          128 * 1024, a, jn, T0);
             }
-            if (n - jn > 0) sytrd_form_kernel<<<nb_form, SY_THREADS, 0, s>>>(a, jn, 0, 0, 1, 0, 0, 1, 0);
+            if (n - jn > 0) emit_form(em, nb_form, a, jn, 0, 0, 1, 0, 0, 1, 0);
             cf = 0;
         }
     }
+    return em.ok;
+}
+
+static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
+                                double* ws) {
+    SytrdEmitter em;
+    em.s = s;
+    emit_sytrd(em, n64, A, ld, d, e, tau, ws);
 }
 
 // measurement hook: only the symv launches of a full tridiagonalisation (same grid shapes and
@@ -745,13 +815,15 @@ void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, 
     for (int j = 0; j <= n - 2; ++j) {
         const int cf = j % SY_NB;
         const int n_norm = (n - j + SY_FROWS - 1) / SY_FROWS;
-        launch_symv(s, a, j, cf, n_norm, symv_geometry(n, j, cf));
+        SytrdEmitter em;
+        em.s = s;
+        emit_symv(em, a, j, cf, n_norm, symv_geometry(n, j, cf));
     }
 }
 
 // Most of the ~2n + n/32 launches of the tridiagonalisation are shorter than the cost of
 // launching them from the host (2-4 us of kernel against 3-5 us of launch): the launch sequence of
-// one problem shape is captured once into a hipGraph and replayed.  Key = every value baked into
+// one problem shape is built once as a hipGraph (explicit nodes, see SytrdEmitter) and replayed.  Key = every value baked into
 // the nodes (order, leading dimension, all pointers); the ctx's buffers are grow-only, so the key
 // is stable across calls.  A few graphs are kept (generic elements alternate between two or
 // three buffers).
@@ -799,14 +871,15 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
         if (victim->exec) hipGraphExecDestroy(victim->exec);
         victim->exec = nullptr;
         hipGraph_t graph = nullptr;
-        bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        bool ok = hipGraphCreate(&graph, 0) == hipSuccess && graph;
         if (ok) {
-            launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
-            ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph;
+            SytrdEmitter em;
+            em.graph = graph;
+            ok = emit_sytrd(em, n64, A, ld, d, e, tau, ws);
         }
         if (ok) ok = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0) == hipSuccess;
         if (graph) hipGraphDestroy(graph);
-        if (!ok) {  // capture not possible here (e.g. the stream is already being captured): plain launches
+        if (!ok) {  // graph construction failed: plain launches
             victim->exec = nullptr;
             (void)hipGetLastError();
             launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
@@ -1015,31 +1088,38 @@ small_syev_jacobi_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __
 
 // The matrix is padded to an even order m with a zero row/column (the dummy player of the
 // tournament: a_pq = 0 gives the identity rotation), so the step has no validity branches; the
-// pairs of all m-1 rounds sit in an LDS table.
+// pairs of a round come from register arithmetic and the step ping-pongs between two LDS copies.
 //
 // jacobi64_fill_pairs / jacobi64_sweeps are the workgroup-level core, shared by the single-problem
 // kernel below and by the batched eigen_decomposition kernel (kernels_batched.hip includes this
 // file's declarations through jacobi64.h).
+template <bool PP>
 __global__ void __launch_bounds__(JAC_MAXTHREADS)
 small_syev_jacobi64_kernel(int n, double* __restrict__ Ag, int64_t lda, double* __restrict__ wout,
                            int* __restrict__ info) {
-    extern __shared__ __attribute__((aligned(16))) double sA[];  // A (m x m, ld ldl), V (same), pair table
-    __shared__ double s_red[JAC_MAXTHREADS / 64 + 2];
+    extern __shared__ __attribute__((aligned(16))) double sA[];  // A, V and their ping-pong twins (m x m, ld ldl)
+    __shared__ double s_red[2 * JAC_MAXTHREADS / 64];
     __shared__ int s_rank[64];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int m = (n + 1) & ~1, half = m >> 1;
+    const int m = (n + 1) & ~1;
     const int ldl = m | 1;
-    double* __restrict__ sV = sA + (size_t)ldl * m;
-    int* __restrict__ s_pq = reinterpret_cast<int*>(sV + (size_t)ldl * m);  // [(m-1) * half]: p | q << 16, p < q
+    double* sV = sA + (size_t)ldl * m;
     for (int e = tid; e < m * m; e += nthr) {
         const int j = e / m, i = e - j * m;
         const int ii = i > j ? i : j, jj = i > j ? j : i;
         sA[i + j * ldl] = (ii < n) ? Ag[ii + (int64_t)jj * lda] : 0.0;
         sV[i + j * ldl] = (i == j) ? 1.0 : 0.0;
     }
-    jacobi64_fill_pairs(m, s_pq);
-    __syncthreads();
-    const int sweep = jacobi64_sweeps(n, m, ldl, sA, sV, s_pq, s_red);
+    int sweep;
+    if (PP) {
+        __syncthreads();
+        sweep = jacobi64_sweeps_pp(n, m, ldl, sA, sV, sV + (size_t)ldl * m, sV + 2 * (size_t)ldl * m, s_red);
+    } else {
+        int* s_pq = reinterpret_cast<int*>(sV + (size_t)ldl * m);
+        jacobi64_fill_pairs(m, s_pq);
+        __syncthreads();
+        sweep = jacobi64_sweeps(n, m, ldl, sA, sV, s_pq, s_red);
+    }
     for (int i = tid; i < n; i += nthr) {
         const double li = sA[i + i * ldl];
         int rk = 0;
@@ -1062,8 +1142,10 @@ small_syev_jacobi64_kernel(int n, double* __restrict__ Ag, int64_t lda, double* 
 }
 
 void small_syev_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }
@@ -1075,8 +1157,10 @@ bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double*
         const int half = (int)((n + 1) / 2), mm = 2 * half;
         int threads = (half * half + 63) / 64 * 64;
         if (threads < 64) threads = 64;
-        const size_t lds64 = 2 * (size_t)(mm | 1) * mm * sizeof(double) + (size_t)(mm - 1) * half * sizeof(int) + 64;
-        small_syev_jacobi64_kernel<<<1, threads, lds64, s>>>((int)n, A, lda, w, info);
+        const size_t lds64 = 4 * (size_t)(mm | 1) * mm * sizeof(double) + 64;
+        static const bool old_core = getenv("SDPSR_JACOBI_TWO_BARRIERS") != nullptr;  // diagnostic
+        if (old_core) small_syev_jacobi64_kernel<false><<<1, threads, lds64, s>>>((int)n, A, lda, w, info);
+        else small_syev_jacobi64_kernel<true><<<1, threads, lds64, s>>>((int)n, A, lda, w, info);
         return true;
     }
     const int v_in_lds = (2 * lds <= 150 * 1024) ? 1 : 0;

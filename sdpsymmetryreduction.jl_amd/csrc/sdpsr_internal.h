@@ -133,7 +133,29 @@ struct RefineWs {
 size_t refine_block_entries();
 size_t refine_counters_bytes();
 uint32_t refine_small_k();
-void launch_refine(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out,
+// Where the insert pass takes its signatures from: an array (SIG_ARRAY), or computed on the fly
+// from the data the matching signature kernel reads (the signatures never travel through HBM).
+// `sig` is the array (SIG_ARRAY) or len entries of scratch for the paths that need one (sort).
+enum { SIG_ARRAY = 0, SIG_PAIR = 1, SIG_PROJ = 2, SIG_CHAN_I32 = 3, SIG_CHAN_F32 = 4 };
+struct SigSource {
+    int kind = SIG_ARRAY;
+    uint64_t* sig = nullptr;
+    const double *a = nullptr, *b = nullptr;                      // SIG_PAIR (launch_sig_f64_pair)
+    const double *U = nullptr, *coef = nullptr;                   // SIG_PROJ (launch_proj_apply, rounded, sig only)
+    const uint32_t* L = nullptr;                                  // old labels (SIG_PROJ, SIG_CHAN_*)
+    int r = 0;
+    uint64_t key = 0;
+    double atol = 0, scale = 1;
+    int64_t n = 0, ld = 0;                                        // SIG_CHAN_* (launch_sig_i32 / launch_sig_f32)
+    int T = 0;
+    const void* C = nullptr;
+    int packed = 0;                                               // lower triangle only, densely packed (symmetric labels)
+    const uint32_t* zero_flag = nullptr;                          // device constant 0 when packed (the kernels' "lower" flag)
+};
+bool sig_source_fusable(const SigSource& q);
+void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint64_t* sig);
+// slot: len entries of scratch; labels_out may alias q.L (it is written only by a pass that succeeded)
+void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slot, uint32_t* labels_out,
                    const RefineWs& ws);
 
 // kernels_refine_sort.hip: radix-sort relabel for the many-classes regime
