@@ -398,6 +398,23 @@ def main():
                                "reference does ONE square per iteration: 4 channels are this build's redundancy for 8-bit draws); "
                                "executed = (T+1)/(2T) of that (lower-triangle tiles); algorithmic bytes per launch = channels x "
                                "(N^2 int8 read + N^2 int32 written)"}
+        # shader clock while this launch runs (sdpsr_profile_clock: a one-wave sampler on a side
+        # stream, clock64 against the 100 MHz wall clock): the int8 squares are power-limited on this
+        # part -- the matrix pipe alone holds ~2.1-2.2 GHz (tools/probes/mfma_clock_probe.hip), the
+        # whole kernel ~1.4-1.7 GHz -- so the fraction of the peak AT THE MEASURED CLOCK is reported
+        # beside the fraction of the nominal (2.4 GHz) peak
+        try:
+            co = (C.c_double * 3)()
+            ctx.check(lib.sdpsr_profile_clock(ctx._h, 0, n, 104, 40, co))
+            if co[1] > 0:
+                roof["shader_clock_mhz"] = round(co[1], 0)
+                roof["nominal_clock_mhz"] = 2400
+                roof["frac_at_measured_clock"] = round(roof["frac"] * 2400.0 / co[1], 4)
+            co2 = (C.c_double * 3)()
+            ctx.check(lib.sdpsr_profile_clock(ctx._h, 1, n, 1, 10, co2))
+            kernels["square_f32"]["shader_clock_mhz"] = round(co2[1], 0)
+        except Exception as e:  # noqa: BLE001  (diagnostic only)
+            roof["shader_clock_note"] = f"clock meter failed: {e!r}"
         cpu_n = n if args.cpu_n < 0 else args.cpu_n
         if cpu_n > 0:
             cb = cpu_baseline(pr, cpu_n, seed=1)

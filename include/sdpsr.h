@@ -273,6 +273,12 @@ int sdpsr_syev_f64(sdpsr_ctx* ctx, int64_t n, const double* A, double* values, d
    ms_per_launch[0] = average milliseconds per launch. */
 int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps,
                          double* ms_per_launch);
+/* The same measurement with the shader clock sampled meanwhile by a one-wave kernel on a side
+   stream (clock64 against the 100 MHz wall_clock64, ~20 us intervals): out[0] = ms per launch,
+   out[1] = median shader clock in MHz while the timed launches ran, out[2] = intervals used.
+   The int8 squares run power-limited (the clock drops under the kernel); the roofline of
+   bench.py reports the fraction of the peak both at the nominal and at this measured clock. */
+int sdpsr_profile_clock(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps, double* out);
 
 #ifdef __cplusplus
 }

@@ -2561,3 +2561,49 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
     hipEventDestroy(e1);
     return SDPSR_OK;
 }
+
+// Diagnostic: sdpsr_profile_kernel(kind, n, aux, reps) with the shader clock sampled meanwhile.
+// out[0] = ms per launch, out[1] = median shader clock (MHz) over the ~20 us intervals of the run,
+// out[2] = number of intervals used.
+extern "C" int sdpsr_profile_clock(sdpsr_ctx* c, int kind, int64_t n, int64_t aux, int reps, double* out) {
+    CHECK_CTX(c);
+    if (!out) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    double ms = 0;
+    int st = sdpsr_profile_kernel(c, kind, n, aux, 1, &ms);  // buffers, tables, clocks: warm
+    if (st) return st;
+    const int NS = 8192;
+    long long* buf = (long long*)ctx_buf(c, "clk_buf", (size_t)(2 * NS + 8) * 8);
+    unsigned* flag = (unsigned*)ctx_buf(c, "clk_flag", 64);
+    if (!buf || !flag) return SDPSR_OUT_OF_MEMORY;
+    long long* marks = buf + 2 * NS;
+    int* count = (int*)(flag + 8);
+    hipStream_t side = nullptr;
+    HIP_TRY(c, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    HIP_TRY(c, hipMemsetAsync(flag, 0, 64, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    launch_clock_sampler(side, buf, NS, flag, 200000000ll /* 2 s */, count);
+    launch_wall_marker(c->stream, marks);
+    st = sdpsr_profile_kernel(c, kind, n, aux, reps, &ms);
+    launch_wall_marker(c->stream, marks + 1);
+    hipMemsetAsync(flag, 1, 4, c->stream);  // releases the sampler whatever happened above
+    hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(side);
+    hipStreamDestroy(side);
+    if (st) return st;
+    std::vector<long long> h((size_t)2 * NS + 8);
+    int hc = 0;
+    HIP_TRY(c, hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&hc, count, 4, hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    // the timed launches are the tail of the marked window (set-up and warm-up come first): use its second half
+    const long long t0 = h[2 * NS] + (h[2 * NS + 1] - h[2 * NS]) / 2, t1 = h[2 * NS + 1];
+    for (int i = 1; i < hc; ++i) {
+        const long long w0 = h[2 * (i - 1) + 1], w1 = h[2 * i + 1];
+        if (w0 >= t0 && w1 <= t1 && w1 > w0) mhz.push_back((double)(h[2 * i] - h[2 * (i - 1)]) / (double)(w1 - w0) * 100.0);
+    }
+    std::sort(mhz.begin(), mhz.end());
+    out[0] = ms;
+    out[1] = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+    out[2] = (double)mhz.size();
+    return SDPSR_OK;
+}

@@ -10,7 +10,6 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
-#include <mutex>
 #include "sdpsr_internal.h"
 
 namespace sdpsr {
@@ -82,9 +81,6 @@ static int backtransform_device(sdpsr_ctx* c, int64_t n, const double* A, int64_
 
 static int ensure_handle(sdpsr_ctx* c) {
     if (!c->rocblas) {
-        // handle creation initialises rocBLAS / hipBLASLt process-wide on first use: one thread at a time
-        static std::mutex create_mutex;
-        std::lock_guard<std::mutex> lock(create_mutex);
         rocblas_handle h = nullptr;
         if (rocblas_create_handle(&h) != rocblas_status_success)
             return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocblas_create_handle failed");

@@ -573,7 +573,6 @@ struct SrcChan {  // sig_channels_kernel; packed: e runs over the lower triangle
 constexpr int REFINE_THREADS = 256;
 constexpr int REFINE_PER_THREAD = 4;
 constexpr int REFINE_BLOCK = REFINE_THREADS * REFINE_PER_THREAD;  // 1024 entries
-constexpr int LDS_SLOTS = 2048;
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 constexpr int MAX_PROBES = 512;
 // Few-classes fast path: the first SMALL_K distinct signatures also append their global slot to
@@ -618,7 +617,7 @@ constexpr int LDS_MAX_PROBES = 24;
 // SRC: where the signatures come from (see the Src* functors); INSERT_PER_THREAD entries per
 // thread and chunk (16 for the plain array, 8 for the computed sources: their loads and hashes
 // of one chunk are all live before the first probe)
-template <class SRC, int INSERT_PER_THREAD>
+template <class SRC, int INSERT_PER_THREAD, int LDS_SLOTS>
 __global__ void __launch_bounds__(REFINE_THREADS)
 refine_insert_kernel(int64_t len, const SRC src,
                      uint32_t* __restrict__ slot_out, unsigned long long* __restrict__ tab_sig,
@@ -909,12 +908,17 @@ __global__ void refine_label_kernel(int64_t len, const uint32_t* __restrict__ sl
     }
 }
 
-template <class SRC, int PER>
+// SLOTS: entries of the workgroup's LDS table (16 bytes each): 2048 -> four workgroups per CU,
+// 1024 -> up to eight (the computed sources are bound by their hash arithmetic and by the
+// barriers between the phases of a chunk: more resident workgroups overlap those phases)
+template <class SRC, int PER, int SLOTS = 1024>
 static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SRC& src, uint32_t* slot, const RefineWs& ws,
                           size_t cap) {
     const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
+    static const int per_cu_env = getenv("SDPSR_INSERT_WGS_PER_CU") ? atoi(getenv("SDPSR_INSERT_WGS_PER_CU")) : 0;  // measurement knob
+    if (SLOTS == 1024) g_chunks_cap = 256 * (per_cu_env > 0 ? per_cu_env : 7);
     const int g = (int)(nchunk < g_chunks_cap ? nchunk : g_chunks_cap);
-    refine_insert_kernel<SRC, PER><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
+    refine_insert_kernel<SRC, PER, SLOTS><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                                 (uint32_t)(cap - 1), ws.counters);
 }
 
@@ -977,7 +981,7 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
             break;
         case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;
         case SIG_CHAN_F32: launch_insert_chan<float>(s, gcap, len, q, slot, ws, cap); break;
-        default: launch_insert<SrcArray, 16>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap); break;
+        default: launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap); break;
     }
     const int g2 = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
     // ws.expect_small: the host predicts <= SMALL_K classes (from the previous refinement) and

@@ -211,6 +211,8 @@ void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_
 // Operands must be padded: k multiple of KT, m and n multiples of 128, pointers 16-B
 // aligned, lda/ldb multiples of 16 bytes.
 // ---------------------------------------------------------------------------
+void launch_clock_sampler(hipStream_t s, long long* buf, int ns, const unsigned* flag, long long max_ticks, int* count);
+void launch_wall_marker(hipStream_t s, long long* out);
 void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc,
                            int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag);
 void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X, int64_t ldx, float* C, int64_t ldc,

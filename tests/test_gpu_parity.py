@@ -102,7 +102,7 @@ def test_clamp_round_and_projection(pkg, oracle, gpu_ctx):
 
 
 # ------------------------------------------------------------------ the square
-@pytest.mark.parametrize("n", [1, 10, 57, 128, 200, 384])
+@pytest.mark.parametrize("n", [1, 10, 57, 128, 200, 384, 512, 1000])
 def test_square_i8_exact(pkg, gpu_ctx, n):
     lib = pkg.load_library()
     rng = np.random.default_rng(n)
