@@ -312,16 +312,18 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         ws.log2cap = log2cap;
         ws.nblk = (int)nblk;
         ws.expect_small = (!mispredicted && c->table_log2_hint <= 12) ? 1 : 0;  // hint 12 <=> last dim <= 512
-        launch_refine(c->stream, len, src, slot, labels, ws);
+        const bool sym_fused = sym_n > 0 && sym_n * sym_n == len;  // verdict in counters[3], same read-back
+        launch_refine(c->stream, len, src, slot, labels, ws, sym_fused ? sym_n : 0);
         uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
         if (!h) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
         HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        if (sym_n > 0 && symflag_dev) {
+        if (sym_n > 0 && symflag_dev && !sym_fused) {
             launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);  // flag = 1 if NOT symmetric
             HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (sym_n > 0 && symflag_dev && sym_out) *sym_out = h[8] ? 0 : 1;
+        if (sym_fused) h[8] = h[3];
+        if (sym_n > 0 && (symflag_dev || sym_fused) && sym_out) *sym_out = h[8] ? 0 : 1;
         HIP_TRY(c, hipGetLastError());
         if (!h[1] && ws.expect_small && h[0] > refine_small_k()) {  // more classes than predicted: general ranking
             mispredicted = true;
@@ -1266,11 +1268,14 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     // a non-symmetric partition has a non-symmetric generic element: eigen() leaves the reals
     // (src/eigen_decomposition.jl:247-253)
     if (!gen) {
-        launch_check_symmetric(s, n, L, flag);
+        const bool pre = c->bd_sym_epoch != 0 && c->bd_sym_labels == L;  // checked by the copy pass of blockDiagonalize
+        const uint32_t* fsrc = flag;
+        if (pre) fsrc = (const uint32_t*)ctx_buf(c, "bd_symflag", 64);
+        else launch_check_symmetric(s, n, L, flag);
         uint32_t* hflag = (uint32_t*)c->pinned;
-        HIP_TRY(c, hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(hflag, fsrc, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        if (hflag[0]) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
+        if (pre ? hflag[0] == c->bd_sym_epoch : hflag[0] != 0) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
                                       "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
     }
     // Step 1-2: generic element and its eigendecomposition (:242-254)
@@ -1555,9 +1560,11 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     // looked at after the first read-back of the module growth (the kernels in between are
     // memory-safe for any labels, their results are simply discarded)
     if (!c->pinned_small) return SDPSR_OUT_OF_MEMORY;
-    launch_check_symmetric(s, n, L, flag);
+    const bool sym_pre = c->bd_sym_epoch != 0 && c->bd_sym_labels == L;  // checked by the copy pass of blockDiagonalize
+    if (!sym_pre) launch_check_symmetric(s, n, L, flag);
     c->pinned_small[0] = 0;
-    HIP_TRY(c, hipMemcpyAsync(c->pinned_small, flag, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->pinned_small, sym_pre ? (const uint32_t*)ctx_buf(c, "bd_symflag", 64) : flag, 4,
+                              hipMemcpyDeviceToHost, s));
     bool sym_checked = false;
     // Y <- A W for a fresh generic element A: fused label product when the shape allows it,
     // gather + split-K MFMA GEMM otherwise.  Columns >= wcols of dst keep their old content.
@@ -1661,7 +1668,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         if (abs_err) return -1;
         if (!sym_checked) {  // the stream has been synchronised: the verdict of the symmetric check is in
             sym_checked = true;
-            if (c->pinned_small[0]) {
+            if (sym_pre ? c->pinned_small[0] == c->bd_sym_epoch : c->pinned_small[0] != 0) {
                 abs_err = ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
                                    "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
                 return -1;
@@ -1979,8 +1986,21 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
     // keep a device copy of the labels for phase 2
     uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
     if (!L) return SDPSR_OUT_OF_MEMORY;
+    c->bd_sym_labels = nullptr;
+    c->bd_sym_epoch = 0;
     if (mem == SDPSR_MEM_DEVICE) {
-        if (P != L) HIP_TRY(c, hipMemcpyAsync(L, P, len * 4, hipMemcpyDeviceToDevice, s));
+        if (P != L) {
+            // copy and symmetry check of the same tiles in one pass; the verdict ("bd_symflag"[0] ==
+            // epoch <=> not symmetric) is read back by the driver with its first synchronisation
+            const bool fresh = c->bufs.find("bd_symflag") == c->bufs.end();
+            uint32_t* sf = (uint32_t*)ctx_buf(c, "bd_symflag", 64);
+            if (!sf) return SDPSR_OUT_OF_MEMORY;
+            if (fresh) HIP_TRY(c, hipMemsetAsync(sf, 0, 64, s));
+            if (++c->epoch_counter == 0) ++c->epoch_counter;
+            launch_copy_check_symmetric(s, n, P, L, sf, c->epoch_counter);
+            c->bd_sym_epoch = c->epoch_counter;
+            c->bd_sym_labels = L;
+        }
     } else {
         HIP_TRY(c, hipMemcpyAsync(L, P, len * 4, hipMemcpyHostToDevice, s));
     }

@@ -545,7 +545,7 @@ struct SrcChan {  // sig_channels_kernel; packed: e runs over the lower triangle
         int32_t c[T + (T & 1)];
 #pragma unroll
         for (int t = 0; t < T; ++t) c[t] = (int32_t)__builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
-        if (T & 1) c[T] = 0;
+        if constexpr ((T & 1) != 0) c[T] = 0;
         uint64_t h = sdpsr_sig_start(l);
         bool allz = true;
 #pragma unroll
@@ -908,6 +908,101 @@ __global__ void refine_label_kernel(int64_t len, const uint32_t* __restrict__ sl
     }
 }
 
+// Tile pass shared by refine_label_sym_kernel and copy_check_symmetric_kernel: out = map(in) over an
+// n x n column-major matrix, 64 x 64 tile pairs (I, J), I >= J, with the mirror tile compared
+// through LDS.  16-byte accesses (4 rows per lane) when n % 4 == 0.  Returns true if some
+// out[r, c] != out[c, r] in this workgroup's tiles.
+template <bool VEC4, class MAP>
+__device__ __forceinline__ bool sym_tile_pass(int64_t n, const uint32_t* __restrict__ in, uint32_t* out, const MAP& map,
+                                              uint32_t (*tile)[65]) {
+    const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+    bool bad = false;
+    if (VEC4) {
+        const int vr = threadIdx.x & 15, cb = threadIdx.x >> 4;  // 16 row groups x 16 columns per round
+        uint4 m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // mirror tile: rows j0.., columns i0..
+            const int64_t r = j0 + 4 * vr, cc = i0 + cb + 16 * q;
+            m[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (r < n && cc < n) m[q] = *reinterpret_cast<const uint4*>(in + r + cc * n);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t r = j0 + 4 * vr, cc = i0 + cb + 16 * q;
+            uint4 l = make_uint4(map(m[q].x), map(m[q].y), map(m[q].z), map(m[q].w));
+            if (r < n && cc < n && i0 != j0) *reinterpret_cast<uint4*>(out + r + cc * n) = l;
+            const int c = cb + 16 * q;
+            tile[4 * vr + 0][c] = l.x;
+            tile[4 * vr + 1][c] = l.y;
+            tile[4 * vr + 2][c] = l.z;
+            tile[4 * vr + 3][c] = l.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // tile: rows i0.., columns j0..
+            const int64_t r = i0 + 4 * vr, cc = j0 + cb + 16 * q;
+            if (r < n && cc < n) m[q] = *reinterpret_cast<const uint4*>(in + r + cc * n);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t r = i0 + 4 * vr, cc = j0 + cb + 16 * q;
+            if (r < n && cc < n) {
+                const uint4 l = make_uint4(map(m[q].x), map(m[q].y), map(m[q].z), map(m[q].w));
+                *reinterpret_cast<uint4*>(out + r + cc * n) = l;
+                const int c = cb + 16 * q;  // out[r + k, cc] against out[cc, r + k] = mirror tile (row c, column 4 vr + k)
+                bad = bad || l.x != tile[c][4 * vr + 0] || l.y != tile[c][4 * vr + 1] || l.z != tile[c][4 * vr + 2] ||
+                      l.w != tile[c][4 * vr + 3];
+            }
+        }
+    } else {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int64_t r = j0 + tx, cc = i0 + ty + 4 * q;
+            uint32_t l = 0u;
+            if (r < n && cc < n) {
+                l = map(in[r + cc * n]);
+                if (i0 != j0) out[r + cc * n] = l;
+            }
+            tile[tx][ty + 4 * q] = l;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int64_t r = i0 + tx, cc = j0 + ty + 4 * q;
+            if (r < n && cc < n) {
+                const uint32_t l = map(in[r + cc * n]);
+                out[r + cc * n] = l;
+                if (l != tile[ty + 4 * q][tx]) bad = true;
+            }
+        }
+    }
+    return bad;
+}
+
+struct MapSlotLabel {
+    const uint32_t* __restrict__ tab_lab;
+    __device__ __forceinline__ uint32_t operator()(uint32_t sl) const { return (sl == NO_SLOT) ? 0u : tab_lab[sl]; }
+};
+struct MapIdentity {
+    __device__ __forceinline__ uint32_t operator()(uint32_t v) const { return v; }
+};
+
+// refine_label_kernel for an n x n label matrix, with the symmetry check of the NEW labels folded in
+// (check_symmetric_kernel would read them again).  counters[3] = 1 if the labels are NOT symmetric
+// (counters are cleared by refine_clear_kernel).
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+refine_label_sym_kernel(int64_t n, const uint32_t* __restrict__ slot, uint32_t* labels_out,
+                        const uint32_t* __restrict__ tab_lab, uint32_t* __restrict__ counters, int expect_small) {
+    __shared__ uint32_t tile[64][65];
+    if (counters[1] || (expect_small && counters[0] > SMALL_K)) return;
+    if (blockIdx.x < blockIdx.y) return;  // lower triangle of tile pairs
+    if (sym_tile_pass<VEC4>(n, slot, labels_out, MapSlotLabel{tab_lab}, tile)) counters[3] = 1u;
+}
+
 // SLOTS: entries of the workgroup's LDS table (16 bytes each): 2048 -> four workgroups per CU,
 // 1024 -> up to eight (the computed sources are bound by their hash arithmetic and by the
 // barriers between the phases of a chunk: more resident workgroups overlap those phases)
@@ -959,7 +1054,7 @@ void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint
 }
 
 void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slot, uint32_t* labels_out,
-                   const RefineWs& ws) {
+                   const RefineWs& ws, int64_t sym_n) {
     const size_t cap = (size_t)1 << ws.log2cap;
     refine_clear_kernel<<<grid_for((int64_t)cap, 256), 256, 0, s>>>((int64_t)cap, (unsigned long long*)ws.tab_sig,
                                                                    ws.tab_min, ws.counters);
@@ -995,7 +1090,13 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
         refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt,
                                                          ws.tab_lab, ws.counters);
     }
-    refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small);
+    if (sym_n > 0 && sym_n * sym_n == len) {  // labels of an n x n matrix: the symmetry verdict comes with the label pass
+        const unsigned t = (unsigned)((sym_n + 63) / 64);
+        if (sym_n % 4 == 0) refine_label_sym_kernel<true><<<dim3(t, t), 256, 0, s>>>(sym_n, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small);
+        else refine_label_sym_kernel<false><<<dim3(t, t), 256, 0, s>>>(sym_n, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small);
+    } else {
+        refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1070,6 +1171,23 @@ check_symmetric_kernel(int64_t n, const uint32_t* __restrict__ L, uint32_t* flag
         if (r < n && cc < n && L[r + cc * n] != tile[tx][c]) bad = true;  // L[r,cc] vs L[cc,r]
     }
     if (bad) flag[0] = 1u;
+}
+// dst = src (n x n labels) with the symmetry check of the same tiles: one pass instead of a copy
+// and a check.  flag[0] = epoch if NOT symmetric (no zeroing pass: the host compares with the
+// epoch of this call).
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+copy_check_symmetric_kernel(int64_t n, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t* flag,
+                            uint32_t epoch) {
+    __shared__ uint32_t tile[64][65];
+    if (blockIdx.x < blockIdx.y) return;
+    if (sym_tile_pass<VEC4>(n, src, dst, MapIdentity{}, tile)) flag[0] = epoch;
+}
+void launch_copy_check_symmetric(hipStream_t s, int64_t n, const uint32_t* src, uint32_t* dst, uint32_t* flag, uint32_t epoch) {
+    const unsigned t = (unsigned)((n + 63) / 64);
+    const bool v4 = n % 4 == 0 && (reinterpret_cast<uintptr_t>(src) % 16) == 0 && (reinterpret_cast<uintptr_t>(dst) % 16) == 0;
+    if (v4) copy_check_symmetric_kernel<true><<<dim3(t, t), 256, 0, s>>>(n, src, dst, flag, epoch);
+    else copy_check_symmetric_kernel<false><<<dim3(t, t), 256, 0, s>>>(n, src, dst, flag, epoch);
 }
 void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag) {
     hipMemsetAsync(flag, 0, sizeof(uint32_t), s);

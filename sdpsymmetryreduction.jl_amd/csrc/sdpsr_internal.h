@@ -51,6 +51,9 @@ struct sdpsr_ctx {
     int64_t bdc_n = 0, bdc_d = 0, bdc_sum_s = 0, bdc_sum_sq = 0;
     std::vector<int32_t> bdc_sizes;
     bool bdc_valid = false;
+    uint32_t bd_sym_epoch = 0;            // != 0: "bd_symflag"[0] == epoch <=> bd_sym_labels are NOT symmetric (copy + check pass of blockDiagonalize)
+    const uint32_t* bd_sym_labels = nullptr;
+    uint32_t epoch_counter = 0;
     bool bd_q_valid = false;  // "bd_qhat" holds Q_hat of the last diagonalize (even when check_block_sizes failed)
     bool bd_labels_owned = false;
     // hash table capacity hint (log2) for the next refine
@@ -155,8 +158,9 @@ struct SigSource {
 bool sig_source_fusable(const SigSource& q);
 void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint64_t* sig);
 // slot: len entries of scratch; labels_out may alias q.L (it is written only by a pass that succeeded)
+// sym_n > 0 (and len == sym_n^2): the label pass also checks the new labels for symmetry, counters[3] = 1 if NOT symmetric
 void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slot, uint32_t* labels_out,
-                   const RefineWs& ws);
+                   const RefineWs& ws, int64_t sym_n = 0);
 
 // kernels_refine_sort.hip: radix-sort relabel for the many-classes regime
 size_t refine_sorted_workspace_bytes(int64_t len);
@@ -205,6 +209,7 @@ void sytrd_graph_cache_destroy(SytrdGraphCache* g);
 
 // symmetric-labels check: flag[0] = 1 if some L[i,j] != L[j,i]
 void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag);
+void launch_copy_check_symmetric(hipStream_t s, int64_t n, const uint32_t* src, uint32_t* dst, uint32_t* flag, uint32_t epoch);
 
 // ---------------------------------------------------------------------------
 // kernels_gemm.hip:  C = A' * B (column-major), MFMA tiles staged through LDS.

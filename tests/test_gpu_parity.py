@@ -535,6 +535,43 @@ def test_nonsymmetric_partition_rejected_by_both_drivers(pkg, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_device_resident_labels_copy_and_symmetry_check(pkg, gpu_ctx, golden):
+    """blockDiagonalize on device-resident labels copies them and checks their symmetry in one tile
+    pass (16-byte accesses when n % 4 == 0, scalar otherwise); the label pass of refine! does the
+    same for the projection step.  Non-symmetric labels -> InvalidDecompositionField from both
+    drivers, a mismatch in the last row/column included; symmetric ones go through unchanged."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(12)
+    for n in (24, 57, 640, 642):
+        M = rng.integers(1, 4, size=(n, n)).astype(np.uint32)
+        M = np.triu(M) + np.triu(M, 1).T  # symmetric ...
+        M[n - 1, 0] = 1 + (M[0, n - 1] % 3)  # ... but for one entry in the last row
+        assert not np.array_equal(M, M.T)
+        t = torch.from_numpy(np.asfortranarray(M).ravel(order="F").view(np.int32).copy()).to(dev)
+        lib = gpu_ctx._lib
+        nb, ssq, ss = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        st = lib.sdpsr_block_diagonalize(gpu_ctx._h, n, C.c_void_p(t.data_ptr()), 3, 1e-8, C.byref(nb), C.byref(ssq),
+                                         C.byref(ss), None, pkg.MEM_DEVICE)
+        assert st == 1, (n, st)  # SDPSR_INVALID_DECOMPOSITION_FIELD
+        assert "not symmetric" in lib.sdpsr_last_error(gpu_ctx._h).decode(), n
+    for name in ("er5", "er7"):  # symmetric, n = 31 (scalar tiles) and 57
+        Lm = golden[f"{name}_P"]
+        n = Lm.shape[0]
+        t = torch.from_numpy(np.asfortranarray(Lm).ravel(order="F").astype(np.int32)).to(dev)
+        for attempt in range(20):
+            nb, ssq, ss = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+            st = lib.sdpsr_block_diagonalize(gpu_ctx._h, n, C.c_void_p(t.data_ptr()), int(Lm.max()), 1e-8, C.byref(nb),
+                                             C.byref(ssq), C.byref(ss), None, pkg.MEM_DEVICE)
+            if st == 0:
+                break
+        assert st == 0, lib.sdpsr_last_error(gpu_ctx._h)
+        sizes = np.zeros(nb.value, dtype=np.int32)
+        gpu_ctx.check(lib.sdpsr_block_sizes(gpu_ctx._h, sizes.ctypes.data_as(C.c_void_p)))
+        assert sorted(int(x) for x in sizes) == list(golden[f"{name}_blk"])
+
+
+@pytest.mark.gpu
 def test_seed_and_external_stream(pkg, problems, golden):
     """sdpsr_set_seed reproduces / changes the draws; sdpsr_set_stream runs everything (including
     the compression driver with its side stream) on a caller-owned HIP stream."""
