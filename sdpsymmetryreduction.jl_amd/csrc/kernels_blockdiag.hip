@@ -1,12 +1,15 @@
 // Kernels of the block-diagonalisation stage (src/eigen_decomposition.jl:177-219,295-348,
 // src/diagonalize.jl:42-89): eigenspace block norms, the small products of
 // irreducible_decomposition, and basis_image as a segmented outer-product reduction.
+#include <cstdlib>
 #include <type_traits>
 #include "sdpsr_internal.h"
 
 #include <hipcub/hipcub.hpp>
 
 namespace sdpsr {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {
     int64_t g = (work_items + block - 1) / block;
@@ -356,12 +359,134 @@ basis_image_outer_kernel(int64_t n, int64_t S1, int64_t S, const double* __restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same (class i, block k) workgroups on the fp64 matrix cores: the block image is the small
+// product  B = X Y'  with  X[a][e] = Q_k[r_e][a],  Y[b][e] = Q_k[c_e][b]  over the entries e of the
+// class (K = class size, M = N = s_k).  The gathered row segments of a batch of 32 entries are
+// staged in LDS (zero-padded to 16-element tiles and to the batch), a wave owns the tile rows
+// ti = wave, wave + 4 and all tile columns, operands are 8-byte LDS reads of consecutive doubles,
+// v_mfma_f64_16x16x4_f64 accumulates 16 x 16 tiles; every output is written exactly once, in
+// entry order (fixed summation order: reproducible).  Blocks up to 128 (8 tiles per dimension).
+// ---------------------------------------------------------------------------
+constexpr int BM_EB = 32;  // entries per staged batch (8 MFMA k-steps)
+
+template <int T>
+__device__ __forceinline__ void bo_mfma_block(int s, int sp, int64_t p_begin, int64_t p_end, int64_t n, int64_t S1, int cb,
+                                              const double* __restrict__ Qrm, const uint32_t* __restrict__ ent, double atol,
+                                              double* __restrict__ o, double* qr, double* qc, int* s_rc) {
+    constexpr int TA = (T + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    v4d acc[TA][T];
+#pragma unroll
+    for (int u = 0; u < TA; ++u)
+#pragma unroll
+        for (int tj = 0; tj < T; ++tj) acc[u][tj] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int64_t p0 = p_begin; p0 < p_end; p0 += BM_EB) {
+        const int ne = (int)((p_end - p0 < BM_EB) ? (p_end - p0) : BM_EB);
+        __syncthreads();  // the previous batch has been consumed
+        if (tid < BM_EB) {
+            uint32_t r = 0, c = 0;
+            if (tid < ne) {
+                const uint32_t lin = ent[p0 + tid];
+                c = lin / (uint32_t)n;
+                r = lin - c * (uint32_t)n;
+            }
+            s_rc[2 * tid] = (int)r;
+            s_rc[2 * tid + 1] = (int)c;
+        }
+        __syncthreads();
+        // wave w stages entries w, w + 4, ...; lanes walk the (padded) row segment
+        for (int e = wave; e < BM_EB; e += 4) {
+            const bool ev = e < ne;
+            const double* rr = Qrm + (int64_t)s_rc[2 * e] * S1 + cb;
+            const double* rc = Qrm + (int64_t)s_rc[2 * e + 1] * S1 + cb;
+            for (int j = lane; j < sp; j += 64) {
+                const bool in = ev && j < s;
+                qr[e * sp + j] = in ? rr[j] : 0.0;
+                qc[e * sp + j] = in ? rc[j] : 0.0;
+            }
+        }
+        __syncthreads();
+        const int ksteps = (ne + 3) >> 2;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int e = 4 * ks + g;
+            double xa[TA], yb[T];
+#pragma unroll
+            for (int u = 0; u < TA; ++u) {
+                const int ti = wave + 4 * u;
+                xa[u] = (ti < T) ? qr[e * sp + ti * 16 + m] : 0.0;
+            }
+#pragma unroll
+            for (int tj = 0; tj < T; ++tj) yb[tj] = qc[e * sp + tj * 16 + m];
+#pragma unroll
+            for (int u = 0; u < TA; ++u)
+#pragma unroll
+                for (int tj = 0; tj < T; ++tj)
+                    acc[u][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(yb[tj], xa[u], acc[u][tj], 0, 0, 0);
+        }
+    }
+    // D[jj][ii]: ii = lane & 15 (row a), jj = (lane >> 4) + 4 * reg (column b)
+#pragma unroll
+    for (int u = 0; u < TA; ++u) {
+        const int ti = wave + 4 * u;
+        const int a = ti * 16 + m;
+        if (ti < T && a < s) {
+#pragma unroll
+            for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = tj * 16 + g + 4 * r;
+                    if (b < s) {
+                        const double v = acc[u][tj][r];
+                        __builtin_nontemporal_store((fabs(v) < atol) ? 0.0 : v, &o[a + (int64_t)b * s]);  // written once, never re-read here
+                    }
+                }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+basis_image_outer_mfma_kernel(int64_t n, int64_t S1, int64_t S, const double* __restrict__ Qrm,
+                              const uint32_t* __restrict__ ent, const int64_t* __restrict__ cls_ptr,
+                              const int32_t* __restrict__ blk_col, const int32_t* __restrict__ blk_size,
+                              const int64_t* __restrict__ blk_off, double atol, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double bm_smem[];  // qr[EB][sp], qc[EB][sp], (r, c)[EB]
+    const int i = blockIdx.x, k = blockIdx.y;
+    const int s = blk_size[k], cb = blk_col[k];
+    const int T = (s + 15) >> 4;
+    const int sp = T * 16;
+    const int64_t p_begin = cls_ptr[i + 1], p_end = cls_ptr[i + 2];  // label i + 1
+    double* qr = bm_smem;
+    double* qc = qr + BM_EB * sp;
+    int* s_rc = reinterpret_cast<int*>(qc + BM_EB * sp);
+    double* o = out + (int64_t)i * S + blk_off[k];
+    switch (T) {  // uniform
+        case 1: bo_mfma_block<1>(s, sp, p_begin, p_end, n, S1, cb, Qrm, ent, atol, o, qr, qc, s_rc); break;
+        case 2: bo_mfma_block<2>(s, sp, p_begin, p_end, n, S1, cb, Qrm, ent, atol, o, qr, qc, s_rc); break;
+        case 3: bo_mfma_block<3>(s, sp, p_begin, p_end, n, S1, cb, Qrm, ent, atol, o, qr, qc, s_rc); break;
+        case 4: bo_mfma_block<4>(s, sp, p_begin, p_end, n, S1, cb, Qrm, ent, atol, o, qr, qc, s_rc); break;
+        case 5: bo_mfma_block<5>(s, sp, p_begin, p_end, n, S1, cb, Qrm, ent, atol, o, qr, qc, s_rc); break;
+        case 6: bo_mfma_block<6>(s, sp, p_begin, p_end, n, S1, cb, Qrm, ent, atol, o, qr, qc, s_rc); break;
+        case 7: bo_mfma_block<7>(s, sp, p_begin, p_end, n, S1, cb, Qrm, ent, atol, o, qr, qc, s_rc); break;
+        default: bo_mfma_block<8>(s, sp, p_begin, p_end, n, S1, cb, Qrm, ent, atol, o, qr, qc, s_rc); break;
+    }
+}
+
 void launch_basis_image_outer(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks, int max_s,
                               const double* Qrm, const uint32_t* ent, const int64_t* cls_ptr,
                               const int32_t* blk_col, const int32_t* blk_size, const int64_t* blk_off, double atol,
                               double* out) {
-    const size_t lds = (size_t)2 * BO_EB * max_s * sizeof(double);
     dim3 g((unsigned)d, (unsigned)nblocks);
+    static const bool no_mfma = getenv("SDPSR_BASIS_IMAGE_VALU") != nullptr;  // A/B switch for measurements
+    if (max_s >= 16 && max_s <= 128 && n < 65536 && !no_mfma) {
+        // matrix-core form: worth it once a block spans at least one full MFMA tile
+        const int spmax = ((max_s + 15) / 16) * 16;
+        const size_t lds_m = (size_t)2 * BM_EB * spmax * sizeof(double) + (size_t)2 * BM_EB * sizeof(int);
+        basis_image_outer_mfma_kernel<<<g, 256, lds_m, s>>>(n, S1, S, Qrm, ent, cls_ptr, blk_col, blk_size, blk_off, atol, out);
+        return;
+    }
+    const size_t lds = (size_t)2 * BO_EB * max_s * sizeof(double);
     basis_image_outer_kernel<<<g, BO_THREADS, lds, s>>>(n, S1, S, Qrm, ent, cls_ptr, blk_col, blk_size, blk_off, atol, out);
 }
 
@@ -608,6 +733,8 @@ class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict_
 void blockdiag_set_device_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_outer_mfma_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<2>),
