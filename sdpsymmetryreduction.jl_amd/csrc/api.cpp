@@ -264,7 +264,9 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
     static const bool no_fuse = getenv("SDPSR_REFINE_NO_FUSE") != nullptr;  // diagnostic: always through the array
     if ((no_fuse || !sig_source_fusable(src)) && !materialize())
         return ctx_fail(c, SDPSR_BAD_ARGUMENT, "refine: signature source needs scratch");
-    uint32_t* slot = (uint32_t*)ctx_buf(c, "ref_slots", (size_t)len * 4);
+    // slots of the insert pass: in place for an array source (nothing reads the old labels), a
+    // scratch array for a computed source (it may read the old labels from `labels` on a repeated pass)
+    uint32_t* slot = (src.kind == SIG_ARRAY) ? labels : (uint32_t*)ctx_buf(c, "ref_slots", (size_t)len * 4);
     if (!slot) return SDPSR_OUT_OF_MEMORY;
     const int full = std::max(12, ceil_log2((uint64_t)len * 2));
     int log2cap = std::min(full, std::max(12, c->table_log2_hint));

@@ -896,8 +896,8 @@ __global__ void refine_clear_kernel(int64_t cap, unsigned long long* __restrict_
 
 // A pass the host is going to repeat (table overflow, or more classes than the one-workgroup
 // ranking was launched for) must leave labels_out alone: a computed signature source may read the
-// old labels from that very array.
-__global__ void refine_label_kernel(int64_t len, const uint32_t* __restrict__ slot, uint32_t* labels_out,
+// old labels from that very array.  slot may be labels_out itself (array source: in place).
+__global__ void refine_label_kernel(int64_t len, const uint32_t* slot, uint32_t* labels_out,
                                     const uint32_t* __restrict__ tab_lab, const uint32_t* __restrict__ counters,
                                     int expect_small) {
     if (counters[1] || (expect_small && counters[0] > SMALL_K)) return;
@@ -913,7 +913,7 @@ __global__ void refine_label_kernel(int64_t len, const uint32_t* __restrict__ sl
 // through LDS.  16-byte accesses (4 rows per lane) when n % 4 == 0.  Returns true if some
 // out[r, c] != out[c, r] in this workgroup's tiles.
 template <bool VEC4, class MAP>
-__device__ __forceinline__ bool sym_tile_pass(int64_t n, const uint32_t* __restrict__ in, uint32_t* out, const MAP& map,
+__device__ __forceinline__ bool sym_tile_pass(int64_t n, const uint32_t* in, uint32_t* out, const MAP& map,
                                               uint32_t (*tile)[65]) {
     const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
     bool bad = false;
@@ -995,7 +995,7 @@ struct MapIdentity {
 // (counters are cleared by refine_clear_kernel).
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
-refine_label_sym_kernel(int64_t n, const uint32_t* __restrict__ slot, uint32_t* labels_out,
+refine_label_sym_kernel(int64_t n, const uint32_t* slot, uint32_t* labels_out,
                         const uint32_t* __restrict__ tab_lab, uint32_t* __restrict__ counters, int expect_small) {
     __shared__ uint32_t tile[64][65];
     if (counters[1] || (expect_small && counters[0] > SMALL_K)) return;

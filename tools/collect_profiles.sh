@@ -24,3 +24,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_f32_8192_$C -o p -- python3 $R/tools/pmc_probe.py 1 8192 1 > /dev/null 2>&1
 done
 ls -R $O | head -60
+# (f) the default bench command itself (full JSON line with roofline + cpu_baseline)
+cd $R && python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+# (g) clocks under the hot kernels, the pure-MFMA probe, the int8 diagnostic builds, configs[1..2]
+python3 tools/clock_under_kernels.py > $O/clock_under_kernels.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_clock_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe > $O/mfma_clock_probe.txt 2>&1
+for d in 0 1 2 3; do echo "SDPSR_W4_DIAG=$d" >> $O/i8_w4_diag.txt; SDPSR_GEMM_I8_W4=1 SDPSR_W4_DIAG=$d python3 tools/i8_tri_time.py >> $O/i8_w4_diag.txt 2>&1; done
+python3 tools/config_times.py > $O/config_times.txt 2>&1
+python3 tools/config2_bd_phases.py > $O/config2_bd_phases.txt 2>&1
+python3 tools/small_syev_time.py > $O/small_syev_time.txt 2>&1
