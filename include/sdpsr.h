@@ -222,8 +222,11 @@ int sdpsr_block_images(sdpsr_ctx* ctx, double* blks, double* Q_hat, double* phas
    diagonalize(ComplexF64, P) = desymmetrize (src/diagonalize.jl:26-28) + Murota's decomposition
    over C + check_block_sizes with sum s_k^2 == dim(P) (:13-23); the partition handed to
    basis_image is the desymmetrized one (src/compat.jl:54-57).
-   This version covers n <= 64 (every step in single-workgroup kernels; the reference's own
-   complex tests are 3 x 3 and 4 x 4, test/runtests.jl:43-57); larger n: SDPSR_BAD_ARGUMENT.
+   n <= 64: every step in single-workgroup kernels (the reference's own complex tests are 3 x 3
+   and 4 x 4, test/runtests.jl:43-57).  64 < n <= 3072: the Hermitian elements go through their real
+   symmetric embedding (2n x 2n: the real dense eigensolver and the fp64 MFMA GEMMs; eigenspaces
+   are extracted per eigenvalue cluster, SDPSR_NUMERICAL_INCONSISTENCY if a cluster does not
+   split evenly).  Larger n: SDPSR_BAD_ARGUMENT.
    BEHAVIOURAL DIFFERENCE: the generic elements are Hermitian (A + A^H with complex class
    coefficients) and the eigensolver is a Hermitian Jacobi iteration, where the reference hands a
    general complex element to eigen(); block sizes and block spectra are the same.

@@ -1,8 +1,8 @@
 // Complex path of blockDiagonalize (src/compat.jl:26-32,54-57; src/diagonalize.jl:13-28):
-// desymmetrize, then Murota's decomposition over C.  Version 1 covers orders n <= 64 with every
-// step in single-workgroup kernels on LDS-/L2-resident data (the complex path is the reference's
-// answer to small algebras that do not split over the reals: test/runtests.jl:43-57 runs it on
-// 3 x 3 and 4 x 4 partitions); larger orders return SDPSR_BAD_ARGUMENT.
+// desymmetrize, then Murota's decomposition over C.  Orders n <= 64 run every step in
+// single-workgroup kernels on LDS-/L2-resident data (the complex path is the reference's answer to
+// small algebras that do not split over the reals: test/runtests.jl:43-57 runs it on 3 x 3 and 4 x 4
+// partitions); larger orders go through the real symmetric embedding (second half of this file).
 //
 // DEVIATION: the reference draws a generic element with complex coefficients and
 // calls the general (non-Hermitian) eigen(); here the generic elements are HERMITIAN,
@@ -348,11 +348,207 @@ cx_basis_image_kernel(int n, int S, const uint32_t* __restrict__ L, const double
     }
 }
 
+// ---------------------------------------------------------------------------
+// Orders n > 64: the same steps on matrices that live in HBM.  A Hermitian H is handled through
+// its real symmetric embedding  M(H) = [[Re H, -Im H], [Im H, Re H]]  (2n x 2n; H -> M(H) is a
+// *-isomorphism onto the real matrices that commute with J = [[0, -I], [I, 0]]): the real dense
+// eigensolver and the fp64 MFMA GEMMs of the real path do the O(n^3) work, small kernels move
+// between the two pictures.  A complex n x k matrix Z = X + iY is the real (2n) x k matrix [X; Y].
+// ---------------------------------------------------------------------------
+// M (ld2 x ld2, zeroed by the caller beyond 2n) = M(H)
+__global__ void cx_embed_kernel(int n, const double* __restrict__ Hr, const double* __restrict__ Hi, int64_t ld2,
+                                double* __restrict__ M) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)n * n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e / n), r = (int)(e - (int64_t)c * n);
+        const double re = Hr[e], im = Hi[e];
+        M[r + (int64_t)c * ld2] = re;
+        M[(r + n) + (int64_t)(c + n) * ld2] = re;
+        M[(r + n) + (int64_t)c * ld2] = im;
+        M[r + (int64_t)(c + n) * ld2] = -im;
+    }
+}
+// R = J' E columnwise: R[0:n, j] = E[n:2n, j], R[n:2n, j] = -E[0:n, j]   (so that E' R = X'Y - Y'X = Im(Z^H Z))
+__global__ void cx_rot_kernel(int n, int64_t cols, int64_t ld2, const double* __restrict__ E, double* __restrict__ R) {
+    const int64_t total = (int64_t)n * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = e / n;
+        const int r = (int)(e - j * n);
+        R[r + j * ld2] = E[(r + n) + j * ld2];
+        R[(r + n) + j * ld2] = -E[r + j * ld2];
+    }
+}
+// rows / columns >= m of an ld x ldc buffer back to zero
+__global__ void cx_zero_pad_kernel(int64_t m, int64_t mc, int64_t ld, int64_t ldc, double* __restrict__ A) {
+    const int64_t total = ld * ldc;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = e / ld, i = e - j * ld;
+        if (i >= m || j >= mc) A[e] = 0.0;
+    }
+}
+// eigenvectors of H from those of M(H): output column j (planes, ld = n) is the combination
+//   sum_b Z[:, off_j + b] * C_j[b],  Z = X + iY the real eigenvectors read as complex vectors,
+// C_j (complex, m2_j entries at coef + 2 * cof_j) from the host's rank-revealing Cholesky of the
+// cluster's Gram matrix.  desc[j] = {off, m2, cof}
+__global__ void cx_combine_kernel(int n, int64_t ld2, const double* __restrict__ E, const int32_t* __restrict__ desc,
+                                  const double* __restrict__ coef, double* __restrict__ Vr, double* __restrict__ Vi) {
+    const int j = blockIdx.y;
+    const int off = desc[3 * j], m2 = desc[3 * j + 1], cof = desc[3 * j + 2];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cxd acc = {0, 0};
+    for (int b = 0; b < m2; ++b) {
+        const cxd z = {E[i + (int64_t)(off + b) * ld2], E[(i + n) + (int64_t)(off + b) * ld2]};
+        const cxd cf = {coef[2 * (cof + b)], coef[2 * (cof + b) + 1]};
+        const cxd p = cx_mul(z, cf);
+        acc.re += p.re;
+        acc.im += p.im;
+    }
+    Vr[i + (int64_t)j * n] = acc.re;
+    Vi[i + (int64_t)j * n] = acc.im;
+}
+// E (ld2 x ldc, zero beyond) = [Vr; Vi]
+__global__ void cx_stack_kernel(int n, int64_t cols, const double* __restrict__ Vr, const double* __restrict__ Vi, int64_t ldv,
+                                int64_t ld2, double* __restrict__ E) {
+    const int64_t total = (int64_t)n * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = e / n;
+        const int r = (int)(e - j * n);
+        E[r + j * ld2] = Vr[r + j * ldv];
+        E[(r + n) + j * ld2] = Vi[r + j * ldv];
+    }
+}
+// norms[sa * neig + sb] = max |Gr + i Gi| over the block (Gr, Gi: n x n in ldn x ldn buffers)
+__global__ void cx_block_norms_general_kernel(int n, int64_t ldn, const double* __restrict__ Gr, const double* __restrict__ Gi,
+                                              const int32_t* __restrict__ space_of, int neig, unsigned long long* __restrict__ norms) {
+    const int64_t total = (int64_t)n * n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / n), a = (int)(e - (int64_t)b * n);
+        const double re = Gr[a + (int64_t)b * ldn], im = Gi[a + (int64_t)b * ldn];
+        const double mag = sqrt(re * re + im * im);
+        atomicMax(&norms[(int64_t)space_of[a] * neig + space_of[b]], (unsigned long long)__double_as_longlong(mag));
+    }
+}
+
+// cx_irreducible_kernel for any n: the vectors t = H3 q_i1, u = H3 q_j1 and the coefficients live
+// in dynamic LDS (6 n doubles), every loop strides over the workgroup.
+__global__ void __launch_bounds__(256)
+cx_irreducible_general_kernel(int n, const double* __restrict__ Hr, const double* __restrict__ Hi, const double* __restrict__ Vr,
+                              const double* __restrict__ Vi, const int32_t* __restrict__ desc, double atol,
+                              double* __restrict__ Qhat) {
+    extern __shared__ __attribute__((aligned(16))) double sg[];
+    __shared__ double s_part[256];
+    double *tr = sg, *ti = tr + n, *ur = ti + n, *ui = ur + n, *cr = ui + n, *ci = cr + n;
+    const int32_t* dsc = desc + 6 * blockIdx.x;
+    const int kind = dsc[0], i0 = dsc[1], mi = dsc[2], j0 = dsc[3], mj = dsc[4], col = dsc[5];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    double* out = Qhat + (size_t)2 * n * col;
+    if (kind == 0) {
+        for (int r = tid; r < n; r += nthr) {
+            cxd v = {Vr[r + (int64_t)i0 * n], Vi[r + (int64_t)i0 * n]};
+            if (sqrt(v.re * v.re + v.im * v.im) < atol) v = {0, 0};
+            out[2 * r] = v.re;
+            out[2 * r + 1] = v.im;
+        }
+        return;
+    }
+    for (int r = tid; r < n; r += nthr) {  // t = H3 q_i1, u = H3 q_j1
+        cxd t = {0, 0}, u = {0, 0};
+        for (int k = 0; k < n; ++k) {
+            const cxd h = {Hr[r + (int64_t)k * n], Hi[r + (int64_t)k * n]};
+            const cxd p = cx_mul(h, {Vr[k + (int64_t)i0 * n], Vi[k + (int64_t)i0 * n]});
+            const cxd q = cx_mul(h, {Vr[k + (int64_t)j0 * n], Vi[k + (int64_t)j0 * n]});
+            t.re += p.re;
+            t.im += p.im;
+            u.re += q.re;
+            u.im += q.im;
+        }
+        tr[r] = t.re;
+        ti[r] = t.im;
+        ur[r] = u.re;
+        ui[r] = u.im;
+    }
+    __syncthreads();
+    for (int a = tid; a < mj; a += nthr) {  // c = Q_j^H t
+        cxd acc = {0, 0};
+        for (int k = 0; k < n; ++k) {
+            const cxd p = cx_cmul({Vr[k + (int64_t)(j0 + a) * n], Vi[k + (int64_t)(j0 + a) * n]}, {tr[k], ti[k]});
+            acc.re += p.re;
+            acc.im += p.im;
+        }
+        cr[a] = acc.re;
+        ci[a] = acc.im;
+    }
+    double s2 = 0;  // || Q_i^H u ||^2, members of the root eigenspace strided over the threads
+    for (int a = tid; a < mi; a += nthr) {
+        cxd acc = {0, 0};
+        for (int k = 0; k < n; ++k) {
+            const cxd p = cx_cmul({Vr[k + (int64_t)(i0 + a) * n], Vi[k + (int64_t)(i0 + a) * n]}, {ur[k], ui[k]});
+            acc.re += p.re;
+            acc.im += p.im;
+        }
+        s2 += acc.re * acc.re + acc.im * acc.im;
+    }
+    s_part[tid] = s2;
+    __syncthreads();
+    double tot = 0;
+    for (int k = 0; k < nthr; ++k) tot += s_part[k];  // fixed order
+    const double nrm = sqrt(tot);
+    const double inv = nrm > 0 ? 1.0 / nrm : 0.0;
+    for (int r = tid; r < n; r += nthr) {
+        cxd acc = {0, 0};
+        for (int a = 0; a < mj; ++a) {
+            const cxd p = cx_mul({Vr[r + (int64_t)(j0 + a) * n], Vi[r + (int64_t)(j0 + a) * n]}, {cr[a], ci[a]});
+            acc.re += p.re;
+            acc.im += p.im;
+        }
+        acc.re *= inv;
+        acc.im *= inv;
+        if (sqrt(acc.re * acc.re + acc.im * acc.im) < atol) acc = {0, 0};
+        out[2 * r] = acc.re;
+        out[2 * r + 1] = acc.im;
+    }
+}
+
+static inline unsigned cx_grid(int64_t work) {
+    int64_t g = (work + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (unsigned)g;
+}
+void launch_cx_embed(hipStream_t s, int64_t n, const double* Hr, const double* Hi, int64_t ld2, double* M) {
+    hipMemsetAsync(M, 0, (size_t)ld2 * ld2 * 8, s);
+    cx_embed_kernel<<<cx_grid(n * n), 256, 0, s>>>((int)n, Hr, Hi, ld2, M);
+}
+void launch_cx_rot(hipStream_t s, int64_t n, int64_t cols, int64_t ld2, const double* E, double* R) {
+    cx_rot_kernel<<<cx_grid(n * cols), 256, 0, s>>>((int)n, cols, ld2, E, R);
+}
+void launch_cx_zero_pad(hipStream_t s, int64_t m, int64_t mc, int64_t ld, int64_t ldc, double* A) {
+    cx_zero_pad_kernel<<<cx_grid(ld * ldc), 256, 0, s>>>(m, mc, ld, ldc, A);
+}
+void launch_cx_combine(hipStream_t s, int64_t n, int64_t ld2, const double* E, const int32_t* desc, const double* coef, double* Vr,
+                       double* Vi) {
+    dim3 g((unsigned)((n + 255) / 256), (unsigned)n);
+    cx_combine_kernel<<<g, 256, 0, s>>>((int)n, ld2, E, desc, coef, Vr, Vi);
+}
+void launch_cx_stack(hipStream_t s, int64_t n, int64_t cols, const double* Vr, const double* Vi, int64_t ldv, int64_t ld2, double* E) {
+    cx_stack_kernel<<<cx_grid(n * cols), 256, 0, s>>>((int)n, cols, Vr, Vi, ldv, ld2, E);
+}
+void launch_cx_block_norms_general(hipStream_t s, int64_t n, int64_t ldn, const double* Gr, const double* Gi, const int32_t* space_of,
+                                   int neig, unsigned long long* norms) {
+    cx_block_norms_general_kernel<<<cx_grid(n * n), 256, 0, s>>>((int)n, ldn, Gr, Gi, space_of, neig, norms);
+}
+void launch_cx_irreducible_general(hipStream_t s, int64_t n, const double* Hr, const double* Hi, const double* Vr, const double* Vi,
+                                   const int32_t* desc, int ncols, double atol, double* Qhat) {
+    cx_irreducible_general_kernel<<<ncols, 256, (size_t)6 * n * sizeof(double), s>>>((int)n, Hr, Hi, Vr, Vi, desc, atol, Qhat);
+}
+
 void complex_set_device_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_heev_jacobi64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         150 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_block_norms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         64 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_irreducible_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        144 * 1024);
 }
 
 void launch_cx_gather_herm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, double* Hr, double* Hi) {

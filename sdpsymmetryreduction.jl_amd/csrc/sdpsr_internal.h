@@ -193,6 +193,16 @@ void batched_set_device_attributes();
 void backtransform_set_device_attributes();
 void complex_set_device_attributes();
 // kernels_complex.hip (complex path of blockDiagonalize, n <= 64; planes re / im, ld = n)
+void launch_cx_embed(hipStream_t s, int64_t n, const double* Hr, const double* Hi, int64_t ld2, double* M);
+void launch_cx_rot(hipStream_t s, int64_t n, int64_t cols, int64_t ld2, const double* E, double* R);
+void launch_cx_zero_pad(hipStream_t s, int64_t m, int64_t mc, int64_t ld, int64_t ldc, double* A);
+void launch_cx_combine(hipStream_t s, int64_t n, int64_t ld2, const double* E, const int32_t* desc, const double* coef, double* Vr,
+                       double* Vi);
+void launch_cx_stack(hipStream_t s, int64_t n, int64_t cols, const double* Vr, const double* Vi, int64_t ldv, int64_t ld2, double* E);
+void launch_cx_block_norms_general(hipStream_t s, int64_t n, int64_t ldn, const double* Gr, const double* Gi, const int32_t* space_of,
+                                   int neig, unsigned long long* norms);
+void launch_cx_irreducible_general(hipStream_t s, int64_t n, const double* Hr, const double* Hi, const double* Vr, const double* Vi,
+                                   const int32_t* desc, int ncols, double atol, double* Qhat);
 void launch_cx_gather_herm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, double* Hr, double* Hi);
 void launch_cx_heev(hipStream_t s, int64_t n, const double* Hr, const double* Hi, double* w, double* Vr, double* Vi, int* info);
 void launch_cx_block_norms(hipStream_t s, int64_t n, const double* Hr, const double* Hi, const double* Vr, const double* Vi,

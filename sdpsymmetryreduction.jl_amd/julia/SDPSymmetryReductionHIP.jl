@@ -159,7 +159,7 @@ function SR.diagonalize(::Type{Float64}, P::HIPPartition; verbose=false, atol=1e
     return [Q[:, offs[k]+1:offs[k+1]] for k in eachindex(sizes)]
 end
 
-# ---- blockDiagonalize(ComplexF64, P) (compat.jl:26-32,54-57; n <= 64 in this library version) ---
+# ---- blockDiagonalize(ComplexF64, P) (compat.jl:26-32,54-57; n <= 3072 in this library version) ---
 function SR.blockDiagonalize(::Type{ComplexF64}, P::HIPPartition, verbose=true;
                              epsilon=Base.rtoldefault(Float64))
     n = size(P, 1); cx = ctx()

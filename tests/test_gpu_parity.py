@@ -782,3 +782,38 @@ def test_complex_heev_against_lapack_through_block_images(pkg, gpu_ctx):
     ev = np.array([sum(x[c] * bd.blks[c][k][0, 0] for c in range(n)) for k in range(n)])
     ref = np.linalg.eigvals(A)
     assert np.allclose(np.sort_complex(np.round(ev, 8)), np.sort_complex(np.round(ref, 8)), atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_complex_path_beyond_one_workgroup(pkg, problems, oracle, gpu_ctx):
+    """Orders n > 64 of blockDiagonalize(P; complex=true): the Hermitian eigensolver runs through the
+    real symmetric embedding (2n x 2n, the real dense solver), eigenspaces are extracted per cluster
+    by a pivoted Cholesky of the Gram matrix, Q'AQ goes through fp64 MFMA GEMMs.  Z_100 (100 blocks of
+    size 1, simple spectrum) and C[S3] (x) {I, J - I}_12 (n = 72, non-commutative, eigenspaces of
+    dimension up to 22): block sizes against the oracle's, orthonormal Q_hat, blks == Q_k^H 1[P==i] Q_k,
+    complex spectrum invariant."""
+    n = 100
+    i = np.arange(n)
+    cases = [((i[None, :] - i[:, None]) % n + 1, [1] * n)]
+    Ls3, _ = problems.kron_with_complete(_s3_cayley_labels(), 12, seed=3)
+    ref = oracle.block_diagonalize_complex(oracle.partition_from_labels(Ls3), rng=np.random.default_rng(1))
+    cases.append((Ls3, sorted(int(b) for b in ref[0])))
+    assert cases[1][1] == [1, 1, 1, 1, 2, 2]
+    Lbig, _ = problems.kron_with_complete(_s3_cayley_labels(), 64, seed=4)  # n = 384: embedded order 768, eigenspaces up to 126
+    cases.append((Lbig, [1, 1, 1, 1, 2, 2]))
+    for Lm, expect in cases:
+        P = pkg.Partition.from_matrix(Lm, ctx=gpu_ctx)
+        for rep in range(2):
+            bd = pkg.blockDiagonalize(P, complex=True, ctx=gpu_ctx, retries=3)
+            assert sorted(bd.blkSizes) == expect
+            Pd = bd.partition
+            assert sum(s * s for s in bd.blkSizes) == Pd.nparts
+            for k, q in enumerate(bd.Q_hat):
+                assert np.allclose(q.conj().T @ q, np.eye(q.shape[1]), atol=1e-9)
+                for c in range(0, Pd.nparts, max(1, Pd.nparts // 12)):
+                    M = (np.asarray(Pd.matrix) == c + 1).astype(np.float64)
+                    assert np.allclose(bd.blks[c][k], q.conj().T @ M @ q, atol=1e-9)
+            x = np.random.default_rng(17 + rep).random(Pd.nparts)
+            full, blk = oracle.spectrum_invariant_complex(oracle.Partition(Pd.nparts, np.asarray(Pd.matrix).astype(np.int64)), bd.blks, x)
+            assert len(full) == len(blk)
+            assert np.allclose(full, blk, rtol=1e-6, atol=1e-8)
