@@ -2353,7 +2353,24 @@ int sdpsr_block_images_complex(sdpsr_ctx* c, double* blks, double* Q_hat, int me
     }
     st = h2d_sync(c, ddesc, hdesc.data(), hdesc.size() * 4);
     if (st) return st;
-    launch_cx_basis_image(s, n, d, S, L, Qhat, ddesc, ddesc + S, 1e-12 * (double)n, out);
+    if (n <= 64) {
+        launch_cx_basis_image(s, n, d, S, L, Qhat, ddesc, ddesc + S, 1e-12 * (double)n, out);
+    } else {
+        // entries grouped by class (_constraints(P), src/diagonalize.jl:42-50): a class workgroup walks its own entries only
+        uint32_t* ent = nullptr;
+        int64_t* class_ptr = nullptr;
+        st = sort_entries_by_label(c, n * n, d, L, &ent, &class_ptr);
+        if (st) return st;
+        int64_t* d_cls = (int64_t*)ctx_buf(c, "bi_cls_ptr", (size_t)(d + 2) * 8);
+        if (!d_cls) {
+            free(class_ptr);
+            return SDPSR_OUT_OF_MEMORY;
+        }
+        st = h2d_sync(c, d_cls, class_ptr, (size_t)(d + 2) * 8);
+        free(class_ptr);
+        if (st) return st;
+        launch_cx_basis_image_sorted(s, n, d, S, ent, d_cls, Qhat, ddesc, ddesc + S, 1e-12 * (double)n, out);
+    }
     HIP_TRY(c, hipGetLastError());
     st = out_finish(c, blks, out, (size_t)2 * d * S, mem);
     if (st) return st;

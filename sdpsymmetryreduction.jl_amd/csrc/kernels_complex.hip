@@ -542,6 +542,40 @@ void launch_cx_irreducible_general(hipStream_t s, int64_t n, const double* Hr, c
     cx_irreducible_general_kernel<<<ncols, 256, (size_t)6 * n * sizeof(double), s>>>((int)n, Hr, Hi, Vr, Vi, desc, atol, Qhat);
 }
 
+// cx_basis_image_kernel over the entries of the class only (ent: linear indices grouped by label,
+// cls_ptr[l] .. cls_ptr[l + 1] = label l): O(|class| * S) per class instead of a scan of all labels.
+__global__ void __launch_bounds__(256)
+cx_basis_image_sorted_kernel(int n, int S, const uint32_t* __restrict__ ent, const int64_t* __restrict__ cls_ptr,
+                             const double* __restrict__ Qhat, const int32_t* __restrict__ descA,
+                             const int32_t* __restrict__ descB, double atol, double* __restrict__ out) {
+    const int64_t p0 = cls_ptr[blockIdx.x + 1], p1 = cls_ptr[blockIdx.x + 2];
+    const int tid = threadIdx.x;
+    for (int o0 = 0; o0 < S; o0 += 256) {
+        const int o = o0 + tid;
+        const bool ok = o < S;
+        const int ca = ok ? descA[o] : 0, cb = ok ? descB[o] : 0;
+        cxd acc = {0, 0};
+        for (int64_t p = p0; p < p1; ++p) {  // entry order: fixed, reproducible
+            const uint32_t lin = ent[p];     // uniform over the workgroup
+            const uint32_t c = lin / (uint32_t)n, r = lin - c * (uint32_t)n;
+            const cxd qa = {Qhat[2 * (r + (size_t)ca * n)], Qhat[2 * (r + (size_t)ca * n) + 1]};
+            const cxd qb = {Qhat[2 * (c + (size_t)cb * n)], Qhat[2 * (c + (size_t)cb * n) + 1]};
+            const cxd pr = cx_cmul(qa, qb);
+            acc.re += pr.re;
+            acc.im += pr.im;
+        }
+        if (ok) {
+            if (sqrt(acc.re * acc.re + acc.im * acc.im) < atol) acc = {0, 0};
+            out[2 * ((size_t)blockIdx.x * S + o)] = acc.re;
+            out[2 * ((size_t)blockIdx.x * S + o) + 1] = acc.im;
+        }
+    }
+}
+void launch_cx_basis_image_sorted(hipStream_t s, int64_t n, int64_t d, int64_t S, const uint32_t* ent, const int64_t* cls_ptr,
+                                  const double* Qhat, const int32_t* descA, const int32_t* descB, double atol, double* out) {
+    cx_basis_image_sorted_kernel<<<(unsigned)d, 256, 0, s>>>((int)n, (int)S, ent, cls_ptr, Qhat, descA, descB, atol, out);
+}
+
 void complex_set_device_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_heev_jacobi64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         150 * 1024);

@@ -203,6 +203,8 @@ void launch_cx_block_norms_general(hipStream_t s, int64_t n, int64_t ldn, const 
                                    int neig, unsigned long long* norms);
 void launch_cx_irreducible_general(hipStream_t s, int64_t n, const double* Hr, const double* Hi, const double* Vr, const double* Vi,
                                    const int32_t* desc, int ncols, double atol, double* Qhat);
+void launch_cx_basis_image_sorted(hipStream_t s, int64_t n, int64_t d, int64_t S, const uint32_t* ent, const int64_t* cls_ptr,
+                                  const double* Qhat, const int32_t* descA, const int32_t* descB, double atol, double* out);
 void launch_cx_gather_herm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, double* Hr, double* Hi);
 void launch_cx_heev(hipStream_t s, int64_t n, const double* Hr, const double* Hi, double* w, double* Vr, double* Vi, int* info);
 void launch_cx_block_norms(hipStream_t s, int64_t n, const double* Hr, const double* Hi, const double* Vr, const double* Vi,
