@@ -91,6 +91,7 @@ def load_library():
         "sdpsr_block_images_complex": (C.c_int, [vp, vp, vp, C.c_int]),
         "sdpsr_eigen_decomposition_batched": (C.c_int, [vp, i64, vp, i64, dbl, i64, vp, vp, vp, vp, C.c_int]),
         "sdpsr_syev_f64": (C.c_int, [vp, i64, vp, vp, vp, C.c_int]),
+        "sdpsr_hint_symmetric_basis": (C.c_int, [vp, C.c_int]),
         "sdpsr_profile_kernel": (C.c_int, [vp, C.c_int, i64, i64, C.c_int, C.POINTER(C.c_double)]),
         "sdpsr_profile_clock": (C.c_int, [vp, C.c_int, i64, i64, C.c_int, C.POINTER(C.c_double)]),
     }

@@ -293,7 +293,27 @@ def admissible_setup(C_, A, b, atol=RTOL_DEFAULT):
 
     CL = symm(clamp_round_host(c - proj(c), atol))
     X0L = clamp_round_host(proj(symm(x0)), atol)
-    return n, np.ascontiguousarray(CL), np.ascontiguousarray(X0L), U
+    return Setup((n, np.ascontiguousarray(CL), np.ascontiguousarray(X0L), U), basis_is_symmetric(n, U))
+
+
+class Setup(tuple):
+    """(n, CL, X0L, U) of ``admissible_setup`` plus ``basis_symmetric``: every column of U is a
+    symmetric n x n matrix (passed to the library as ``sdpsr_hint_symmetric_basis``)."""
+
+    def __new__(cls, items, basis_symmetric=False):
+        t = super().__new__(cls, items)
+        t.basis_symmetric = bool(basis_symmetric)
+        return t
+
+
+def basis_is_symmetric(n, U, tol=1e-12):
+    """True if every column of U (n^2 x r), reshaped column-major to n x n, is symmetric."""
+    U = np.asarray(U)
+    for k in range(U.shape[1]):
+        M = U[:, k].reshape(n, n, order="F")
+        if not np.allclose(M, M.T, rtol=0.0, atol=tol):
+            return False
+    return True
 
 
 def _admissible_subspace_device_setup(C_, A, b, atol, ctx, verbose):
@@ -333,7 +353,11 @@ def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, se
         m_rows = A.shape[0]
         if m_rows * int(np.prod(np.shape(C_))) * 8 <= (4 << 30):
             return _admissible_subspace_device_setup(C_, A, b, atol, ctx, verbose)
-    n, CL, X0L, U = setup if setup is not None else admissible_setup(C_, A, b, atol)
+    if setup is None:
+        setup = admissible_setup(C_, A, b, atol)
+    n, CL, X0L, U = setup
+    if getattr(setup, "basis_symmetric", False):
+        ctx._lib.sdpsr_hint_symmetric_basis(ctx._h, 1)  # applies to the call below only
     on_dev = _is_torch(CL)
     r = U.shape[1]
     if on_dev:

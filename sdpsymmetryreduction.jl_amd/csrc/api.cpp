@@ -496,6 +496,12 @@ int sdpsr_wait_stream(sdpsr_ctx* c, void* hip_stream) {
     return SDPSR_OK;
 }
 
+int sdpsr_hint_symmetric_basis(sdpsr_ctx* c, int yes) {
+    if (!c) return SDPSR_BAD_ARGUMENT;
+    c->hint_symmetric_basis = yes ? 1 : 0;
+    return SDPSR_OK;
+}
+
 int sdpsr_set_seed(sdpsr_ctx* c, uint64_t seed) {
     if (!c) return SDPSR_BAD_ARGUMENT;
     c->seed = seed;
@@ -723,8 +729,8 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     uint32_t* L = out_dev(c, "adm_labels", P_out, len, mem, &st);
     uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
     const int nblk = 2048;
-    double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * nblk * 8);
-    double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
+    double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)2 * std::max<int64_t>(r, 1) * nblk * 8);  // + the symmetry probes
+    double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)2 * std::max<int64_t>(r, 1) * 8);
     uint32_t* symflag = (uint32_t*)ctx_buf(c, "adm_symflag", 64);  // [0] verdict of the last check, [8] constant 0
     if (st || !sig || !partial || !coef || !symflag) return st ? st : SDPSR_OUT_OF_MEMORY;
     HIP_TRY(c, hipMemsetAsync(symflag, 0, 64, s));
@@ -769,12 +775,20 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         q.sig = sig;
         q.a = dCL;
         q.b = dX0;
-        st = refine_signatures(c, len, q, L, &d);
+        st = refine_signatures(c, len, q, L, &d, n, symflag, &labels_sym);  // + symmetry verdict of the initial partition
     }
     tm.end();
     if (st) return st;
     HIP_TRY(c, hipStreamSynchronize(s));
     tm.collect();
+    // Projection on the lower triangle (half the bytes and hashes of the step) needs symmetric
+    // labels AND symmetric basis matrices U_k.  The caller may vouch for the latter
+    // (sdpsr_hint_symmetric_basis); otherwise the first iteration's dot-product pass carries a
+    // randomized symmetry probe and the following iterations use its verdict.
+    bool basis_sym = (r == 0) || c->hint_symmetric_basis != 0;
+    bool probe_pending = !basis_sym;
+    c->hint_symmetric_basis = 0;  // one call only
+    double* probe_host = nullptr;
 
     const int64_t maximal = (len + n) / 2;  // :148
     int64_t current = d;
@@ -787,8 +801,22 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         // --- random projection (:159-164) ---
         tm.begin(SDPSR_T_PROJECT);
         const uint64_t key = next_key(c);
-        launch_proj_coef(s, len, r, dU, L, key, nullptr, partial, nblk, coef);
         const bool int_mode = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
+        const bool packed_proj = int_mode && labels_sym && basis_sym && r <= 4 && len < (int64_t(1) << 32);
+        bool probed = false;
+        if (packed_proj) {
+            launch_proj_coef_lower(s, n, r, dU, L, key, partial, nblk, coef);
+        } else if (probe_pending && int_mode && len < (int64_t(1) << 32)) {
+            launch_proj_coef_probe(s, len, n, r, dU, L, key, partial, nblk, coef);
+            probe_host = (double*)c->pinned + 64;  // c->pinned[0..63] carries the refinement's counters
+            if ((size_t)(r + 64) * 8 > c->pinned_bytes) probe_host = nullptr;
+            if (probe_host) {
+                HIP_TRY(c, hipMemcpyAsync(probe_host, coef + r, (size_t)r * 8, hipMemcpyDeviceToHost, s));
+                probed = true;
+            }
+        } else {
+            launch_proj_coef(s, len, r, dU, L, key, nullptr, partial, nblk, coef);
+        }
         SigSource qp;  // integer modes: y = round(x - U coef) exists only inside the insert pass of the refinement
         qp.sig = sig;
         if (Y) {
@@ -802,13 +830,30 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             qp.key = key;
             qp.atol = atol;
             qp.scale = scale;
+            qp.n = n;
+            qp.packed = packed_proj ? 1 : 0;
         }
         tm.end();
         tm.begin(SDPSR_T_REFINE);
         int64_t d1 = 0;
-        st = refine_signatures(c, len, qp, L, &d1, int_mode ? n : 0, symflag, &labels_sym);
+        if (packed_proj) {
+            // symmetric by construction: refine the packed lower triangle, mirror it (as after the squares)
+            const int64_t lenp = n * (n + 1) / 2;
+            uint32_t* Lp = (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4);
+            if (!Lp) return SDPSR_OUT_OF_MEMORY;
+            st = refine_signatures(c, lenp, qp, Lp, &d1);
+            if (!st) launch_unpack_symmetric_labels(s, n, Lp, L);
+        } else {
+            st = refine_signatures(c, len, qp, L, &d1, int_mode ? n : 0, symflag, &labels_sym);
+        }
         tm.end();
         if (st) return st;
+        if (probed) {  // the refinement has synchronised the stream: the probes are in
+            probe_pending = false;
+            basis_sym = true;
+            for (int64_t k = 0; k < r; ++k)
+                if (!(std::fabs(probe_host[k]) <= 1e-10)) basis_sym = false;  // |U_k| = 1 (orthonormal basis)
+        }
         // --- random square (:166-174) ---
         int64_t d2 = d1;
         for (;;) {

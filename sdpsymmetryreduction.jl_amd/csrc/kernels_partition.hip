@@ -345,6 +345,123 @@ void launch_proj_apply(hipStream_t s, int64_t len, int64_t r, const double* U, c
 }
 
 // ---------------------------------------------------------------------------
+// Projection on the lower triangle.  With symmetric labels (x symmetric) and symmetric basis
+// matrices U_k the products U_k'x and the projected element need the entries i >= j only
+// (off-diagonal ones count twice in the dot products): half the bytes and half the hashes of the
+// projection step; the refinement then runs on the packed lower triangle like the one of the squares.
+// ---------------------------------------------------------------------------
+// (i, j), i >= j, of packed index e: column j starts at off(j) = j n - j (j - 1) / 2
+__device__ __forceinline__ void packed_lower_ij(int n, int64_t e, uint32_t& i, uint32_t& j) {
+    const float t = (float)(2 * n + 1);
+    int jj = (int)((t - sqrtf(fmaxf(t * t - 8.0f * (float)e, 0.0f))) * 0.5f);
+    jj = jj < 0 ? 0 : (jj > n - 1 ? n - 1 : jj);
+    while ((int64_t)jj * n - (int64_t)jj * (jj - 1) / 2 > e) --jj;
+    while (jj + 1 < n && (int64_t)(jj + 1) * n - (int64_t)(jj + 1) * jj / 2 <= e) ++jj;
+    j = (uint32_t)jj;
+    i = j + (uint32_t)(e - ((int64_t)jj * n - (int64_t)jj * (jj - 1) / 2));
+}
+
+// grid = (nblk, r): workgroups stride over the columns, threads over the rows i >= j of a column
+__global__ void proj_coef_lower_kernel(int n, const double* __restrict__ U, const uint32_t* __restrict__ L, uint64_t key,
+                                       double* __restrict__ partial) {
+    __shared__ double sh[8];
+    const int k = blockIdx.y;
+    const double* Uk = U + (int64_t)k * n * n;
+    double a0 = 0, a1 = 0;
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        const double* Uj = Uk + (int64_t)j * n;
+        const uint32_t* Lj = L + (int64_t)j * n;
+        int i = j + threadIdx.x;
+        for (; i + (int)blockDim.x < n; i += 2 * blockDim.x) {
+            const double u0 = Uj[i], u1 = Uj[i + blockDim.x];
+            const uint32_t l0 = Lj[i], l1 = Lj[i + blockDim.x];
+            const double x0 = l0 ? sdpsr_class_uniform(key, l0) : 0.0, x1 = l1 ? sdpsr_class_uniform(key, l1) : 0.0;
+            a0 = fma(i == j ? u0 : 2.0 * u0, x0, a0);
+            a1 = fma(2.0 * u1, x1, a1);
+        }
+        if (i < n) {
+            const uint32_t l0 = Lj[i];
+            const double u0 = Uj[i], x0 = l0 ? sdpsr_class_uniform(key, l0) : 0.0;
+            a0 = fma(i == j ? u0 : 2.0 * u0, x0, a0);
+        }
+    }
+    const double r = block_reduce_sum(a0 + a1, sh);
+    if (threadIdx.x == 0) partial[(int64_t)k * gridDim.x + blockIdx.x] = r;
+}
+void launch_proj_coef_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
+                            double* partial, int nblk, double* coef) {
+    if (r <= 0) return;
+    dim3 g(nblk, (unsigned)r);
+    proj_coef_lower_kernel<<<g, 256, 0, s>>>((int)n, U, L, key, partial);
+    proj_coef_final_kernel<<<(unsigned)r, 256, 0, s>>>(nblk, partial, coef);
+}
+
+// Symmetry probe of the basis matrices, riding on the full dot-product pass of the first
+// iteration: with W[i,j] = w(i + j n) pseudo-random, <U_k, W - W'> = 0 for a symmetric U_k and a
+// random number of size ~|U_k - U_k'| otherwise.  partial rows r .. 2r-1.
+__global__ void proj_coef_probe_kernel(int64_t len, int n, const double* __restrict__ U, const uint32_t* __restrict__ L,
+                                       uint64_t key, double* __restrict__ partial, int r) {
+    __shared__ double sh[8];
+    const int k = blockIdx.y;
+    const double* Uk = U + (int64_t)k * len;
+    double acc = 0, pa = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint64_t wkey = key ^ 0x5DEECE66D1CE4E5BULL;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const double u = Uk[e];
+        const uint32_t l = L[e];
+        acc = fma(u, l ? sdpsr_class_uniform(key, l) : 0.0, acc);
+        const uint32_t j = (uint32_t)e / (uint32_t)n, i = (uint32_t)e - j * (uint32_t)n;
+        const uint64_t et = (uint64_t)j + (uint64_t)i * (uint32_t)n;
+        const double w = (double)(sdpsr_fmix64(wkey + (uint64_t)e) >> 11) - (double)(sdpsr_fmix64(wkey + et) >> 11);
+        pa = fma(u, w * (1.0 / 9007199254740992.0), pa);
+    }
+    double t = block_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) partial[(int64_t)k * gridDim.x + blockIdx.x] = t;
+    __syncthreads();
+    t = block_reduce_sum(pa, sh);
+    if (threadIdx.x == 0) partial[(int64_t)(r + k) * gridDim.x + blockIdx.x] = t;
+}
+// coef[0..r) = U'x, coef[r..2r) = the symmetry probes
+void launch_proj_coef_probe(hipStream_t s, int64_t len, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
+                            double* partial, int nblk, double* coef) {
+    if (r <= 0) return;
+    dim3 g(nblk, (unsigned)r);
+    proj_coef_probe_kernel<<<g, 256, 0, s>>>(len, (int)n, U, L, key, partial, (int)r);
+    proj_coef_final_kernel<<<(unsigned)(2 * r), 256, 0, s>>>(nblk, partial, coef);
+}
+
+// proj_apply on the lower triangle, signatures packed (column j at offset j n - j (j - 1) / 2): the
+// stand-alone form of SrcProj<R> with packed = 1 (sort path / r > 4)
+__global__ void proj_apply_lower_kernel(int n, int r, const double* __restrict__ U, const uint32_t* __restrict__ L, uint64_t key,
+                                        const double* __restrict__ coef, double atol, double scale, uint64_t* __restrict__ sig) {
+    const int64_t len = (int64_t)n * n;
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        uint64_t* sj = sig + ((int64_t)j * n - (int64_t)j * (j - 1) / 2 - j);
+        for (int i = j + threadIdx.x; i < n; i += blockDim.x) {
+            const int64_t e = i + (int64_t)j * n;
+            const uint32_t l = L[e];
+            const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
+            double p = 0;
+            for (int k = 0; k < r; ++k) p = fma(U[(int64_t)k * len + e], coef[k], p);
+            const double y = sdpsr_clamp_round(x - p, atol, scale);
+            const uint64_t kb = (uint64_t)__double_as_longlong(y);
+            uint64_t h = 0;
+            if (l != 0 || kb != 0) {
+                h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
+                if (h == 0) h = 1;
+            }
+            sj[i] = h;
+        }
+    }
+}
+void launch_proj_apply_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
+                             const double* coef, double atol, double scale, uint64_t* sig) {
+    const int g = (int)(n < 256 * 8 ? n : 256 * 8);
+    proj_apply_lower_kernel<<<g, 256, 0, s>>>((int)n, (int)r, U, L, key, coef, atol, scale, sig);
+}
+
+// ---------------------------------------------------------------------------
 // signatures
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t finish_sig(uint32_t l, bool all_zero, uint64_t h) {
@@ -499,7 +616,13 @@ struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig onl
     int64_t len;
     uint64_t key;
     double atol, scale;
+    int n, packed;  // packed: e runs over the lower triangle column by column (symmetric labels and basis)
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        if (packed) {
+            uint32_t i, j;
+            packed_lower_ij(n, e, i, j);
+            e = (int64_t)i + (int64_t)j * n;
+        }
         const uint32_t l = L[e];
         double u[R > 0 ? R : 1];
 #pragma unroll
@@ -528,14 +651,7 @@ struct SrcChan {  // sig_channels_kernel; packed: e runs over the lower triangle
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         uint32_t i, j;
         if (packed) {
-            // column j starts at off(j) = j n - j (j - 1) / 2
-            const float t = (float)(2 * n + 1);
-            int jj = (int)((t - sqrtf(fmaxf(t * t - 8.0f * (float)e, 0.0f))) * 0.5f);
-            jj = jj < 0 ? 0 : (jj > n - 1 ? n - 1 : jj);
-            while ((int64_t)jj * n - (int64_t)jj * (jj - 1) / 2 > e) --jj;
-            while (jj + 1 < n && (int64_t)(jj + 1) * n - (int64_t)(jj + 1) * jj / 2 <= e) ++jj;
-            j = (uint32_t)jj;
-            i = j + (uint32_t)(e - ((int64_t)jj * n - (int64_t)jj * (jj - 1) / 2));
+            packed_lower_ij(n, e, i, j);
         } else {
             j = (uint32_t)e / (uint32_t)n;
             i = (uint32_t)e - j * (uint32_t)n;
@@ -1046,7 +1162,10 @@ bool sig_source_fusable(const SigSource& q) {
 void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint64_t* sig) {
     switch (q.kind) {
         case SIG_PAIR: launch_sig_f64_pair(s, len, q.a, q.b, sig); break;
-        case SIG_PROJ: launch_proj_apply(s, len, q.r, q.U, q.L, q.key, nullptr, q.coef, q.atol, q.scale, 1, nullptr, sig); break;
+        case SIG_PROJ:
+            if (q.packed) launch_proj_apply_lower(s, q.n, q.r, q.U, q.L, q.key, q.coef, q.atol, q.scale, sig);
+            else launch_proj_apply(s, len, q.r, q.U, q.L, q.key, nullptr, q.coef, q.atol, q.scale, 1, nullptr, sig);
+            break;
         case SIG_CHAN_I32: launch_sig_i32(s, q.n, q.ld, q.T, q.L, (const int32_t*)q.C, sig, q.zero_flag, q.packed); break;
         case SIG_CHAN_F32: launch_sig_f32(s, q.n, q.ld, q.T, q.L, (const float*)q.C, sig, q.zero_flag, q.packed); break;
         default: break;
@@ -1067,11 +1186,11 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
         case SIG_PAIR: launch_insert<SrcPair, 8>(s, gcap, len, SrcPair{q.a, q.b}, slot, ws, cap); break;
         case SIG_PROJ:
             switch (q.r) {
-                case 0: launch_insert<SrcProj<0>, 8>(s, gcap, len, SrcProj<0>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
-                case 1: launch_insert<SrcProj<1>, 8>(s, gcap, len, SrcProj<1>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
-                case 2: launch_insert<SrcProj<2>, 8>(s, gcap, len, SrcProj<2>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
-                case 3: launch_insert<SrcProj<3>, 8>(s, gcap, len, SrcProj<3>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
-                default: launch_insert<SrcProj<4>, 8>(s, gcap, len, SrcProj<4>{q.U, q.L, q.coef, len, q.key, q.atol, q.scale}, slot, ws, cap); break;
+                case 0: launch_insert<SrcProj<0>, 8>(s, gcap, len, SrcProj<0>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
+                case 1: launch_insert<SrcProj<1>, 8>(s, gcap, len, SrcProj<1>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
+                case 2: launch_insert<SrcProj<2>, 8>(s, gcap, len, SrcProj<2>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
+                case 3: launch_insert<SrcProj<3>, 8>(s, gcap, len, SrcProj<3>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
+                default: launch_insert<SrcProj<4>, 8>(s, gcap, len, SrcProj<4>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
             }
             break;
         case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;

@@ -54,6 +54,7 @@ struct sdpsr_ctx {
     uint32_t bd_sym_epoch = 0;            // != 0: "bd_symflag"[0] == epoch <=> bd_sym_labels are NOT symmetric (copy + check pass of blockDiagonalize)
     const uint32_t* bd_sym_labels = nullptr;
     uint32_t epoch_counter = 0;
+    int hint_symmetric_basis = 0;         // sdpsr_hint_symmetric_basis: applies to the next admissible_subspace call
     bool bd_q_valid = false;  // "bd_qhat" holds Q_hat of the last diagonalize (even when check_block_sizes failed)
     bool bd_labels_owned = false;
     // hash table capacity hint (log2) for the next refine
@@ -104,6 +105,12 @@ void launch_proj_coef(hipStream_t s, int64_t len, int64_t r, const double* U, co
                       uint64_t key, const double* xin, double* partial, int nblk, double* coef);
 // y[e] = x[e] - sum_k U[e,k] coef[k]; optional outputs: yout (rounded value, fp64),
 // sig (signature chained on L).  x as above.
+void launch_proj_coef_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
+                            double* partial, int nblk, double* coef);
+void launch_proj_coef_probe(hipStream_t s, int64_t len, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
+                            double* partial, int nblk, double* coef);
+void launch_proj_apply_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
+                             const double* coef, double atol, double scale, uint64_t* sig);
 void launch_proj_apply(hipStream_t s, int64_t len, int64_t r, const double* U, const uint32_t* L,
                        uint64_t key, const double* xin, const double* coef, double atol,
                        double scale, int do_round, double* yout, uint64_t* sig);
@@ -152,7 +159,7 @@ struct SigSource {
     int64_t n = 0, ld = 0;                                        // SIG_CHAN_* (launch_sig_i32 / launch_sig_f32)
     int T = 0;
     const void* C = nullptr;
-    int packed = 0;                                               // lower triangle only, densely packed (symmetric labels)
+    int packed = 0;                                               // lower triangle only, densely packed (symmetric labels; SIG_PROJ: and symmetric basis, needs n)
     const uint32_t* zero_flag = nullptr;                          // device constant 0 when packed (the kernels' "lower" flag)
 };
 bool sig_source_fusable(const SigSource& q);

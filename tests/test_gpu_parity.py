@@ -817,3 +817,35 @@ def test_complex_path_beyond_one_workgroup(pkg, problems, oracle, gpu_ctx):
             full, blk = oracle.spectrum_invariant_complex(oracle.Partition(Pd.nparts, np.asarray(Pd.matrix).astype(np.int64)), bd.blks, x)
             assert len(full) == len(blk)
             assert np.allclose(full, blk, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_projection_on_the_lower_triangle(pkg, problems, golden):
+    """With symmetric labels and symmetric basis matrices the projection step runs on the lower
+    triangle: vouched for by the caller (sdpsr_hint_symmetric_basis, set by the wrapper from the
+    host setup), or found by the randomized probe of the first iteration (plain tuple: no hint).
+    Both must give the golden partition, as must a basis that is NOT symmetric (probe says no)."""
+    for name, q in (("er5", 5), ("er7", 7)):
+        Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(q))
+        setup = pkg.admissible_setup(Cv, A, b)
+        assert setup.basis_symmetric
+        for seed in (1, 2, 3):
+            with pkg.Context(seed=seed) as ctx:
+                P1 = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)            # hint
+                P2 = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=tuple(setup))     # probe
+                assert np.array_equal(P1.matrix, golden[f"{name}_P"]) and np.array_equal(P2.matrix, golden[f"{name}_P"])
+    # a non-symmetric constraint matrix: U has a non-symmetric column, the projected element is not
+    # symmetric, the probe must keep the full pass (result: the oracle's partition, checked by dim here
+    # through the device-setup path, which never hints)
+    Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(5))
+    n = int(round(np.sqrt(A.shape[1])))
+    extra = np.zeros((n, n))
+    extra[0, 1] = 1.0  # E_01 alone: not symmetric
+    A2 = np.vstack([A, extra.ravel(order="F")[None, :]])
+    b2 = np.concatenate([b, [0.0]])
+    s2 = pkg.admissible_setup(Cv, A2, b2)
+    assert not s2.basis_symmetric
+    with pkg.Context(seed=4) as ctx:
+        Pa = pkg.admissible_subspace(Cv, A2, b2, ctx=ctx, setup=s2)
+        Pb = pkg.admissible_subspace(Cv, A2, b2, ctx=ctx)  # device setup, probe
+        assert Pa.nparts == Pb.nparts and np.array_equal(Pa.matrix, Pb.matrix)
