@@ -101,7 +101,7 @@ class Workload:
         n, CL, X0L, U = setup
         # the host setup knows whether the basis matrices are symmetric (they are whenever the
         # constraint matrices are); the loop is told before every call (sdpsr_hint_symmetric_basis)
-        self.basis_symmetric = bool(getattr(setup, "basis_symmetric", False))
+        self.hint = int(getattr(setup, "hint", 0))
         self.n, self.d, self.blocks = n, int(d), sorted(blocks)
         self.r = U.shape[1]
         self.tCL = torch.from_numpy(CL).to(dev)
@@ -182,8 +182,8 @@ def main():
         dd = C.c_int64(0)
         it = C.c_int32(0)
         ms = (C.c_double * L.T_COUNT)()
-        if w.basis_symmetric:
-            lib.sdpsr_hint_symmetric_basis(cx._h, 1)
+        if w.hint:
+            lib.sdpsr_hint_symmetric_basis(cx._h, w.hint)
         cx.check(lib.sdpsr_admissible_subspace(cx._h, w.n, vp(w.tCL), vp(w.tX0), vp(w.tU), w.r, ATOL, vp(w.tP), C.byref(dd),
                                                C.byref(it), C.cast(ms, C.c_void_p), L.MEM_DEVICE))
         acc.iters += it.value

@@ -114,11 +114,15 @@ int sdpsr_synchronize(sdpsr_ctx* ctx);
    NULL = the legacy default stream) so far: event record + hipStreamWaitEvent, no host wait.
    For device-resident arguments produced by the caller's own kernels. */
 int sdpsr_wait_stream(sdpsr_ctx* ctx, void* hip_stream);
-/* Hint for the NEXT sdpsr_admissible_subspace call on this ctx: the columns of U, read as n x n
-   matrices, are symmetric (true whenever the constraint matrices A_i are; a host-side setup
-   knows).  With symmetric labels the projection step then works on the lower triangle only (half
-   the bytes).  Without the hint the first iteration's dot-product pass carries a randomized
-   symmetry probe (<U_k, W - W'> for a pseudo-random W) and later iterations use its verdict. */
+/* Hints for the NEXT sdpsr_admissible_subspace call on this ctx (bit mask `yes`):
+   bit 0: the columns of U, read as n x n matrices, are symmetric (true whenever the constraint
+          matrices A_i are; a host-side setup knows).  With symmetric labels the projection step then
+          works on the lower triangle only (half the bytes).  Without it the first iteration's
+          dot-product pass carries a randomized symmetry probe (<U_k, W - W'> for a pseudo-random W)
+          and later iterations use its verdict.
+   bit 1: CL and X0L are symmetric (the reference symmetrises both, src/partitions.jl:128-141): the
+          initial partition is formed from the lower triangle.
+   A wrong hint is the caller's error (the result is then the partition of the mirrored lower triangle). */
 int sdpsr_hint_symmetric_basis(sdpsr_ctx* ctx, int yes);
 /* Reseed (tests; independent restarts use distinct seeds per rank). */
 int sdpsr_set_seed(sdpsr_ctx* ctx, uint64_t seed);

@@ -293,16 +293,22 @@ def admissible_setup(C_, A, b, atol=RTOL_DEFAULT):
 
     CL = symm(clamp_round_host(c - proj(c), atol))
     X0L = clamp_round_host(proj(symm(x0)), atol)
-    return Setup((n, np.ascontiguousarray(CL), np.ascontiguousarray(X0L), U), basis_is_symmetric(n, U))
+    CL, X0L = np.ascontiguousarray(CL), np.ascontiguousarray(X0L)
+    m1, m2 = CL.reshape(n, n, order="F"), X0L.reshape(n, n, order="F")
+    return Setup((n, CL, X0L, U), basis_is_symmetric(n, U), bool(np.array_equal(m1, m1.T) and np.array_equal(m2, m2.T)))
 
 
 class Setup(tuple):
-    """(n, CL, X0L, U) of ``admissible_setup`` plus ``basis_symmetric``: every column of U is a
-    symmetric n x n matrix (passed to the library as ``sdpsr_hint_symmetric_basis``)."""
+    """(n, CL, X0L, U) of ``admissible_setup`` plus what the host knows about symmetry:
+    ``basis_symmetric`` (every column of U is a symmetric n x n matrix) and ``inputs_symmetric``
+    (CL and X0L are exactly symmetric, as the reference's setup makes them).  ``hint`` is the bit
+    mask for ``sdpsr_hint_symmetric_basis``."""
 
-    def __new__(cls, items, basis_symmetric=False):
+    def __new__(cls, items, basis_symmetric=False, inputs_symmetric=False):
         t = super().__new__(cls, items)
         t.basis_symmetric = bool(basis_symmetric)
+        t.inputs_symmetric = bool(inputs_symmetric)
+        t.hint = (1 if basis_symmetric else 0) | (2 if inputs_symmetric else 0)
         return t
 
 
@@ -356,8 +362,8 @@ def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, se
     if setup is None:
         setup = admissible_setup(C_, A, b, atol)
     n, CL, X0L, U = setup
-    if getattr(setup, "basis_symmetric", False):
-        ctx._lib.sdpsr_hint_symmetric_basis(ctx._h, 1)  # applies to the call below only
+    if getattr(setup, "hint", 0):
+        ctx._lib.sdpsr_hint_symmetric_basis(ctx._h, int(setup.hint))  # applies to the call below only
     on_dev = _is_torch(CL)
     r = U.shape[1]
     if on_dev:

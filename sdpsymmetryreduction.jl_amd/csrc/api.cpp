@@ -498,7 +498,7 @@ int sdpsr_wait_stream(sdpsr_ctx* c, void* hip_stream) {
 
 int sdpsr_hint_symmetric_basis(sdpsr_ctx* c, int yes) {
     if (!c) return SDPSR_BAD_ARGUMENT;
-    c->hint_symmetric_basis = yes ? 1 : 0;
+    c->hint_symmetric_basis = yes & 3;
     return SDPSR_OK;
 }
 
@@ -775,7 +775,20 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         q.sig = sig;
         q.a = dCL;
         q.b = dX0;
-        st = refine_signatures(c, len, q, L, &d, n, symflag, &labels_sym);  // + symmetry verdict of the initial partition
+        if ((c->hint_symmetric_basis & 2) && len < (int64_t(1) << 32)) {
+            // the caller vouches for symmetric CL / X0L (the reference symmetrises both,
+            // src/partitions.jl:128-141): the initial partition from the lower triangle, mirrored
+            const int64_t lenp = n * (n + 1) / 2;
+            uint32_t* Lp = (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4);
+            if (!Lp) return SDPSR_OUT_OF_MEMORY;
+            q.n = n;
+            q.packed = 1;
+            st = refine_signatures(c, lenp, q, Lp, &d);
+            if (!st) launch_unpack_symmetric_labels(s, n, Lp, L);
+            labels_sym = 1;
+        } else {
+            st = refine_signatures(c, len, q, L, &d, n, symflag, &labels_sym);  // + symmetry verdict of the initial partition
+        }
     }
     tm.end();
     if (st) return st;
@@ -785,7 +798,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     // labels AND symmetric basis matrices U_k.  The caller may vouch for the latter
     // (sdpsr_hint_symmetric_basis); otherwise the first iteration's dot-product pass carries a
     // randomized symmetry probe and the following iterations use its verdict.
-    bool basis_sym = (r == 0) || c->hint_symmetric_basis != 0;
+    bool basis_sym = (r == 0) || (c->hint_symmetric_basis & 1) != 0;
     bool probe_pending = !basis_sym;
     c->hint_symmetric_basis = 0;  // one call only
     double* probe_host = nullptr;

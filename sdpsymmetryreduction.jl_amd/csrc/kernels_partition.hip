@@ -495,6 +495,20 @@ __global__ void sig_f64_pair_kernel(int64_t len, const double* __restrict__ a, c
         sig[e] = finish_sig(0u, ka == 0 && kb == 0, h);
     }
 }
+// the pair signatures of the lower triangle, packed (column j at offset j n - j (j - 1) / 2)
+__global__ void sig_f64_pair_lower_kernel(int n, const double* __restrict__ a, const double* __restrict__ b,
+                                          uint64_t* __restrict__ sig) {
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        uint64_t* sj = sig + ((int64_t)j * n - (int64_t)j * (j - 1) / 2 - j);
+        for (int i = j + threadIdx.x; i < n; i += blockDim.x) {
+            const int64_t e = i + (int64_t)j * n;
+            const uint64_t ka = (uint64_t)__double_as_longlong(a[e]);
+            const uint64_t kb = (uint64_t)__double_as_longlong(b[e]);
+            const uint64_t h = sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb);
+            sj[i] = finish_sig(0u, ka == 0 && kb == 0, h);
+        }
+    }
+}
 void launch_sig_f64_pair(hipStream_t s, int64_t len, const double* a, const double* b, uint64_t* sig) {
     sig_f64_pair_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, a, b, sig);
 }
@@ -598,10 +612,16 @@ struct SrcArray {
     const uint64_t* __restrict__ sig;
     __device__ __forceinline__ uint64_t operator()(int64_t e) const { return __builtin_nontemporal_load(&sig[e]); }
 };
-struct SrcPair {  // sig_f64_pair_kernel
+struct SrcPair {  // sig_f64_pair_kernel; packed: e runs over the lower triangle column by column (a, b symmetric)
     const double* __restrict__ a;
     const double* __restrict__ b;
+    int n, packed;
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        if (packed) {
+            uint32_t i, j;
+            packed_lower_ij(n, e, i, j);
+            e = (int64_t)i + (int64_t)j * n;
+        }
         const uint64_t ka = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(&a[e]));
         const uint64_t kb = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(&b[e]));
         const uint64_t h = sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb);
@@ -1161,7 +1181,10 @@ bool sig_source_fusable(const SigSource& q) {
 // instance for): the stand-alone kernels
 void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint64_t* sig) {
     switch (q.kind) {
-        case SIG_PAIR: launch_sig_f64_pair(s, len, q.a, q.b, sig); break;
+        case SIG_PAIR:
+            if (q.packed) sig_f64_pair_lower_kernel<<<(int)(q.n < 2048 ? q.n : 2048), 256, 0, s>>>((int)q.n, q.a, q.b, sig);
+            else launch_sig_f64_pair(s, len, q.a, q.b, sig);
+            break;
         case SIG_PROJ:
             if (q.packed) launch_proj_apply_lower(s, q.n, q.r, q.U, q.L, q.key, q.coef, q.atol, q.scale, sig);
             else launch_proj_apply(s, len, q.r, q.U, q.L, q.key, nullptr, q.coef, q.atol, q.scale, 1, nullptr, sig);
@@ -1183,7 +1206,7 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
     const int per_cu = (ws.log2cap <= 16) ? 4 : 5;  // many classes: bound by the global table, a few more workgroups help
     const int gcap = 256 * per_cu;
     switch (q.kind) {
-        case SIG_PAIR: launch_insert<SrcPair, 8>(s, gcap, len, SrcPair{q.a, q.b}, slot, ws, cap); break;
+        case SIG_PAIR: launch_insert<SrcPair, 8>(s, gcap, len, SrcPair{q.a, q.b, (int)q.n, q.packed}, slot, ws, cap); break;
         case SIG_PROJ:
             switch (q.r) {
                 case 0: launch_insert<SrcProj<0>, 8>(s, gcap, len, SrcProj<0>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;

@@ -111,9 +111,9 @@ function SR.admissible_subspace(::Type{HIPPartition}, C::AbstractVector{T}, A::A
     x0, _ = SR.Krylov.craig(A, b); SR._symmetrize!(x0, n); x0 = proj(x0); SR._clamp_round!(x0, atol=atol)
     P = Matrix{UInt32}(undef, n, n); d = Ref{Int64}(0); it = Ref{Int32}(0); cx = ctx()
     # symmetric basis matrices (the usual case): the projection step may work on the lower triangle
-    if all(k -> (M = reshape(view(U, :, k), n, n); isapprox(M, M'; atol=1e-12, rtol=0)), 1:size(U, 2))
-        ccall((:sdpsr_hint_symmetric_basis, libsdpsr), Cint, (Ptr{Cvoid}, Cint), cx.handle, 1)
-    end
+    # (bit 1: c and x0 were symmetrised above)
+    hint = 2 | (all(k -> (M = reshape(view(U, :, k), n, n); isapprox(M, M'; atol=1e-12, rtol=0)), 1:size(U, 2)) ? 1 : 0)
+    ccall((:sdpsr_hint_symmetric_basis, libsdpsr), Cint, (Ptr{Cvoid}, Cint), cx.handle, hint)
     check(cx, ccall((:sdpsr_admissible_subspace, libsdpsr), Cint,
                     (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Float64,
                      Ptr{UInt32}, Ref{Int64}, Ref{Int32}, Ptr{Float64}, Cint),

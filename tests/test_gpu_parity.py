@@ -828,7 +828,7 @@ def test_projection_on_the_lower_triangle(pkg, problems, golden):
     for name, q in (("er5", 5), ("er7", 7)):
         Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(q))
         setup = pkg.admissible_setup(Cv, A, b)
-        assert setup.basis_symmetric
+        assert setup.basis_symmetric and setup.inputs_symmetric and setup.hint == 3
         for seed in (1, 2, 3):
             with pkg.Context(seed=seed) as ctx:
                 P1 = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)            # hint
