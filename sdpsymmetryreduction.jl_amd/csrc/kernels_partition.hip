@@ -608,41 +608,77 @@ void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t*
 // each signature from the data the matching sig_* / proj_apply kernel would have read -- the same
 // device functions, so the same bits -- and the 8 bytes per entry never travel through HBM.
 // ---------------------------------------------------------------------------
+// A source is either FLAT (signature of the linear index e) or walks the matrix by (row i, column j):
+// the insert kernel locates the first entry of a thread's chunk once (a division, or the inversion
+// of the packed lower-triangle numbering: a square root and two correction loops) and STEPS from
+// one of its entries to the next (+256 rows, wrapping into the following columns) -- the per-entry
+// inversion cost as much as the hash (packed passes took 100-118 us for half the entries of a
+// 130 us full pass).
+struct IjWalk {
+    // lower: rows j .. n-1 of column j, column-major (packed lower triangle); else the full n x n square
+    __device__ __forceinline__ static void locate(int n, bool lower, int64_t e, uint32_t& i, uint32_t& j) {
+        if (lower) {
+            packed_lower_ij(n, e, i, j);
+        } else {
+            j = (uint32_t)e / (uint32_t)n;
+            i = (uint32_t)e - j * (uint32_t)n;
+        }
+    }
+    __device__ __forceinline__ static void step(int n, bool lower, uint32_t& i, uint32_t& j, uint32_t by) {
+        i += by;
+        while (i >= (uint32_t)n && j < (uint32_t)n) {
+            ++j;
+            i = i - (uint32_t)n + (lower ? j : 0u);
+        }
+    }
+};
 struct SrcArray {
+    static constexpr bool kIJ = false;
     const uint64_t* __restrict__ sig;
+    __device__ __forceinline__ bool walks() const { return false; }
+    __device__ __forceinline__ bool lower() const { return false; }
+    __device__ __forceinline__ int order() const { return 1; }
+    __device__ __forceinline__ uint64_t at(uint32_t, uint32_t) const { return 0; }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const { return __builtin_nontemporal_load(&sig[e]); }
 };
-struct SrcPair {  // sig_f64_pair_kernel; packed: e runs over the lower triangle column by column (a, b symmetric)
+struct SrcPair {  // sig_f64_pair_kernel; packed: the lower triangle column by column (a, b symmetric)
+    static constexpr bool kIJ = true;
     const double* __restrict__ a;
     const double* __restrict__ b;
     int n, packed;
-    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
-        if (packed) {
-            uint32_t i, j;
-            packed_lower_ij(n, e, i, j);
-            e = (int64_t)i + (int64_t)j * n;
-        }
+    __device__ __forceinline__ bool walks() const { return packed != 0; }
+    __device__ __forceinline__ bool lower() const { return true; }
+    __device__ __forceinline__ int order() const { return n; }
+    __device__ __forceinline__ uint64_t flat(int64_t e) const {
         const uint64_t ka = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(&a[e]));
         const uint64_t kb = (uint64_t)__double_as_longlong(__builtin_nontemporal_load(&b[e]));
         const uint64_t h = sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb);
         return finish_sig(0u, ka == 0 && kb == 0, h);
     }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j) const { return flat((int64_t)i + (int64_t)j * n); }
+    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        if (packed) {
+            uint32_t i, j;
+            packed_lower_ij(n, e, i, j);
+            return at(i, j);
+        }
+        return flat(e);
+    }
 };
 template <int R>
 struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig only
+    static constexpr bool kIJ = true;
     const double* __restrict__ U;
     const uint32_t* L;  // may alias the label output of the refinement (read before the entry's own write)
     const double* __restrict__ coef;
     int64_t len;
     uint64_t key;
     double atol, scale;
-    int n, packed;  // packed: e runs over the lower triangle column by column (symmetric labels and basis)
-    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
-        if (packed) {
-            uint32_t i, j;
-            packed_lower_ij(n, e, i, j);
-            e = (int64_t)i + (int64_t)j * n;
-        }
+    int n, packed;  // packed: the lower triangle column by column (symmetric labels and basis)
+    __device__ __forceinline__ bool walks() const { return packed != 0; }
+    __device__ __forceinline__ bool lower() const { return true; }
+    __device__ __forceinline__ int order() const { return n; }
+    __device__ __forceinline__ uint64_t flat(int64_t e) const {
         const uint32_t l = L[e];
         double u[R > 0 ? R : 1];
 #pragma unroll
@@ -660,22 +696,28 @@ struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig onl
         }
         return h;
     }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j) const { return flat((int64_t)i + (int64_t)j * n); }
+    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        if (packed) {
+            uint32_t i, j;
+            packed_lower_ij(n, e, i, j);
+            return at(i, j);
+        }
+        return flat(e);
+    }
 };
 template <typename CT, int T>
-struct SrcChan {  // sig_channels_kernel; packed: e runs over the lower triangle column by column
+struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by column
+    static constexpr bool kIJ = true;
     int n;
     int64_t ld;
     const uint32_t* L;
     const CT* __restrict__ C;
     int packed;
-    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
-        uint32_t i, j;
-        if (packed) {
-            packed_lower_ij(n, e, i, j);
-        } else {
-            j = (uint32_t)e / (uint32_t)n;
-            i = (uint32_t)e - j * (uint32_t)n;
-        }
+    __device__ __forceinline__ bool walks() const { return true; }  // C is ld-strided: (i, j) needed either way
+    __device__ __forceinline__ bool lower() const { return packed != 0; }
+    __device__ __forceinline__ int order() const { return n; }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j) const {
         const uint32_t l = L[(int64_t)j * n + i];
         const CT* Cij = C + (int64_t)j * ld + i;
         int32_t c[T + (T & 1)];
@@ -690,6 +732,11 @@ struct SrcChan {  // sig_channels_kernel; packed: e runs over the lower triangle
             h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[t] | ((uint64_t)(uint32_t)c[t + 1] << 32));
         }
         return finish_sig(l, allz, h);
+    }
+    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        uint32_t i, j;
+        IjWalk::locate(n, packed != 0, e, i, j);
+        return at(i, j);
     }
 };
 
@@ -805,10 +852,23 @@ refine_insert_kernel(int64_t len, const SRC src,
         // all 16 signature loads are issued before the first probe: the probe loop contains LDS
         // atomics, which the compiler will not move global loads across
         uint64_t sgs[INSERT_PER_THREAD];
+        if (SRC::kIJ && src.walks()) {  // uniform
+            const int nn = src.order();
+            const bool low = src.lower();
+            uint32_t wi = 0, wj = 0;
+            if (base + threadIdx.x < len) IjWalk::locate(nn, low, base + threadIdx.x, wi, wj);
 #pragma unroll
-        for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-            const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-            sgs[q] = (e < len) ? src(e) : 0ull;
+            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
+                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+                sgs[q] = (e < len) ? src.at(wi, wj) : 0ull;
+                IjWalk::step(nn, low, wi, wj, REFINE_THREADS);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
+                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+                sgs[q] = (e < len) ? src(e) : 0ull;
+            }
         }
 #pragma unroll
         for (int q = 0; q < INSERT_PER_THREAD; ++q) {
