@@ -1207,7 +1207,7 @@ static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SR
                           size_t cap) {
     const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
     static const int per_cu_env = getenv("SDPSR_INSERT_WGS_PER_CU") ? atoi(getenv("SDPSR_INSERT_WGS_PER_CU")) : 0;  // measurement knob
-    if (SLOTS == 1024) g_chunks_cap = 256 * (per_cu_env > 0 ? per_cu_env : 7);
+    if (SLOTS == 1024) g_chunks_cap = 256 * (per_cu_env > 0 ? per_cu_env : 5);  // measured 2..8: 5 is the minimum of a flat curve
     const int g = (int)(nchunk < g_chunks_cap ? nchunk : g_chunks_cap);
     refine_insert_kernel<SRC, PER, SLOTS><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                                 (uint32_t)(cap - 1), ws.counters);
