@@ -766,6 +766,22 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     const double sigdigits = std::floor(-std::log10(atol));  // src/utils.jl:37
     const double scale = std::pow(10.0, sigdigits);
 
+    // Symmetric labels live as the packed lower triangle Lp (column j at offset j n - j (j - 1) / 2)
+    // between the refinements of the int8 loop: every consumer there reads the packed form (the
+    // channel gather mirrors it tile by tile), the full matrix L is formed once at the end -- or
+    // whenever a step needs it (non-symmetric basis, other square modes).
+    const int64_t lenp = n * (n + 1) / 2;
+    const bool int_modes = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
+    uint32_t* Lp = int_modes ? (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4) : nullptr;
+    if (int_modes && !Lp) return SDPSR_OUT_OF_MEMORY;
+    const bool keep_packed = mode == SDPSR_SQUARE_I8 && (T == 1 || T == 2 || T == 4) && !getenv("SDPSR_UNPACK_EVERY_STEP");
+    bool full_valid = true, packed_valid = false;
+    auto need_full = [&]() {
+        if (!full_valid) {
+            launch_unpack_symmetric_labels(s, n, Lp, L);
+            full_valid = true;
+        }
+    };
     // S = Part(CL); S = refine!(S, Part(X0L))   (:145-146)
     int64_t d = 0;
     tm.begin(SDPSR_T_REFINE);
@@ -775,17 +791,16 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         q.sig = sig;
         q.a = dCL;
         q.b = dX0;
-        if ((c->hint_symmetric_basis & 2) && len < (int64_t(1) << 32)) {
+        if ((c->hint_symmetric_basis & 2) && Lp && len < (int64_t(1) << 32)) {
             // the caller vouches for symmetric CL / X0L (the reference symmetrises both,
             // src/partitions.jl:128-141): the initial partition from the lower triangle, mirrored
-            const int64_t lenp = n * (n + 1) / 2;
-            uint32_t* Lp = (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4);
-            if (!Lp) return SDPSR_OUT_OF_MEMORY;
             q.n = n;
             q.packed = 1;
             st = refine_signatures(c, lenp, q, Lp, &d);
-            if (!st) launch_unpack_symmetric_labels(s, n, Lp, L);
             labels_sym = 1;
+            packed_valid = true;
+            full_valid = false;
+            if (!st && !keep_packed) need_full();
         } else {
             st = refine_signatures(c, len, q, L, &d, n, symflag, &labels_sym);  // + symmetry verdict of the initial partition
         }
@@ -817,8 +832,10 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         const bool int_mode = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
         const bool packed_proj = int_mode && labels_sym && basis_sym && r <= 4 && len < (int64_t(1) << 32);
         bool probed = false;
+        const bool plab = packed_proj && packed_valid;  // the projection reads the packed labels
+        if (!plab) need_full();
         if (packed_proj) {
-            launch_proj_coef_lower(s, n, r, dU, L, key, partial, nblk, coef);
+            launch_proj_coef_lower(s, n, r, dU, plab ? Lp : L, plab ? 1 : 0, key, partial, nblk, coef);
         } else if (probe_pending && int_mode && len < (int64_t(1) << 32)) {
             launch_proj_coef_probe(s, len, n, r, dU, L, key, partial, nblk, coef);
             probe_host = (double*)c->pinned + 64;  // c->pinned[0..63] carries the refinement's counters
@@ -845,19 +862,24 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             qp.scale = scale;
             qp.n = n;
             qp.packed = packed_proj ? 1 : 0;
+            if (plab) {
+                qp.L = Lp;
+                qp.lab_packed = 1;
+            }
         }
         tm.end();
         tm.begin(SDPSR_T_REFINE);
         int64_t d1 = 0;
         if (packed_proj) {
-            // symmetric by construction: refine the packed lower triangle, mirror it (as after the squares)
-            const int64_t lenp = n * (n + 1) / 2;
-            uint32_t* Lp = (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4);
-            if (!Lp) return SDPSR_OUT_OF_MEMORY;
+            // symmetric by construction: refine the packed lower triangle (in place when the labels were packed)
             st = refine_signatures(c, lenp, qp, Lp, &d1);
-            if (!st) launch_unpack_symmetric_labels(s, n, Lp, L);
+            packed_valid = true;
+            full_valid = false;
+            if (!st && !keep_packed) need_full();
         } else {
             st = refine_signatures(c, len, qp, L, &d1, int_mode ? n : 0, symflag, &labels_sym);
+            full_valid = true;
+            packed_valid = false;
         }
         tm.end();
         if (st) return st;
@@ -880,6 +902,8 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             // triangle: same canonical numbering).  Non-symmetric labels: X X literally, with
             // the K-contiguous left operand gathered from the transposed labels (same draw).
             const uint32_t* lower = labels_sym ? zero_flag : nullptr;
+            const bool slab = keep_packed && labels_sym && packed_valid;  // the square step reads the packed labels
+            if (!slab) need_full();
             const uint32_t* Lleft = L;
             // signatures of the squares: computed inside the insert pass of the refinement (integer
             // modes), an array for the fp64 mode
@@ -892,6 +916,10 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             qs.C = Cp;
             qs.packed = labels_sym;
             qs.zero_flag = lower;
+            if (slab) {
+                qs.L = Lp;
+                qs.lab_packed = 1;
+            }
             if (int_mode && !labels_sym) {
                 uint32_t* Lt = (uint32_t*)ctx_buf(c, "des_lt", len * 4);
                 if (!Lt) return SDPSR_OUT_OF_MEMORY;
@@ -900,7 +928,8 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             }
             if (mode == SDPSR_SQUARE_I8) {
                 int8_t* Xl = (int8_t*)Xp;
-                launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp, d2);  // d2 = current dimension
+                if (slab) launch_gather_i8_sym_packed(s, n, ld, T, Lp, key2, (int8_t*)Xp, d2);  // d2 = current dimension
+                else launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp, d2);
                 if (!labels_sym) {
                     Xl = (int8_t*)ctx_buf(c, "des_yi8", (size_t)T * ld * ld);
                     if (!Xl) return SDPSR_OUT_OF_MEMORY;
@@ -936,16 +965,17 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             tm.end();
             tm.begin(SDPSR_T_REFINE);
             if (int_mode && labels_sym) {
-                // symmetric labels: the signatures were written for the packed lower triangle
-                // only; refine n (n + 1) / 2 entries (same relative order, same canonical
-                // numbering), then expand to the full symmetric matrix
-                const int64_t lenp = n * (n + 1) / 2;
-                uint32_t* Lp = (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4);
-                if (!Lp) return SDPSR_OUT_OF_MEMORY;
+                // symmetric labels: the signatures exist for the packed lower triangle only;
+                // refine n (n + 1) / 2 entries (same relative order, same canonical numbering);
+                // the full symmetric matrix is formed when somebody needs it
                 st = refine_signatures(c, lenp, qs, Lp, &d2);
-                if (!st) launch_unpack_symmetric_labels(s, n, Lp, L);
+                packed_valid = true;
+                full_valid = false;
+                if (!st && !keep_packed) need_full();
             } else {
                 st = refine_signatures(c, len, qs, L, &d2);
+                full_valid = true;
+                packed_valid = false;
             }
             tm.end();
             if (st) return st;
@@ -964,6 +994,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         current = d2;  // :184
         if (current >= maximal) converged = true;
     }
+    need_full();
     HIP_TRY(c, hipGetLastError());
     *dim_out = current;
     if (iters_out) *iters_out = it;

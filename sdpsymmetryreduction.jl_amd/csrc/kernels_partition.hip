@@ -149,6 +149,94 @@ void launch_gather_i8(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_
     }
 }
 
+// Channel gather from the PACKED lower triangle of symmetric labels (column j at offset
+// j n - j (j - 1) / 2, rows j .. n-1): 64 x 64 tile pairs (I >= J).  The tile's entries are gathered
+// once (coalesced along the packed columns) as 32-bit words holding the <= 4 channel bytes of the
+// class, staged in LDS, and written twice: to X[I, J] and, transposed, to X[J, I], 16 rows per
+// thread and channel (one 16-byte store each, bytes regrouped by v_perm).  Replaces
+// unpack_symmetric_labels + gather_i8 inside the loop (the labels stay packed between the
+// refinements of an iteration).  Padding rows / columns (>= n) are written as zero.
+__device__ __forceinline__ void bytes_4x4_transpose(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t o[4]) {
+    // o[t] = byte t of a, b, c, d (a lowest)
+    const uint32_t ab_lo = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
+    const uint32_t ab_hi = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+    const uint32_t cd_lo = __builtin_amdgcn_perm(d, c, 0x05010400u);
+    const uint32_t cd_hi = __builtin_amdgcn_perm(d, c, 0x07030602u);
+    o[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);  // a0 b0 c0 d0
+    o[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+}
+
+template <int T>
+__global__ void __launch_bounds__(256)
+gather_i8_sym_packed_kernel(int n, int64_t ld, const uint32_t* __restrict__ Lp, uint64_t key, int8_t* __restrict__ X, int dlut) {
+    __shared__ uint32_t lut[GATHER_LUT + 1];
+    __shared__ uint32_t tile[64][65];  // [column][row]: channel bytes of element (i0 + row, j0 + column)
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bi < bj) return;
+    if (dlut > 0) {
+        for (int i = threadIdx.x; i <= dlut; i += blockDim.x) lut[i] = i ? (uint32_t)sdpsr_class_bits(key, (uint32_t)i) : 0u;
+        __syncthreads();
+    }
+    const int i0 = bi * 64, j0 = bj * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    uint32_t lab[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = i0 + tx, j = j0 + ty + 4 * q;
+        lab[q] = 0xFFFFFFFFu;
+        if (i < n && j < n) {
+            const int hi = i > j ? i : j, lo = i > j ? j : i;  // (diagonal tiles: the upper half by symmetry)
+            lab[q] = Lp[(int64_t)lo * n - (int64_t)lo * (lo - 1) / 2 + (hi - lo)];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t l = lab[q];
+        uint32_t v = 0u;
+        if (l != 0xFFFFFFFFu) v = dlut > 0 ? lut[l] : (l ? (uint32_t)sdpsr_class_bits(key, l) : 0u);
+        tile[ty + 4 * q][tx] = v;
+    }
+    __syncthreads();
+    // 64 columns x 4 sixteen-row groups = 256 (column, group) pairs per orientation: one per thread
+    const int col = threadIdx.x >> 2, seg = threadIdx.x & 3;
+#pragma unroll
+    for (int orient = 0; orient < 2; ++orient) {
+        if (orient == 1 && bi == bj) break;
+        uint32_t w[T][4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            uint32_t e[4], o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = seg * 16 + g4 * 4 + k;
+                e[k] = orient == 0 ? tile[col][r] : tile[r][col];  // straight: column `col`, rows r; transposed: row `col` of the tile
+            }
+            bytes_4x4_transpose(e[0], e[1], e[2], e[3], o);
+#pragma unroll
+            for (int t = 0; t < T; ++t) w[t][g4] = o[t];
+        }
+        // straight: X[i0 + seg*16 .., j0 + col]; transposed: X[j0 + seg*16 .., i0 + col]
+        const int64_t r0 = (orient == 0 ? i0 : j0) + seg * 16, c0 = (orient == 0 ? j0 : i0) + col;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            *reinterpret_cast<uint4*>(X + (int64_t)t * ld * ld + r0 + c0 * ld) = make_uint4(w[t][0], w[t][1], w[t][2], w[t][3]);
+    }
+}
+void launch_gather_i8_sym_packed(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* Lp, uint64_t key, int8_t* X,
+                                 int64_t dmax) {
+    const int dlut = (dmax > 0 && dmax <= GATHER_LUT) ? (int)dmax : 0;
+    const unsigned t = (unsigned)(ld / 64);  // ld is a multiple of 128
+    dim3 g(t, t);
+    switch (T) {
+        case 1: gather_i8_sym_packed_kernel<1><<<g, 256, 0, s>>>((int)n, ld, Lp, key, X, dlut); break;
+        case 2: gather_i8_sym_packed_kernel<2><<<g, 256, 0, s>>>((int)n, ld, Lp, key, X, dlut); break;
+        case 4: gather_i8_sym_packed_kernel<4><<<g, 256, 0, s>>>((int)n, ld, Lp, key, X, dlut); break;
+        default: break;
+    }
+}
+
 __global__ void gather_f32_kernel(int64_t n, int64_t ld, int T, int vmax,
                                   const uint32_t* __restrict__ L, uint64_t key,
                                   float* __restrict__ X) {
@@ -362,15 +450,16 @@ __device__ __forceinline__ void packed_lower_ij(int n, int64_t e, uint32_t& i, u
 }
 
 // grid = (nblk, r): workgroups stride over the columns, threads over the rows i >= j of a column
-__global__ void proj_coef_lower_kernel(int n, const double* __restrict__ U, const uint32_t* __restrict__ L, uint64_t key,
-                                       double* __restrict__ partial) {
+__global__ void proj_coef_lower_kernel(int n, const double* __restrict__ U, const uint32_t* __restrict__ L, int lab_packed,
+                                       uint64_t key, double* __restrict__ partial) {
     __shared__ double sh[8];
     const int k = blockIdx.y;
     const double* Uk = U + (int64_t)k * n * n;
     double a0 = 0, a1 = 0;
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
         const double* Uj = Uk + (int64_t)j * n;
-        const uint32_t* Lj = L + (int64_t)j * n;
+        // labels: the full matrix, or its packed lower triangle (column j at offset j n - j (j - 1) / 2, rows j ..)
+        const uint32_t* Lj = lab_packed ? L + ((int64_t)j * n - (int64_t)j * (j - 1) / 2 - j) : L + (int64_t)j * n;
         int i = j + threadIdx.x;
         for (; i + (int)blockDim.x < n; i += 2 * blockDim.x) {
             const double u0 = Uj[i], u1 = Uj[i + blockDim.x];
@@ -388,11 +477,11 @@ __global__ void proj_coef_lower_kernel(int n, const double* __restrict__ U, cons
     const double r = block_reduce_sum(a0 + a1, sh);
     if (threadIdx.x == 0) partial[(int64_t)k * gridDim.x + blockIdx.x] = r;
 }
-void launch_proj_coef_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
-                            double* partial, int nblk, double* coef) {
+void launch_proj_coef_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, int lab_packed,
+                            uint64_t key, double* partial, int nblk, double* coef) {
     if (r <= 0) return;
     dim3 g(nblk, (unsigned)r);
-    proj_coef_lower_kernel<<<g, 256, 0, s>>>((int)n, U, L, key, partial);
+    proj_coef_lower_kernel<<<g, 256, 0, s>>>((int)n, U, L, lab_packed, key, partial);
     proj_coef_final_kernel<<<(unsigned)r, 256, 0, s>>>(nblk, partial, coef);
 }
 
@@ -433,14 +522,16 @@ void launch_proj_coef_probe(hipStream_t s, int64_t len, int64_t n, int64_t r, co
 
 // proj_apply on the lower triangle, signatures packed (column j at offset j n - j (j - 1) / 2): the
 // stand-alone form of SrcProj<R> with packed = 1 (sort path / r > 4)
-__global__ void proj_apply_lower_kernel(int n, int r, const double* __restrict__ U, const uint32_t* __restrict__ L, uint64_t key,
-                                        const double* __restrict__ coef, double atol, double scale, uint64_t* __restrict__ sig) {
+__global__ void proj_apply_lower_kernel(int n, int r, const double* __restrict__ U, const uint32_t* __restrict__ L, int lab_packed,
+                                        uint64_t key, const double* __restrict__ coef, double atol, double scale,
+                                        uint64_t* __restrict__ sig) {
     const int64_t len = (int64_t)n * n;
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
-        uint64_t* sj = sig + ((int64_t)j * n - (int64_t)j * (j - 1) / 2 - j);
+        const int64_t poff = (int64_t)j * n - (int64_t)j * (j - 1) / 2 - j;
+        uint64_t* sj = sig + poff;
         for (int i = j + threadIdx.x; i < n; i += blockDim.x) {
             const int64_t e = i + (int64_t)j * n;
-            const uint32_t l = L[e];
+            const uint32_t l = lab_packed ? L[poff + i] : L[e];
             const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
             double p = 0;
             for (int k = 0; k < r; ++k) p = fma(U[(int64_t)k * len + e], coef[k], p);
@@ -455,10 +546,10 @@ __global__ void proj_apply_lower_kernel(int n, int r, const double* __restrict__
         }
     }
 }
-void launch_proj_apply_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
+void launch_proj_apply_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, int lab_packed, uint64_t key,
                              const double* coef, double atol, double scale, uint64_t* sig) {
     const int g = (int)(n < 256 * 8 ? n : 256 * 8);
-    proj_apply_lower_kernel<<<g, 256, 0, s>>>((int)n, (int)r, U, L, key, coef, atol, scale, sig);
+    proj_apply_lower_kernel<<<g, 256, 0, s>>>((int)n, (int)r, U, L, lab_packed, key, coef, atol, scale, sig);
 }
 
 // ---------------------------------------------------------------------------
@@ -550,7 +641,7 @@ void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_
 template <typename CT>
 __global__ void sig_channels_kernel(int64_t n, int64_t ld, int T, const uint32_t* __restrict__ L,
                                     const CT* __restrict__ C, uint64_t* __restrict__ sig,
-                                    const uint32_t* __restrict__ nonsym_flag, int packed) {
+                                    const uint32_t* __restrict__ nonsym_flag, int packed, int lab_packed) {
     const int64_t istride = (int64_t)gridDim.x * blockDim.x;
     // lower != 0: labels and products are symmetric, only entries i >= j get a signature (the
     // strict upper triangle gets the zero signature and is mirrored after the refinement; first
@@ -558,11 +649,11 @@ __global__ void sig_channels_kernel(int64_t n, int64_t ld, int T, const uint32_t
     // numbering is unchanged)
     const bool lower = nonsym_flag && *nonsym_flag == 0u;
     for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
-        const uint32_t* Lj = L + j * n;
         // packed != 0 (with lower): the signatures of the lower triangle are written densely,
         // column j at offset j n - j (j - 1) / 2, rows j .. n-1 -- the refinement then runs on
-        // n (n + 1) / 2 entries in the same relative order
+        // n (n + 1) / 2 entries in the same relative order; lab_packed: the labels come packed the same way
         const bool pk = lower && packed;
+        const uint32_t* Lj = (pk && lab_packed) ? L + (j * n - j * (j - 1) / 2 - j) : L + j * n;
         uint64_t* sj = pk ? sig + (j * n - j * (j - 1) / 2 - j) : sig + j * n;
         const CT* Cj = C + j * ld;
 #pragma unroll 2
@@ -595,12 +686,12 @@ static inline dim3 column_grid(int64_t n) {
     return dim3((unsigned)gx, (unsigned)gy);
 }
 void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag, int packed) {
-    sig_channels_kernel<int32_t><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag, packed);
+                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag, int packed, int lab_packed) {
+    sig_channels_kernel<int32_t><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag, packed, lab_packed);
 }
 void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag, int packed) {
-    sig_channels_kernel<float><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag, packed);
+                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag, int packed, int lab_packed) {
+    sig_channels_kernel<float><<<column_grid(n), 256, 0, s>>>(n, ld, T, L, C, sig, nonsym_flag, packed, lab_packed);
 }
 
 // ---------------------------------------------------------------------------
@@ -638,7 +729,7 @@ struct SrcArray {
     __device__ __forceinline__ bool walks() const { return false; }
     __device__ __forceinline__ bool lower() const { return false; }
     __device__ __forceinline__ int order() const { return 1; }
-    __device__ __forceinline__ uint64_t at(uint32_t, uint32_t) const { return 0; }
+    __device__ __forceinline__ uint64_t at(uint32_t, uint32_t, int64_t) const { return 0; }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const { return __builtin_nontemporal_load(&sig[e]); }
 };
 struct SrcPair {  // sig_f64_pair_kernel; packed: the lower triangle column by column (a, b symmetric)
@@ -655,12 +746,12 @@ struct SrcPair {  // sig_f64_pair_kernel; packed: the lower triangle column by c
         const uint64_t h = sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb);
         return finish_sig(0u, ka == 0 && kb == 0, h);
     }
-    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j) const { return flat((int64_t)i + (int64_t)j * n); }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t) const { return flat((int64_t)i + (int64_t)j * n); }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         if (packed) {
             uint32_t i, j;
             packed_lower_ij(n, e, i, j);
-            return at(i, j);
+            return at(i, j, e);
         }
         return flat(e);
     }
@@ -675,11 +766,13 @@ struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig onl
     uint64_t key;
     double atol, scale;
     int n, packed;  // packed: the lower triangle column by column (symmetric labels and basis)
+    int lab_packed;  // L is the packed lower triangle itself (label of packed entry e = L[e])
     __device__ __forceinline__ bool walks() const { return packed != 0; }
     __device__ __forceinline__ bool lower() const { return true; }
     __device__ __forceinline__ int order() const { return n; }
-    __device__ __forceinline__ uint64_t flat(int64_t e) const {
-        const uint32_t l = L[e];
+    __device__ __forceinline__ uint64_t flat(int64_t e) const { return flat(e, e); }
+    __device__ __forceinline__ uint64_t flat(int64_t e, int64_t el) const {
+        const uint32_t l = L[el];
         double u[R > 0 ? R : 1];
 #pragma unroll
         for (int k = 0; k < R; ++k) u[k] = __builtin_nontemporal_load(&U[(int64_t)k * len + e]);
@@ -696,12 +789,15 @@ struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig onl
         }
         return h;
     }
-    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j) const { return flat((int64_t)i + (int64_t)j * n); }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const {
+        const int64_t ef = (int64_t)i + (int64_t)j * n;
+        return flat(ef, lab_packed ? e : ef);
+    }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         if (packed) {
             uint32_t i, j;
             packed_lower_ij(n, e, i, j);
-            return at(i, j);
+            return at(i, j, e);
         }
         return flat(e);
     }
@@ -714,11 +810,12 @@ struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by c
     const uint32_t* L;
     const CT* __restrict__ C;
     int packed;
+    int lab_packed;  // (with packed) L is the packed lower triangle itself
     __device__ __forceinline__ bool walks() const { return true; }  // C is ld-strided: (i, j) needed either way
     __device__ __forceinline__ bool lower() const { return packed != 0; }
     __device__ __forceinline__ int order() const { return n; }
-    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j) const {
-        const uint32_t l = L[(int64_t)j * n + i];
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const {
+        const uint32_t l = lab_packed ? L[e] : L[(int64_t)j * n + i];
         const CT* Cij = C + (int64_t)j * ld + i;
         int32_t c[T + (T & 1)];
 #pragma unroll
@@ -736,7 +833,7 @@ struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by c
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         uint32_t i, j;
         IjWalk::locate(n, packed != 0, e, i, j);
-        return at(i, j);
+        return at(i, j, e);
     }
 };
 
@@ -860,7 +957,7 @@ refine_insert_kernel(int64_t len, const SRC src,
 #pragma unroll
             for (int q = 0; q < INSERT_PER_THREAD; ++q) {
                 const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-                sgs[q] = (e < len) ? src.at(wi, wj) : 0ull;
+                sgs[q] = (e < len) ? src.at(wi, wj, e) : 0ull;
                 IjWalk::step(nn, low, wi, wj, REFINE_THREADS);
             }
         } else {
@@ -1218,10 +1315,10 @@ static bool launch_insert_chan(hipStream_t s, int gcap, int64_t len, const SigSo
                                size_t cap) {
     const CT* C = (const CT*)q.C;
     switch (q.T) {
-        case 1: launch_insert<SrcChan<CT, 1>, 8>(s, gcap, len, SrcChan<CT, 1>{(int)q.n, q.ld, q.L, C, q.packed}, slot, ws, cap); return true;
-        case 2: launch_insert<SrcChan<CT, 2>, 8>(s, gcap, len, SrcChan<CT, 2>{(int)q.n, q.ld, q.L, C, q.packed}, slot, ws, cap); return true;
-        case 4: launch_insert<SrcChan<CT, 4>, 8>(s, gcap, len, SrcChan<CT, 4>{(int)q.n, q.ld, q.L, C, q.packed}, slot, ws, cap); return true;
-        case 8: launch_insert<SrcChan<CT, 8>, 4>(s, gcap, len, SrcChan<CT, 8>{(int)q.n, q.ld, q.L, C, q.packed}, slot, ws, cap); return true;
+        case 1: launch_insert<SrcChan<CT, 1>, 8>(s, gcap, len, SrcChan<CT, 1>{(int)q.n, q.ld, q.L, C, q.packed, q.lab_packed}, slot, ws, cap); return true;
+        case 2: launch_insert<SrcChan<CT, 2>, 8>(s, gcap, len, SrcChan<CT, 2>{(int)q.n, q.ld, q.L, C, q.packed, q.lab_packed}, slot, ws, cap); return true;
+        case 4: launch_insert<SrcChan<CT, 4>, 8>(s, gcap, len, SrcChan<CT, 4>{(int)q.n, q.ld, q.L, C, q.packed, q.lab_packed}, slot, ws, cap); return true;
+        case 8: launch_insert<SrcChan<CT, 8>, 4>(s, gcap, len, SrcChan<CT, 8>{(int)q.n, q.ld, q.L, C, q.packed, q.lab_packed}, slot, ws, cap); return true;
         default: return false;
     }
 }
@@ -1246,11 +1343,11 @@ void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint
             else launch_sig_f64_pair(s, len, q.a, q.b, sig);
             break;
         case SIG_PROJ:
-            if (q.packed) launch_proj_apply_lower(s, q.n, q.r, q.U, q.L, q.key, q.coef, q.atol, q.scale, sig);
+            if (q.packed) launch_proj_apply_lower(s, q.n, q.r, q.U, q.L, q.lab_packed, q.key, q.coef, q.atol, q.scale, sig);
             else launch_proj_apply(s, len, q.r, q.U, q.L, q.key, nullptr, q.coef, q.atol, q.scale, 1, nullptr, sig);
             break;
-        case SIG_CHAN_I32: launch_sig_i32(s, q.n, q.ld, q.T, q.L, (const int32_t*)q.C, sig, q.zero_flag, q.packed); break;
-        case SIG_CHAN_F32: launch_sig_f32(s, q.n, q.ld, q.T, q.L, (const float*)q.C, sig, q.zero_flag, q.packed); break;
+        case SIG_CHAN_I32: launch_sig_i32(s, q.n, q.ld, q.T, q.L, (const int32_t*)q.C, sig, q.zero_flag, q.packed, q.lab_packed); break;
+        case SIG_CHAN_F32: launch_sig_f32(s, q.n, q.ld, q.T, q.L, (const float*)q.C, sig, q.zero_flag, q.packed, q.lab_packed); break;
         default: break;
     }
 }
@@ -1269,11 +1366,11 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
         case SIG_PAIR: launch_insert<SrcPair, 8>(s, gcap, len, SrcPair{q.a, q.b, (int)q.n, q.packed}, slot, ws, cap); break;
         case SIG_PROJ:
             switch (q.r) {
-                case 0: launch_insert<SrcProj<0>, 8>(s, gcap, len, SrcProj<0>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
-                case 1: launch_insert<SrcProj<1>, 8>(s, gcap, len, SrcProj<1>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
-                case 2: launch_insert<SrcProj<2>, 8>(s, gcap, len, SrcProj<2>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
-                case 3: launch_insert<SrcProj<3>, 8>(s, gcap, len, SrcProj<3>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
-                default: launch_insert<SrcProj<4>, 8>(s, gcap, len, SrcProj<4>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed}, slot, ws, cap); break;
+                case 0: launch_insert<SrcProj<0>, 8>(s, gcap, len, SrcProj<0>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed, q.lab_packed}, slot, ws, cap); break;
+                case 1: launch_insert<SrcProj<1>, 8>(s, gcap, len, SrcProj<1>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed, q.lab_packed}, slot, ws, cap); break;
+                case 2: launch_insert<SrcProj<2>, 8>(s, gcap, len, SrcProj<2>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed, q.lab_packed}, slot, ws, cap); break;
+                case 3: launch_insert<SrcProj<3>, 8>(s, gcap, len, SrcProj<3>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed, q.lab_packed}, slot, ws, cap); break;
+                default: launch_insert<SrcProj<4>, 8>(s, gcap, len, SrcProj<4>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed, q.lab_packed}, slot, ws, cap); break;
             }
             break;
         case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;

@@ -105,11 +105,13 @@ void launch_proj_coef(hipStream_t s, int64_t len, int64_t r, const double* U, co
                       uint64_t key, const double* xin, double* partial, int nblk, double* coef);
 // y[e] = x[e] - sum_k U[e,k] coef[k]; optional outputs: yout (rounded value, fp64),
 // sig (signature chained on L).  x as above.
-void launch_proj_coef_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
-                            double* partial, int nblk, double* coef);
+void launch_gather_i8_sym_packed(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* Lp, uint64_t key, int8_t* X,
+                                 int64_t dmax);
+void launch_proj_coef_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, int lab_packed,
+                            uint64_t key, double* partial, int nblk, double* coef);
 void launch_proj_coef_probe(hipStream_t s, int64_t len, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
                             double* partial, int nblk, double* coef);
-void launch_proj_apply_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, uint64_t key,
+void launch_proj_apply_lower(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* L, int lab_packed, uint64_t key,
                              const double* coef, double atol, double scale, uint64_t* sig);
 void launch_proj_apply(hipStream_t s, int64_t len, int64_t r, const double* U, const uint32_t* L,
                        uint64_t key, const double* xin, const double* coef, double atol,
@@ -124,9 +126,9 @@ void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_
                     uint64_t* sig);
 // T channels of int32 / f32 squares, padded ld, C[t] at C + t*ld*ld
 void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr, int packed = 0);
+                    const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr, int packed = 0, int lab_packed = 0);
 void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
-                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr, int packed = 0);
+                    const float* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr, int packed = 0, int lab_packed = 0);
 
 // canonical relabel of signatures (hash table + first-occurrence ranking).
 // Workspace layout is owned by the caller (see refine_workspace_bytes).
@@ -160,6 +162,7 @@ struct SigSource {
     int T = 0;
     const void* C = nullptr;
     int packed = 0;                                               // lower triangle only, densely packed (symmetric labels; SIG_PROJ: and symmetric basis, needs n)
+    int lab_packed = 0;                                           // (with packed) L is the packed lower triangle itself: label of packed entry e = L[e]
     const uint32_t* zero_flag = nullptr;                          // device constant 0 when packed (the kernels' "lower" flag)
 };
 bool sig_source_fusable(const SigSource& q);
