@@ -1337,6 +1337,10 @@ struct ElemGen {
     // and make the main stream wait for it
     std::function<int(double* dst)> prefetch;
     std::function<int()> join;
+    // optional: mark the fork point on the main stream NOW; a later prefetch() starts from this
+    // point (so that the eigensolver can be enqueued first and its launches do not wait behind the
+    // prefetch's host-side launch work)
+    std::function<int()> fork;
 };
 
 int make_element(sdpsr_ctx* c, const ElemGen* gen, int64_t n, int64_t ld, const uint32_t* L, double* dst) {
@@ -1377,9 +1381,15 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     dbg_mark("eigen_decomposition: element made");
     // the second generic element does not depend on the eigendecomposition of the first: when
     // the generator can, it is formed on a side stream while the (one-workgroup) eigensolver runs
-    const bool prefetched = gen && gen->prefetch && gen->join && gen->prefetch(Ap) == SDPSR_OK;
+    bool prefetched = false;
     info.vals.resize(n);
-    st = syev_device(c, n, Q, ld, w, info.vals.data());
+    if (gen && gen->prefetch && gen->join && gen->fork && gen->fork() == SDPSR_OK) {
+        const std::function<void()> after = [&]() { prefetched = gen->prefetch(Ap) == SDPSR_OK; };
+        st = syev_device(c, n, Q, ld, w, info.vals.data(), &after);
+    } else {
+        prefetched = gen && gen->prefetch && gen->join && gen->prefetch(Ap) == SDPSR_OK;
+        st = syev_device(c, n, Q, ld, w, info.vals.data());
+    }
     dbg_mark("eigen_decomposition: syev returned");
     tm.end();
     if (st) {
@@ -1915,7 +1925,8 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         launch_symmetrize(s, w, wp, dst);
         return SDPSR_OK;
     };
-    gen.prefetch = [&](double* dst) -> int {
+    bool forked = false;
+    auto ensure_side = [&]() -> int {
         if (!c->side_stream) {
             if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1924,9 +1935,22 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
                 return SDPSR_HIP_ERROR;
             }
         }
+        return SDPSR_OK;
+    };
+    gen.fork = [&]() -> int {
+        forked = false;
+        if (have_saved) return SDPSR_BAD_STATE;  // the next element is the saved one: nothing to overlap
+        if (ensure_side()) return SDPSR_HIP_ERROR;
+        if (hipEventRecord(c->ev_fork, c->stream) != hipSuccess) return SDPSR_HIP_ERROR;
+        forked = true;
+        return SDPSR_OK;
+    };
+    gen.prefetch = [&](double* dst) -> int {
+        if (ensure_side()) return SDPSR_HIP_ERROR;
         if (have_saved) return SDPSR_BAD_STATE;  // the next element is the saved one: nothing to overlap
         hipStream_t main_stream = c->stream;
-        if (hipEventRecord(c->ev_fork, main_stream) != hipSuccess) return SDPSR_HIP_ERROR;
+        if (!forked && hipEventRecord(c->ev_fork, main_stream) != hipSuccess) return SDPSR_HIP_ERROR;
+        forked = false;
         if (hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return SDPSR_HIP_ERROR;
         c->stream = c->side_stream;  // every helper launches on c->stream / s
         c->main_shadow = main_stream;

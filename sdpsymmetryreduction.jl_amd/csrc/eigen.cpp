@@ -98,7 +98,8 @@ void destroy_handle(sdpsr_ctx* c) {
 
 // A: n x n column-major with leading dimension lda, lower triangle referenced; on exit the
 // columns of A are the orthonormal eigenvectors, w ascending.
-int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, double* host_w) {
+int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, double* host_w,
+                const std::function<void()>* after_launch) {
     int st = ensure_handle(c);
     if (st) return st;
     rocblas_handle h = (rocblas_handle)c->rocblas;
@@ -157,6 +158,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
                              hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             return ctx_fail(c, SDPSR_HIP_ERROR, "copy of eigenvectors failed");
     }
+    if (after_launch) (*after_launch)();  // everything of the eigensolver is enqueued; the caller overlaps its own launches here
     // read-back through the pinned scratch of the ctx (a pageable 4-byte copy costs tens of us)
     rocblas_int* hpin = (rocblas_int*)ctx_pinned(c, 64 + (host_w ? (size_t)n * sizeof(double) : 0));
     if (!hpin || hipMemcpyAsync(hpin, info, 2 * sizeof(rocblas_int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

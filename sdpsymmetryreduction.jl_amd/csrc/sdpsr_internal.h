@@ -6,6 +6,7 @@
 #include <stddef.h>
 
 #include <map>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -310,7 +311,9 @@ int sort_entries_by_label(sdpsr_ctx* c, int64_t len, int64_t d, const uint32_t* 
 // ---------------------------------------------------------------------------
 // A (n x n, leading dimension lda) is overwritten with the eigenvectors; w[n] ascending.
 // host_w (optional): the eigenvalues are also delivered to the host, riding on the status read-back
-int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, double* host_w = nullptr);
+// after_launch: called once the eigensolver's kernels are enqueued, before the read-back synchronises
+int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, double* host_w = nullptr,
+                const std::function<void()>* after_launch = nullptr);
 void* ctx_pinned(sdpsr_ctx* c, size_t bytes);
 void destroy_handle(sdpsr_ctx* c);
 
