@@ -185,7 +185,15 @@ int sdpsr_gemm_tn_f64(sdpsr_ctx* ctx, int64_t m, int64_t n, int64_t k, const dou
      X0L  n x n  reshape(_clamp_round!(projL(_symmetrize!(craig(A,b)))), n, n) (:137-142)
      U    n^2 x r orthonormal basis of rowspace(A)                              (:124)
    Outputs: P_out (n x n labels), *dim_out, *iters_out, phase_ms[SDPSR_T_COUNT] (may be
-   NULL). */
+   NULL).
+   BEHAVIOURAL DIFFERENCE (int8 mode, symmetric labels and basis, <= 4 basis matrices): an
+   iteration refines the partition ONCE, by the projected random element and the square of a second
+   random element of the same partition together; the reference refines after the projection and
+   draws the squared element from the refined partition (:159-174).  Both loops end at the same
+   partition (the smallest partition subspace containing C_L and X0 that is closed under the
+   projection and under squaring; P_out is canonical, so it is the same matrix); *iters_out counts
+   joint steps (equal to the reference-structured count on every test problem).
+   SDPSR_SEPARATE_REFINEMENTS=1 in the environment restores two refinements per iteration. */
 int sdpsr_admissible_subspace(sdpsr_ctx* ctx, int64_t n, const double* CL, const double* X0L,
                               const double* U, int64_t r, double atol, uint32_t* P_out,
                               int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem);

@@ -831,6 +831,67 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
         const uint64_t key = next_key(c);
         const bool int_mode = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
         const bool packed_proj = int_mode && labels_sym && basis_sym && r <= 4 && len < (int64_t(1) << 32);
+        // Joint iteration (int8, everything symmetric, few classes): the projected element and the
+        // square -- two independent random elements of the SAME partition S -- refine S in ONE
+        // canonical relabel of the signature (label, rounded projection, channel values).  The
+        // reference refines twice per iteration and draws the squared element from the already
+        // refined partition (:159-174); both loops stop at the same fixed point (the smallest
+        // partition subspace containing C_L, X0 that is closed under the projection and under
+        // squaring), since a class is only ever split when generic elements of the closure force
+        // it.  An "iteration" is then one joint step.
+        static const bool separate = getenv("SDPSR_SEPARATE_REFINEMENTS") != nullptr;
+        if (!separate && packed_proj && keep_packed && T == 4 && c->table_log2_hint < 21) {
+            const bool jl = packed_valid;
+            if (!jl) need_full();
+            launch_proj_coef_lower(s, n, r, dU, jl ? Lp : L, jl ? 1 : 0, key, partial, nblk, coef);
+            tm.end();
+            int64_t dj = current;
+            for (;;) {
+                tm.begin(SDPSR_T_SQUARE);
+                const uint64_t key2 = next_key(c);
+                const bool jl2 = packed_valid;
+                if (jl2) launch_gather_i8_sym_packed(s, n, ld, T, Lp, key2, (int8_t*)Xp, current);
+                else launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp, current);
+                launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, zero_flag);
+                tm.end();
+                tm.begin(SDPSR_T_REFINE);
+                SigSource qj;
+                qj.kind = SIG_JOINT_I32;
+                qj.sig = sig;
+                qj.U = dU;
+                qj.coef = coef;
+                qj.r = (int)r;
+                qj.key = key;
+                qj.atol = atol;
+                qj.scale = scale;
+                qj.n = n;
+                qj.ld = ld;
+                qj.T = T;
+                qj.C = Cp;
+                qj.packed = 1;
+                qj.L = jl2 ? Lp : L;
+                qj.lab_packed = jl2 ? 1 : 0;
+                st = refine_signatures(c, lenp, qj, Lp, &dj);
+                packed_valid = true;
+                full_valid = false;
+                tm.end();
+                if (st) return st;
+                tm.collect();
+                if (dj == current && confirm_left > 0) {  // extra independent draws before stopping
+                    --confirm_left;
+                    continue;  // (same projected element, a fresh square: the projection did not refine either)
+                }
+                break;
+            }
+            if (dj == current) {
+                converged = true;
+                break;
+            }
+            confirm_left = c->opts.confirm_rounds;
+            current = dj;
+            if (current >= maximal) converged = true;
+            continue;
+        }
         bool probed = false;
         const bool plab = packed_proj && packed_valid;  // the projection reads the packed labels
         if (!plab) need_full();

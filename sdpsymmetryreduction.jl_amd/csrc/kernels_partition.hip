@@ -837,6 +837,53 @@ struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by c
     }
 };
 
+// Projection and square of ONE iteration refined together: signature of (old label, rounded
+// projected value, channel values of the square) on the packed lower triangle.  Both random
+// elements are drawn from the same partition S; the loop reaches the same fixed point as the
+// reference's two refinements per iteration (a class is only ever split when it has to be), with
+// one insert pass per iteration instead of two.
+template <int R>
+struct SrcJoint {
+    static constexpr bool kIJ = true;
+    const double* __restrict__ U;
+    const uint32_t* L;
+    const double* __restrict__ coef;
+    uint64_t key;
+    double atol, scale;
+    const int32_t* __restrict__ C;  // 4 channels, ld x ld each
+    int64_t ld;
+    int n, lab_packed;
+    __device__ __forceinline__ bool walks() const { return true; }
+    __device__ __forceinline__ bool lower() const { return true; }
+    __device__ __forceinline__ int order() const { return n; }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const {
+        const int64_t ef = (int64_t)i + (int64_t)j * n;
+        const uint32_t l = lab_packed ? L[e] : L[ef];
+        double u[R > 0 ? R : 1];
+#pragma unroll
+        for (int k = 0; k < R; ++k) u[k] = __builtin_nontemporal_load(&U[(int64_t)k * n * n + ef]);
+        const int32_t* Cij = C + (int64_t)j * ld + i;
+        int32_t c[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c[t] = __builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
+        const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) p = fma(u[k], coef[k], p);
+        const double y = sdpsr_clamp_round(x - p, atol, scale);
+        const uint64_t kb = (uint64_t)__double_as_longlong(y);
+        uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
+        h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[0] | ((uint64_t)(uint32_t)c[1] << 32));
+        h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[2] | ((uint64_t)(uint32_t)c[3] << 32));
+        return finish_sig(l, kb == 0 && c[0] == 0 && c[1] == 0 && c[2] == 0 && c[3] == 0, h);
+    }
+    __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+        uint32_t i, j;
+        packed_lower_ij(n, e, i, j);
+        return at(i, j, e);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // Canonical refinement of 64-bit signatures.
 //
@@ -1323,8 +1370,34 @@ static bool launch_insert_chan(hipStream_t s, int gcap, int64_t len, const SigSo
     }
 }
 
+// stand-alone form of SrcJoint (sort path)
+__global__ void sig_joint_lower_kernel(int n, int64_t ld, int r, const double* __restrict__ U, const uint32_t* __restrict__ L,
+                                       int lab_packed, uint64_t key, const double* __restrict__ coef, double atol, double scale,
+                                       const int32_t* __restrict__ C, uint64_t* __restrict__ sig) {
+    const int64_t len = (int64_t)n * n;
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        const int64_t poff = (int64_t)j * n - (int64_t)j * (j - 1) / 2 - j;
+        for (int i = j + threadIdx.x; i < n; i += blockDim.x) {
+            const int64_t e = i + (int64_t)j * n;
+            const uint32_t l = lab_packed ? L[poff + i] : L[e];
+            const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
+            double p = 0;
+            for (int k = 0; k < r; ++k) p = fma(U[(int64_t)k * len + e], coef[k], p);
+            const double y = sdpsr_clamp_round(x - p, atol, scale);
+            const uint64_t kb = (uint64_t)__double_as_longlong(y);
+            const int32_t* Cij = C + (int64_t)j * ld + i;
+            const int32_t c0 = Cij[0], c1 = Cij[ld * ld], c2 = Cij[2 * ld * ld], c3 = Cij[3 * ld * ld];
+            uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
+            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c0 | ((uint64_t)(uint32_t)c1 << 32));
+            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c2 | ((uint64_t)(uint32_t)c3 << 32));
+            sig[poff + i] = finish_sig(l, kb == 0 && c0 == 0 && c1 == 0 && c2 == 0 && c3 == 0, h);
+        }
+    }
+}
+
 bool sig_source_fusable(const SigSource& q) {
     switch (q.kind) {
+        case SIG_JOINT_I32: return q.r >= 0 && q.r <= 4 && q.T == 4 && q.packed;
         case SIG_ARRAY: return true;
         case SIG_PAIR: return true;
         case SIG_PROJ: return q.r >= 0 && q.r <= 4;
@@ -1345,6 +1418,10 @@ void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint
         case SIG_PROJ:
             if (q.packed) launch_proj_apply_lower(s, q.n, q.r, q.U, q.L, q.lab_packed, q.key, q.coef, q.atol, q.scale, sig);
             else launch_proj_apply(s, len, q.r, q.U, q.L, q.key, nullptr, q.coef, q.atol, q.scale, 1, nullptr, sig);
+            break;
+        case SIG_JOINT_I32:
+            sig_joint_lower_kernel<<<(int)(q.n < 2048 ? q.n : 2048), 256, 0, s>>>((int)q.n, q.ld, q.r, q.U, q.L, q.lab_packed, q.key, q.coef,
+                                                                                 q.atol, q.scale, (const int32_t*)q.C, sig);
             break;
         case SIG_CHAN_I32: launch_sig_i32(s, q.n, q.ld, q.T, q.L, (const int32_t*)q.C, sig, q.zero_flag, q.packed, q.lab_packed); break;
         case SIG_CHAN_F32: launch_sig_f32(s, q.n, q.ld, q.T, q.L, (const float*)q.C, sig, q.zero_flag, q.packed, q.lab_packed); break;
@@ -1373,6 +1450,17 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
                 default: launch_insert<SrcProj<4>, 8>(s, gcap, len, SrcProj<4>{q.U, q.L, q.coef, q.packed ? q.n * q.n : len, q.key, q.atol, q.scale, (int)q.n, q.packed, q.lab_packed}, slot, ws, cap); break;
             }
             break;
+        case SIG_JOINT_I32: {
+            const int32_t* Cj = (const int32_t*)q.C;
+            switch (q.r) {
+                case 0: launch_insert<SrcJoint<0>, 8>(s, gcap, len, SrcJoint<0>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
+                case 1: launch_insert<SrcJoint<1>, 8>(s, gcap, len, SrcJoint<1>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
+                case 2: launch_insert<SrcJoint<2>, 8>(s, gcap, len, SrcJoint<2>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
+                case 3: launch_insert<SrcJoint<3>, 8>(s, gcap, len, SrcJoint<3>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
+                default: launch_insert<SrcJoint<4>, 8>(s, gcap, len, SrcJoint<4>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
+            }
+            break;
+        }
         case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;
         case SIG_CHAN_F32: launch_insert_chan<float>(s, gcap, len, q, slot, ws, cap); break;
         default: launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap); break;

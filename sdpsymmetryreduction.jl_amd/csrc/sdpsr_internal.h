@@ -149,7 +149,7 @@ uint32_t refine_small_k();
 // Where the insert pass takes its signatures from: an array (SIG_ARRAY), or computed on the fly
 // from the data the matching signature kernel reads (the signatures never travel through HBM).
 // `sig` is the array (SIG_ARRAY) or len entries of scratch for the paths that need one (sort).
-enum { SIG_ARRAY = 0, SIG_PAIR = 1, SIG_PROJ = 2, SIG_CHAN_I32 = 3, SIG_CHAN_F32 = 4 };
+enum { SIG_ARRAY = 0, SIG_PAIR = 1, SIG_PROJ = 2, SIG_CHAN_I32 = 3, SIG_CHAN_F32 = 4, SIG_JOINT_I32 = 5 };  // JOINT: SIG_PROJ and SIG_CHAN_I32 fields together (packed)
 struct SigSource {
     int kind = SIG_ARRAY;
     uint64_t* sig = nullptr;
