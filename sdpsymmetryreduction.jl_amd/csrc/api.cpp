@@ -1481,9 +1481,13 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     HIP_TRY(c, hipMemsetAsync(dnorms, 0, (size_t)neig * neig * 8, s));
     st = prefetched ? gen->join() : make_element(c, gen, n, ld, L, Ap);
     if (st) return st;
-    launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);   // T = A Q (A symmetric)
-    launch_gemm_tn_f64(s, ld, ld, ld, Q, ld, Tp, ld, Ap, ld, 1, 0, 0, 0);   // M = Q' T  (into Ap)
-    launch_block_norms(s, n, ld, Ap, dspace, neig, dnorms);
+    if (n <= 64) {  // small (compressed) problems: one workgroup does Q'AQ and the block maxima
+        launch_small_qtaq_block_norms(s, n, ld, Ap, Q, dspace, neig, dnorms, nullptr);
+    } else {
+        launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);   // T = A Q (A symmetric)
+        launch_gemm_tn_f64(s, ld, ld, ld, Q, ld, Tp, ld, Ap, ld, 1, 0, 0, 0);   // M = Q' T  (into Ap)
+        launch_block_norms(s, n, ld, Ap, dspace, neig, dnorms);
+    }
     tm.end();
     std::vector<double> norms((size_t)neig * neig);
     auto dimof = [&](int b) { return info.ptrs[b + 1] - info.ptrs[b]; };

@@ -48,6 +48,47 @@ __global__ void block_norms_kernel(int64_t n, int64_t ld, const double* __restri
         if (valid && head && v) atomicMax(&norms[key], v);
     }
 }
+// Q'AQ and its block norms for a small problem (n <= 64: the compressed problems of the
+// module-compression driver) in ONE workgroup: A, Q in LDS, T = A Q, M = Q'T entry by entry into
+// the block maxima.  Replaces two padded 128 x 128 MFMA launches (21 us each, pure latency) and the
+// block-norm launch.  Also leaves M in Mout (ld-strided) for the callers that read it.
+__global__ void __launch_bounds__(1024)
+small_qtaq_block_norms_kernel(int n, int64_t ld, const double* __restrict__ A, const double* __restrict__ Q,
+                              const int32_t* __restrict__ space_of, int neig, unsigned long long* __restrict__ norms,
+                              double* __restrict__ Mout) {
+    extern __shared__ __attribute__((aligned(16))) double sq[];
+    const int ldl = n | 1;
+    double* sA = sq;
+    double* sQ = sA + (size_t)ldl * n;
+    double* sT = sQ + (size_t)ldl * n;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int e = tid; e < n * n; e += nthr) {
+        const int j = e / n, i = e - j * n;
+        sA[i + j * ldl] = A[i + (int64_t)j * ld];
+        sQ[i + j * ldl] = Q[i + (int64_t)j * ld];
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += nthr) {  // T = A Q (A symmetric: row i = column i)
+        const int j = e / n, i = e - j * n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc = fma(sA[k + i * ldl], sQ[k + j * ldl], acc);
+        sT[i + j * ldl] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += nthr) {  // M[a, b] = Q[:, a]' T[:, b]
+        const int b = e / n, a = e - b * n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc = fma(sQ[k + a * ldl], sT[k + b * ldl], acc);
+        if (Mout) Mout[a + (int64_t)b * ld] = acc;
+        const unsigned long long v = (unsigned long long)__double_as_longlong(fabs(acc));
+        if (v) atomicMax(&norms[space_of[a] * neig + space_of[b]], v);
+    }
+}
+void launch_small_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* Q,
+                                   const int32_t* space_of, int neig, unsigned long long* norms, double* Mout) {
+    const size_t lds = (size_t)3 * (n | 1) * n * 8;
+    small_qtaq_block_norms_kernel<<<1, 1024, lds, s>>>((int)n, ld, A, Q, space_of, neig, norms, Mout);
+}
 void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
                         const int32_t* space_of, int neig, unsigned long long* norms) {
     block_norms_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, M, space_of, neig, norms);
@@ -733,6 +774,8 @@ class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict_
 void blockdiag_set_device_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_qtaq_block_norms_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_outer_mfma_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
