@@ -1542,6 +1542,8 @@ namespace sdpsr {
 void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B);
 void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
 size_t label_spmm_partial_doubles(int64_t n, int w);
+bool launch_label_spmm_multi(hipStream_t s, int64_t n, const uint32_t* L, const uint64_t* keys, int G, int64_t d, const double* W,
+                             int64_t ldw, int w, double* partials, double* Y, int64_t ldy);
 bool launch_label_spmm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, int64_t d, const double* W,
                        int64_t ldw, int w, double* partials, double* Y, int64_t ldy);
 void launch_tall_times_small(hipStream_t s, int64_t n, int64_t ldi, const double* In, int kk, const double* S,
@@ -1941,7 +1943,18 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         // candidates: W[:, w + g*w + (0:w)] = A_g W for fresh generic elements A_g (rows >= n zero)
         double* Y = W + (size_t)w * ld;
         HIP_TRY(c, hipMemsetAsync(Y, 0, (size_t)ld * round_up(m, 128) * 8, s));
-        for (int gidx = 0; gidx < G; ++gidx) {
+        bool batched = false;
+        if (fused && G > 1 && G != 3 && G * w <= 64 && !getenv("SDPSR_SPMM_ONE_BY_ONE")) {
+            // the G generic elements of the round in one pass over the labels
+            double* part = (double*)ctx_buf(c, "cm_part", label_spmm_partial_doubles(n, 64) * 8);
+            if (!part) return SDPSR_OUT_OF_MEMORY;
+            uint64_t keys[4];
+            const uint64_t save = c->stream_counter;
+            for (int gidx = 0; gidx < G; ++gidx) keys[gidx] = next_key(c);
+            batched = launch_label_spmm_multi(s, n, L, keys, G, d, W, ld, w, part, Y, ld);
+            if (!batched) c->stream_counter = save;
+        }
+        for (int gidx = 0; gidx < G && !batched; ++gidx) {
             int e2 = apply_generic(w, Y + (size_t)gidx * w * ld);
             if (e2) return e2;
         }

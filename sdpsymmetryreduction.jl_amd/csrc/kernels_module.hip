@@ -128,24 +128,35 @@ __global__ void transpose_pad_w_kernel(int n, int npad, int w, int jw, const dou
     }
 }
 
-template <int WMAX>
+// G generic elements A_g (keys k[g]) applied to the same W in ONE pass over the labels:
+// Y[:, g w + j] = (A_g W)[:, j].  The growth rounds of the module-compression driver draw 2-4
+// elements per round; one launch per element read the label matrix that many times.
+struct SpmmKeys {
+    uint64_t k[4];
+};
+template <int WMAX, int G>
 __global__ void __launch_bounds__(256)
-label_spmm_sload_kernel(int n, int npad, const uint32_t* __restrict__ L, uint64_t key, int d,
+label_spmm_sload_kernel(int n, int npad, const uint32_t* __restrict__ L, SpmmKeys keys, int d,
                         const double* __restrict__ Wt, int w, int cols_per_block, double* __restrict__ P) {
     constexpr int JW = WMAX / 4;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sV = smem;  // [d + 1] class values
+    double* sV = smem;  // [G][d + 1] class values
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = blockIdx.x * 64 + lane;
     const int c_begin = blockIdx.y * cols_per_block;
     int c_end = c_begin + cols_per_block;
     if (c_end > n) c_end = n;
-    for (int i = tid; i <= d; i += 256) sV[i] = i ? sdpsr_class_uniform(key, (uint32_t)i) : 0.0;
-    __syncthreads();
-    double acc[JW];
+    const int dv = d + 1;
 #pragma unroll
-    for (int j = 0; j < JW; ++j) acc[j] = 0.0;
+    for (int g = 0; g < G; ++g)
+        for (int i = tid; i <= d; i += 256) sV[g * dv + i] = i ? sdpsr_class_uniform(keys.k[g], (uint32_t)i) : 0.0;
+    __syncthreads();
+    double acc[G][JW];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < JW; ++j) acc[g][j] = 0.0;
     const double* __restrict__ Ww = Wt + (int64_t)wave * npad * JW;
     const bool row_ok = r < n;
 #pragma unroll 1
@@ -158,19 +169,24 @@ label_spmm_sload_kernel(int n, int npad, const uint32_t* __restrict__ L, uint64_
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const double v = sV[lab[u]];
             const double* __restrict__ wr = Ww + (int64_t)(cb + u) * JW;  // uniform address (rows >= n are zero)
 #pragma unroll
-            for (int j = 0; j < JW; ++j) acc[j] = fma(v, wr[j], acc[j]);
+            for (int g = 0; g < G; ++g) {
+                const double v = sV[g * dv + lab[u]];
+#pragma unroll
+                for (int j = 0; j < JW; ++j) acc[g][j] = fma(v, wr[j], acc[g][j]);
+            }
         }
     }
     if (row_ok) {
-        double* p = P + (int64_t)blockIdx.y * n * w;
+        double* p = P + (int64_t)blockIdx.y * n * (G * w);
 #pragma unroll
-        for (int j = 0; j < JW; ++j) {
-            const int jj = wave * JW + j;
-            if (jj < w) p[r + (int64_t)jj * n] = acc[j];
-        }
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int jj = wave * JW + j;
+                if (jj < w) p[r + (int64_t)(g * w + jj) * n] = acc[g][j];
+            }
     }
 }
 
@@ -195,10 +211,11 @@ size_t label_spmm_partial_doubles(int64_t n, int w) {
     return (size_t)zg * n * 64 + (size_t)(n + 8) * 64;  // partial sums + transposed copy of W
 }
 
-// returns false when the shape is not supported (w > 64 or the class table does not fit in LDS)
-bool launch_label_spmm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, int64_t d, const double* W,
-                       int64_t ldw, int w, double* partials, double* Y, int64_t ldy) {
-    if (w < 1 || w > 64 || d > 4000) return false;
+// returns false when the shape is not supported (w > 64 or the class table does not fit in LDS).
+// G keys: Y gets G blocks of w columns (G w <= 64).
+bool launch_label_spmm_multi(hipStream_t s, int64_t n, const uint32_t* L, const uint64_t* keys, int G, int64_t d, const double* W,
+                             int64_t ldw, int w, double* partials, double* Y, int64_t ldy) {
+    if (w < 1 || G < 1 || G > 4 || G == 3 || G * w > 64 || d > 4000 || (size_t)G * (d + 2) * 8 > 64 * 1024) return false;
     const int rb = (int)((n + 63) / 64);
     int zg = 2048 / rb;
     if (zg < 1) zg = 1;
@@ -211,21 +228,38 @@ bool launch_label_spmm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key
     // transposed zero-padded copy of W behind the partial sums (label_spmm_partial_doubles leaves room)
     double* Wt = partials + (size_t)zg_cap * n * 64;
     const int npad = (int)n + 8;
+    SpmmKeys kk;
+    for (int i = 0; i < 4; ++i) kk.k[i] = keys[i < G ? i : 0];
     auto go = [&](auto kern, int wmax) {
         transpose_pad_w_kernel<<<(unsigned)std::min<int64_t>(((int64_t)npad * wmax + 255) / 256, 2048), 256, 0, s>>>(
             (int)n, npad, w, wmax / 4, W, ldw, Wt);
-        const size_t lds = ((size_t)d + 2) * sizeof(double);
-        kern<<<g, 256, lds, s>>>((int)n, npad, L, key, (int)d, Wt, w, cpb, partials);
+        const size_t lds = (size_t)G * ((size_t)d + 2) * sizeof(double);
+        kern<<<g, 256, lds, s>>>((int)n, npad, L, kk, (int)d, Wt, w, cpb, partials);
     };
-    if (w <= 8) go(label_spmm_sload_kernel<8>, 8);
-    else if (w <= 16) go(label_spmm_sload_kernel<16>, 16);
-    else if (w <= 32) go(label_spmm_sload_kernel<32>, 32);
-    else if (w <= 48) go(label_spmm_sload_kernel<48>, 48);
-    else go(label_spmm_sload_kernel<64>, 64);
-    int64_t gr = ((int64_t)n * w + 255) / 256;
+    if (G == 1) {
+        if (w <= 8) go(label_spmm_sload_kernel<8, 1>, 8);
+        else if (w <= 16) go(label_spmm_sload_kernel<16, 1>, 16);
+        else if (w <= 32) go(label_spmm_sload_kernel<32, 1>, 32);
+        else if (w <= 48) go(label_spmm_sload_kernel<48, 1>, 48);
+        else go(label_spmm_sload_kernel<64, 1>, 64);
+    } else if (G == 2) {
+        if (w <= 8) go(label_spmm_sload_kernel<8, 2>, 8);
+        else if (w <= 16) go(label_spmm_sload_kernel<16, 2>, 16);
+        else go(label_spmm_sload_kernel<32, 2>, 32);
+    } else {
+        if (w <= 8) go(label_spmm_sload_kernel<8, 4>, 8);
+        else go(label_spmm_sload_kernel<16, 4>, 16);
+    }
+    const int wt = G * w;
+    int64_t gr = ((int64_t)n * wt + 255) / 256;
     if (gr > 2048) gr = 2048;
-    label_spmm_reduce_kernel<<<(unsigned)gr, 256, 0, s>>>((int)n, w, zg, partials, Y, ldy);
+    label_spmm_reduce_kernel<<<(unsigned)gr, 256, 0, s>>>((int)n, wt, zg, partials, Y, ldy);
     return true;
+}
+bool launch_label_spmm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, int64_t d, const double* W,
+                       int64_t ldw, int w, double* partials, double* Y, int64_t ldy) {
+    if (w > 64) return false;
+    return launch_label_spmm_multi(s, n, L, &key, 1, d, W, ldw, w, partials, Y, ldy);
 }
 
 }  // namespace sdpsr
