@@ -1919,8 +1919,8 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     // level 1: S x = span{P_i x}: all d class sums of x in ONE pass over the labels (the
     // row-sum kernel of basis_image with a single column).  For a commutative algebra this
     // already is the whole module.
-    if (ld == n && basis_image_two_stage_fits(n, d, 1) && d <= ycap && d + 1 < wmax) {
-        launch_class_sums(s, n, d, L, W, W + (size_t)w * ld);  // W[:, w + i] = P_{i+1} x
+    if (class_sums_supports(n, d, ld) && basis_image_two_stage_fits(n, d, 1) && d <= ycap && d + 1 < wmax) {
+        launch_class_sums(s, n, d, L, W, W + (size_t)w * ld, ld);  // W[:, w + i] = P_{i+1} x
         const int got = absorb((int)d);
         if (got < 0) {
             tm.end();

@@ -730,7 +730,7 @@ bool basis_image_two_stage_fits(int64_t n, int64_t d, int64_t S1) {
 // Workgroup = 4 waves = 4 rows at a time, sharing x.
 __global__ void __launch_bounds__(256)
 class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict__ L, const double* __restrict__ x,
-                          double* __restrict__ out) {
+                          double* __restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) double cs_smem[];
     double* sx = cs_smem;                                  // [n]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -764,7 +764,7 @@ class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict_
             for (int i = 1 + lane; i <= d; i += 64) {
                 double t = 0;
                 for (int l2 = 0; l2 < 64; ++l2) t += acc[(size_t)l2 * tstride + i];
-                out[(int64_t)(i - 1) * n + r] = t;
+                out[(int64_t)(i - 1) * ldo + r] = t;
             }
         __syncthreads();
     }
@@ -784,13 +784,18 @@ void blockdiag_set_device_attributes() {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 
-void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out) {
+// ldo: distance between the output columns (>= n; rows >= n are not written)
+bool class_sums_supports(int64_t n, int64_t d, int64_t ldo) {
+    const int tstride = (int)((d + 1) | 1);
+    return ldo == n || ((size_t)n + (size_t)4 * 64 * tstride) * sizeof(double) <= 150 * 1024;
+}
+void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out, int64_t ldo) {
     const int tstride = (int)((d + 1) | 1);
     const size_t lds_small = ((size_t)n + (size_t)4 * 64 * tstride) * sizeof(double);
     if (lds_small <= 150 * 1024) {
         int g = (int)((n + 3) / 4);
         if (g > 256) g = 256;  // one resident workgroup per CU, rows in rounds
-        class_sums_small_d_kernel<<<g, 256, lds_small, s>>>((int)n, (int)d, tstride, L, x, out);
+        class_sums_small_d_kernel<<<g, 256, lds_small, s>>>((int)n, (int)d, tstride, L, x, out, ldo);
         return;
     }
     const size_t lds = (size_t)2 * (d + 2) * 4 + (size_t)n * 2 + 16;

@@ -298,7 +298,8 @@ void launch_basis_image_outer(hipStream_t s, int64_t n, int64_t d, int64_t S1, i
                               const int32_t* blk_col, const int32_t* blk_size, const int64_t* blk_off, double atol,
                               double* out);
 // out[r + i*n] = sum over c with L[c + r*n] == i+1 of x[c]   (class sums of a vector, i < d)
-void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out);
+bool class_sums_supports(int64_t n, int64_t d, int64_t ldo);
+void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, const double* x, double* out, int64_t ldo);
 void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S,
                                   const uint32_t* L, const double* Qrm, double* T, const int32_t* colA,
                                   const int32_t* colB, double atol, double* out);
