@@ -1386,6 +1386,9 @@ struct EigInfo {
     std::vector<double> vals;
     std::vector<int> ptrs;  // 0-based boundaries, size neig+1
     std::vector<int> kpart; // root of every eigenspace
+    // "bd_t" holds T = A2 Q for the ONE generic element A2 whose couplings decided the classes
+    // (false after extra coupling elements: the decisive block may come from any of them)
+    bool t_valid = false;
 };
 
 
@@ -1481,8 +1484,9 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     HIP_TRY(c, hipMemsetAsync(dnorms, 0, (size_t)neig * neig * 8, s));
     st = prefetched ? gen->join() : make_element(c, gen, n, ld, L, Ap);
     if (st) return st;
-    if (n <= 64) {  // small (compressed) problems: one workgroup does Q'AQ and the block maxima
-        launch_small_qtaq_block_norms(s, n, ld, Ap, Q, dspace, neig, dnorms, nullptr);
+    info.t_valid = true;
+    if (n <= 64) {  // small (compressed) problems: one workgroup does Q'AQ and the block maxima (T = A Q goes to Tp)
+        launch_small_qtaq_block_norms(s, n, ld, Ap, Q, dspace, neig, dnorms, nullptr, Tp);
     } else {
         launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);   // T = A Q (A symmetric)
         launch_gemm_tn_f64(s, ld, ld, ld, Q, ld, Tp, ld, Ap, ld, 1, 0, 0, 0);   // M = Q' T  (into Ap)
@@ -1524,6 +1528,7 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
                 return st;
             }
         }
+        info.t_valid = false;  // the classes now rest on several coupling elements
         int e2 = make_element(c, gen, n, ld, L, Ap);
         if (e2) return e2;
         launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);
@@ -1606,6 +1611,22 @@ int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen*
         double* F = (double*)ctx_buf(c, "bd_f", (size_t)ld * nfp * 8);
         Bf = (double*)ctx_buf(c, "bd_bf", (size_t)ld * nfp * 8);
         if (!A3 || !F || !Bf) return SDPSR_OUT_OF_MEMORY;
+        static const bool fresh = getenv("SDPSR_FRESH_IRREDUCIBLE_ELEMENT") != nullptr;
+        double* Tq = (double*)ctx_buf(c, "bd_t", (size_t)ld * ld * 8);
+        if (info.t_valid && Tq && !fresh) {
+            // B = A F needs A q for the first eigenvector q of every merged eigenspace: those are
+            // columns of T = A2 Q, which the isomorphism step has just formed.  The reference draws
+            // a third generic element here (:306); any generic element of the algebra serves, and
+            // A2 is the one whose blocks between the merged eigenspaces are known to be large
+            // (they passed the Otsu threshold).  Saves an element, its products and ~neig copies.
+            std::vector<int32_t> bsrc, bdst;
+            for (int j = 0; j < neig; ++j)
+                if (fcol[j] >= 0) {
+                    bsrc.push_back((int32_t)info.ptrs[j]);
+                    bdst.push_back((int32_t)fcol[j]);
+                }
+            launch_copy_cols(s, n, (int64_t)bsrc.size(), bsrc.data(), bdst.data(), Tq, ld, Bf, ld);
+        } else {
         st = make_element(c, gen, n, ld, L, A3);  // generic element #3 (:306)
         if (st) return st;
         HIP_TRY(c, hipMemsetAsync(F, 0, (size_t)ld * nfp * 8, s));
@@ -1614,6 +1635,7 @@ int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen*
                 HIP_TRY(c, hipMemcpyAsync(F + (size_t)fcol[j] * ld, Q + (size_t)info.ptrs[j] * ld, n * 8,
                                           hipMemcpyDeviceToDevice, s));
         launch_gemm_tn_f64(s, ld, nfp, ld, A3, ld, F, ld, Bf, ld, 1, 0, 0, 0);  // B = A3' F = A3 F
+        }
     }
     int64_t col = 0;
     std::vector<int32_t> cp_src, cp_dst;  // first members, copied in one launch after the loop

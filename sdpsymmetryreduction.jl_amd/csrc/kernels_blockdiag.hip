@@ -55,7 +55,7 @@ __global__ void block_norms_kernel(int64_t n, int64_t ld, const double* __restri
 __global__ void __launch_bounds__(1024)
 small_qtaq_block_norms_kernel(int n, int64_t ld, const double* __restrict__ A, const double* __restrict__ Q,
                               const int32_t* __restrict__ space_of, int neig, unsigned long long* __restrict__ norms,
-                              double* __restrict__ Mout) {
+                              double* __restrict__ Mout, double* __restrict__ Tout) {
     extern __shared__ __attribute__((aligned(16))) double sq[];
     const int ldl = n | 1;
     double* sA = sq;
@@ -73,6 +73,7 @@ small_qtaq_block_norms_kernel(int n, int64_t ld, const double* __restrict__ A, c
         double acc = 0.0;
         for (int k = 0; k < n; ++k) acc = fma(sA[k + i * ldl], sQ[k + j * ldl], acc);
         sT[i + j * ldl] = acc;
+        if (Tout) Tout[i + (int64_t)j * ld] = acc;
     }
     __syncthreads();
     for (int e = tid; e < n * n; e += nthr) {  // M[a, b] = Q[:, a]' T[:, b]
@@ -85,9 +86,9 @@ small_qtaq_block_norms_kernel(int n, int64_t ld, const double* __restrict__ A, c
     }
 }
 void launch_small_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* Q,
-                                   const int32_t* space_of, int neig, unsigned long long* norms, double* Mout) {
+                                   const int32_t* space_of, int neig, unsigned long long* norms, double* Mout, double* Tout) {
     const size_t lds = (size_t)3 * (n | 1) * n * 8;
-    small_qtaq_block_norms_kernel<<<1, 1024, lds, s>>>((int)n, ld, A, Q, space_of, neig, norms, Mout);
+    small_qtaq_block_norms_kernel<<<1, 1024, lds, s>>>((int)n, ld, A, Q, space_of, neig, norms, Mout, Tout);
 }
 void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
                         const int32_t* space_of, int neig, unsigned long long* norms) {

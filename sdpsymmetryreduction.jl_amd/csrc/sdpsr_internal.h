@@ -262,7 +262,7 @@ void launch_gemm_tn_f64(hipStream_t s, int64_t m, int64_t n, int64_t k, const do
 // norms[bi*neig+bj] = max |M[i,j]| over the (bi,bj) eigenspace block; space_of[n] maps an
 // index to its eigenspace.  norms must be zeroed (as uint64 bit patterns of doubles).
 void launch_small_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* Q,
-                                   const int32_t* space_of, int neig, unsigned long long* norms, double* Mout);
+                                   const int32_t* space_of, int neig, unsigned long long* norms, double* Mout, double* Tout = nullptr);
 void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
                         const int32_t* space_of, int neig, unsigned long long* norms);
 // y = A * x for symmetric A (n x n, ld) and nv vectors (columns of X, ldx): Y[:,v]
