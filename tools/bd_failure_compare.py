@@ -34,6 +34,7 @@ else:
                 bd = pkg.blockDiagonalize(P, ctx=ctx)
                 if sorted(bd.blkSizes) != expect:
                     fails["wrong_sizes"] = fails.get("wrong_sizes", 0) + 1
+                    print("run", s, "sizes", sorted(bd.blkSizes), flush=True)
             except pkg.SdpsrError as e:
                 fails[type(e).__name__] = fails.get(type(e).__name__, 0) + 1
 print(who, "N", L.shape[0], "dim", d, "runs", runs, "failures", fails, "%.1f s" % (time.time() - t0))
