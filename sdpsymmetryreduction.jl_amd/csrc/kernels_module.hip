@@ -222,7 +222,7 @@ bool launch_label_spmm_multi(hipStream_t s, int64_t n, const uint32_t* L, const 
     if (zg > 32) zg = 32;
     const int zg_cap = zg;
     int cpb = (int)((n + zg - 1) / zg);
-    cpb = (cpb + 127) / 128 * 128;
+    cpb = (cpb + 7) / 8 * 8;  // the kernel walks its columns in steps of 8 (rounding to 128 halved the grid at n = 4104)
     zg = (int)((n + cpb - 1) / cpb);
     dim3 g((unsigned)rb, (unsigned)zg);
     // transposed zero-padded copy of W behind the partial sums (label_spmm_partial_doubles leaves room)
