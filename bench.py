@@ -367,8 +367,17 @@ def main():
         ms = prof(8, wdim, reps=10)
         kernels["small_syev_jacobi64"] = {"ms": round(ms, 4), "order": wdim, "bound": "latency (one workgroup, LDS-resident)",
                                           "rocprof_avg_us": rocprof_average_us("small_syev_jacobi64_kernel")}
-        kernels["label_spmm_sload"] = {"bound": "fp64 FMA", "algorithmic_bytes": 4 * n * n, "rocprof_avg_us": rocprof_average_us("label_spmm_sload_kernel"),
-                                       "note": "Y = A(v) W straight from the labels, 2*N^2*w flop; duration from the committed rocprofv3 summary"}
+        # Y = A(v) W straight from the labels on v_mfma_f64_16x16x4_f64 (w = the compressed order): the time is the
+        # whole product (transposed copy of W + MFMA kernel + reduction of the partial sums); executed flop =
+        # 2 N^2 * 16*ceil(w/16) (whole 16-column tiles), useful = 2 N^2 w
+        ms = prof(9, n, aux=wdim | (1 << 8) | (int(d) << 12), reps=20)
+        fl_exec = 2.0 * n * n * 16 * ((wdim + 15) // 16)
+        kernels["label_spmm_mfma"] = {"ms": round(ms, 4), "w": wdim, "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TF,
+                                      "achieved": round(fl_exec / (ms * 1e-3) / 1e12, 2), "frac": round(fl_exec / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4),
+                                      "useful": round(2.0 * n * n * wdim / (ms * 1e-3) / 1e12, 2), "algorithmic_bytes": 4 * n * n,
+                                      "rocprof_avg_us": {"label_spmm_mfma_kernel": rocprof_average_us("label_spmm_mfma_kernel"),
+                                                         "label_spmm_reduce_kernel": rocprof_average_us("label_spmm_reduce_kernel"),
+                                                         "transpose_w_rowmajor_kernel": rocprof_average_us("transpose_w_rowmajor_kernel")}}
         # dense driver: the symmetric-product kernel of the tridiagonalisation, launched once per
         # column j; algorithmic bytes of launch j = 8 * (n-j-1)^2 / 2 (the LOWER triangle of the
         # trailing matrix is read once), 8*n*(2n-1)/12 on average

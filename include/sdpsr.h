@@ -290,7 +290,11 @@ int sdpsr_syev_f64(sdpsr_ctx* ctx, int64_t n, const double* A, double* values, d
    4 = fused gather+projection+signature pass with r = aux basis vectors,
    5 = the tridiagonalisation's symmetric-product (symv) kernel, one launch per column j = 0..n-2
        (average over the n-1 launches), 6 = one whole tridiagonalisation of order n,
-   8 = the one-workgroup Jacobi eigensolver on a random symmetric matrix of order n <= 128.
+   8 = the one-workgroup Jacobi eigensolver on a random symmetric matrix of order n <= 128,
+   9 = the label product Y = A(v) W of the module-compression driver (n x n labels with d classes,
+       W n x w, G elements per pass): aux = w | G << 8 | d << 12; with bit 30 of aux set the call
+       returns in ms_per_launch[0] the largest absolute deviation of sampled rows of Y from a host
+       evaluation in extended precision instead of the time.
    ms_per_launch[0] = average milliseconds per launch. */
 int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps,
                          double* ms_per_launch);

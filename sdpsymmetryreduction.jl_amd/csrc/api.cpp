@@ -424,6 +424,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
     // per-device kernel attributes (dynamic LDS above 64 KiB); cheap and idempotent
     gemm_set_device_attributes();
     blockdiag_set_device_attributes();
+    module_set_device_attributes();
     partition_set_device_attributes();
     sytrd_set_device_attributes();
     small_syev_set_device_attributes();
@@ -2955,6 +2956,54 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         HIP_TRY(c, hipEventRecord(e0, s));
         for (int i = 0; i < reps; ++i) launch_small_syev(s, n, A + (size_t)i * n * n, n, wv, Vt, info);
         HIP_TRY(c, hipEventRecord(e1, s));
+    } else if (kind == 9) {
+        // label product Y = A(v) W of the module-compression driver: aux = w | G << 8 | d << 12 (| 1 << 30:
+        // report the largest deviation from a host evaluation of sampled rows instead of the time)
+        const int w = (int)(aux & 0xff), G = ((aux >> 8) & 0xf) ? (int)((aux >> 8) & 0xf) : 1;
+        const int64_t d = ((aux >> 12) & 0xffff) ? ((aux >> 12) & 0xffff) : 34;
+        const bool verify = (aux >> 30) & 1;
+        if (w < 1 || G * w > 64) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "kind 9: 1 <= G w <= 64");
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)n * n * 4);
+        double* W = (double*)ctx_buf(c, "prof_x", (size_t)n * w * 8);
+        double* Y = (double*)ctx_buf(c, "prof_c", (size_t)n * G * w * 8);
+        double* part = (double*)ctx_buf(c, "cm_part", label_spmm_partial_doubles(n, 64) * 8);
+        if (!Lb || !W || !Y || !part) return SDPSR_OUT_OF_MEMORY;
+        std::vector<uint32_t> hl((size_t)n * n);
+        std::vector<double> hw((size_t)n * w);
+        for (size_t e = 0; e < hl.size(); ++e) hl[e] = (uint32_t)(sdpsr_fmix64(e * 2654435761ull + 17) % (uint64_t)(d + 1));
+        for (size_t e = 0; e < hw.size(); ++e) hw[e] = 2.0 * ((double)(sdpsr_fmix64(e + 99991) >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+        const uint64_t keys[4] = {0x1234567ull, 0x89abcdefull, 0x13579bdfull, 0x2468aceull};
+        HIP_TRY(c, hipMemcpyAsync(Lb, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(W, hw.data(), hw.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (!launch_label_spmm_multi(s, n, Lb, keys, G, d, W, n, w, part, Y, n))
+            return ctx_fail(c, SDPSR_BAD_ARGUMENT, "kind 9: shape not supported by the label product");
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) launch_label_spmm_multi(s, n, Lb, keys, G, d, W, n, w, part, Y, n);
+        HIP_TRY(c, hipEventRecord(e1, s));
+        if (verify) {
+            std::vector<double> hy((size_t)n * G * w);
+            HIP_TRY(c, hipMemcpyAsync(hy.data(), Y, hy.size() * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            double worst = 0;
+            const int64_t rows[12] = {0, 1, 15, 16, 17, 63, 64, n / 3, n / 2, n - 17, n - 2, n - 1};
+            for (int64_t r : rows) {
+                if (r < 0 || r >= n) continue;
+                for (int g = 0; g < G; ++g)
+                    for (int j = 0; j < w; ++j) {
+                        long double acc = 0;
+                        for (int64_t cc = 0; cc < n; ++cc) {
+                            const uint32_t lab = hl[(size_t)r + (size_t)cc * n];
+                            if (lab) acc += (long double)sdpsr_class_uniform(keys[g], lab) * hw[(size_t)cc + (size_t)j * n];
+                        }
+                        worst = std::max(worst, std::fabs((double)acc - hy[(size_t)r + (size_t)(g * w + j) * n]));
+                    }
+            }
+            ms_per_launch[0] = worst;
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+            return SDPSR_OK;
+        }
     } else {
         return ctx_fail(c, SDPSR_BAD_ARGUMENT, "unknown kernel kind");
     }

@@ -2,6 +2,7 @@
 // Y = A(v) W straight from the labels (label_spmm), tall-times-small products, split-K
 // reductions and the small glue around them; plus helpers shared with the setup stage.
 #include <algorithm>
+#include <type_traits>
 #include "sdpsr_internal.h"
 
 namespace sdpsr {
@@ -203,12 +204,186 @@ __global__ void label_spmm_reduce_kernel(int n, int w, int Z, const double* __re
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same product on the fp64 matrix cores.  Y = A W is a GEMM whose left operand is formed on the
+// fly: v_mfma_f64_16x16x4_f64 wants A as one double per lane (row m = lane & 15, k = lane >> 4), which
+// is exactly one label look-up per lane per four matrix columns -- shared by all JT 16-column tiles
+// of W, where the VALU form above spends one look-up per wave and column for WMAX/4 outputs only and
+// waits on a scalar load per column.  Workgroup = 64 rows (wave = 16 rows) x a column range, walked
+// in slabs of 64 columns: the slab of W' (row-major [c][STRIDE], STRIDE = 16 mod 32 doubles: the
+// 4 x 16 operand read of a half-wave touches every LDS bank once) sits in one of two LDS buffers,
+// the next slab travels global -> registers -> the other buffer behind the MFMAs of the current one
+// (one barrier per slab), the labels of the next slab (16 steps of four columns) are prefetched
+// meanwhile.  Per step and wave: 1 label load, G look-ups, JT operand reads, G*JT MFMAs.  The column
+// split is as small as keeps two or three workgroups on every CU: the partial sums (z n w doubles,
+// written here and read by the reduction) are the second HBM stream next to the 4 n^2 label bytes.
+// Bound: the fp64 MFMA rate, 2 n^2 (16 JT) flop per element.  Fixed summation order: reproducible.
+// ---------------------------------------------------------------------------
+typedef double spmm_v4d __attribute__((ext_vector_type(4)));
+constexpr int spmm_stride(int jt) { return (jt * 16) % 32 == 16 ? jt * 16 : jt * 16 + 16; }
+constexpr int SPMM_SLAB = 64;  // columns per slab = 16 steps
+
+// Wt[c][STRIDE] = W[c][0..w) zero-padded, rows c >= n zero.  32 x 32 tiles through LDS: reads walk a
+// column of W, writes a row of W'.  grid (ceil(rows / 32), ceil(stride / 32)), block (32, 8).
+__global__ void __launch_bounds__(256)
+transpose_w_rowmajor_kernel(int n, int64_t rows, int w, int stride, const double* __restrict__ W, int64_t ldw,
+                            double* __restrict__ Wt) {
+    __shared__ double tile[32][33];
+    const int c0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (j < w && c < n) ? W[c + (int64_t)j * ldw] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, j = j0 + tx;
+        if (c < rows && j < stride) Wt[(int64_t)c * stride + j] = tile[tx][ty + 8 * k];
+    }
+}
+
+template <int JT, int G>
+__global__ void __launch_bounds__(256)
+label_spmm_mfma_kernel(int n, const uint32_t* __restrict__ L, SpmmKeys keys, int d, const double* __restrict__ Wt,
+                       int w, int cols_per_block, double* __restrict__ P) {
+    constexpr int STRIDE = spmm_stride(JT);
+    constexpr int U = SPMM_SLAB / 4;             // steps of four columns per slab
+    constexpr int SP = SPMM_SLAB * STRIDE / 2;   // double2 per slab: a multiple of 256 for every STRIDE
+    constexpr int K = SP / 256;
+    static_assert(SP % 256 == 0, "slab copy without guards");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dv = (d + 2) & ~1;  // class values per element, even: the slabs stay 16-byte aligned
+    double* sV = smem;            // [G][dv]
+    double* sW = smem + G * dv;   // [2][SPMM_SLAB][STRIDE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int c_begin = blockIdx.y * cols_per_block;
+    const int nsteps = cols_per_block >> 2;
+    const int nslabs = (nsteps + U - 1) / U;
+    // label of (row, c_begin + 4 step + kq).  No masking: the address is clamped into the matrix and what a
+    // clamped load brings is harmless -- rows >= n are never stored (an output row depends on its own
+    // operand row only), columns >= n meet the zero rows of W', steps >= nsteps are never used.
+    const int row = blockIdx.x * 64 + wave * 16 + m;
+    const uint32_t* Lr = L + (row < n ? row : n - 1);
+    auto fetch = [&](int step) -> uint32_t {
+        int c = c_begin + 4 * step + kq;
+        c = c < n ? c : n - 1;
+        return Lr[(int64_t)c * n];
+    };
+    // slab sl of W' -> registers (W' has SPMM_SLAB zero or foreign rows behind the last range: never multiplied)
+    typedef double spmm_v2d __attribute__((ext_vector_type(2)));
+    spmm_v2d t[K];
+    auto slab_load = [&](int sl) {
+        const spmm_v2d* src = reinterpret_cast<const spmm_v2d*>(Wt + ((int64_t)c_begin + (int64_t)sl * SPMM_SLAB) * STRIDE);
+#pragma unroll
+        for (int k = 0; k < K; ++k) t[k] = src[tid + 256 * k];
+    };
+    auto slab_store = [&](int buf) {
+        spmm_v2d* dst = reinterpret_cast<spmm_v2d*>(sW + buf * (SPMM_SLAB * STRIDE));
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[tid + 256 * k] = t[k];
+    };
+    uint32_t cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = fetch(u);  // in flight while the tables are filled
+    slab_load(0);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        for (int i = tid; i <= d; i += 256) sV[g * dv + i] = i ? sdpsr_class_uniform(keys.k[g], (uint32_t)i) : 0.0;
+    slab_store(0);
+    __syncthreads();
+    spmm_v4d acc[G][JT];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) acc[g][jt] = spmm_v4d{0.0, 0.0, 0.0, 0.0};
+    // operands of step st (LDS -> registers) and the MFMAs on them: the reads of step st + 1 are issued
+    // before the MFMAs of step st (pinned with sched_barrier).  Measured: the same time as with the reads
+    // behind the MFMAs -- with loads, LDS reads and barriers all removed the loop runs within 12 % of
+    // the full kernel; what separates it from the 64 clocks per MFMA of tools/probes/mfma_f64_probe.hip
+    // is the prologue / epilogue of a 30 us launch, not the steady state.
+    auto rd = [&](const double* wl, int st, uint32_t lab, double (&a)[G], double (&b)[JT]) {
+        const double* wr = wl + st * (4 * STRIDE);
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[g] = sV[g * dv + lab];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) b[jt] = wr[jt * 16];
+    };
+    auto mm = [&](const double (&a)[G], const double (&b)[JT]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+                acc[g][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[jt], a[g], acc[g][jt], 0, 0, 0);
+    };
+#pragma unroll 1
+    for (int sl = 0; sl < nslabs; ++sl) {
+        const bool more = sl + 1 < nslabs;  // uniform
+        if (more) slab_load(sl + 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = fetch((sl + 1) * U + u);
+        const double* wl = sW + (sl & 1) * (SPMM_SLAB * STRIDE) + kq * STRIDE + m;
+        const int ns = nsteps - sl * U;
+        if (ns >= U) {  // whole slab: no branches
+            double a0[G], b0[JT], a1[G], b1[JT];
+            rd(wl, 0, cur[0], a0, b0);
+#pragma unroll
+            for (int u = 0; u < U; u += 2) {
+                rd(wl, u + 1, cur[u + 1], a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 2 < U) rd(wl, u + 2, cur[u + 2], a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u < ns) {  // uniform
+                    double a0[G], b0[JT];
+                    rd(wl, u, cur[u], a0, b0);
+                    mm(a0, b0);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        if (more) slab_store((sl + 1) & 1);  // the buffer read two slabs ago: everybody is past the barrier since
+        __syncthreads();
+    }
+    // D[j][r]: r = lane & 15 (matrix row), j = (lane >> 4) + 4 * reg (column of the tile)
+    if (row < n) {
+        double* p = P + (int64_t)blockIdx.y * n * (G * w);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int jj = jt * 16 + kq + 4 * v;
+                    if (jj < w) p[row + (int64_t)(g * w + jj) * n] = acc[g][jt][v];
+                }
+    }
+}
+
+// per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes): two slabs of the
+// four-tile form are 80 KiB
+void module_set_device_attributes() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&label_spmm_mfma_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        150 * 1024);
+}
+
 size_t label_spmm_partial_doubles(int64_t n, int w) {
     int zg = (int)(2048 / ((n + 63) / 64));
     if (zg < 1) zg = 1;
     if (zg > 32) zg = 32;
     (void)w;
-    return (size_t)zg * n * 64 + (size_t)(n + 8) * 64;  // partial sums + transposed copy of W
+    // partial sums + transposed copy of W (VALU form: (n + 8) x 64; MFMA form: up to (n + 4 zg) x 80)
+    return (size_t)zg * n * 64 + (size_t)(n + 8 + 4 * 128) * 80;
 }
 
 // returns false when the shape is not supported (w > 64 or the class table does not fit in LDS).
@@ -221,6 +396,65 @@ bool launch_label_spmm_multi(hipStream_t s, int64_t n, const uint32_t* L, const 
     if (zg < 1) zg = 1;
     if (zg > 32) zg = 32;
     const int zg_cap = zg;
+    static const bool valu = getenv("SDPSR_SPMM_VALU") != nullptr;  // A/B switch for measurements
+    if (!valu && n >= 64) {
+        // matrix-core form.  Column split z: R = 2 or 3 workgroups on every CU, all resident at once (LDS:
+        // class values + two slabs; registers: >= 4 waves per SIMD for every instantiation), the smallest
+        // estimated time of  R x (columns per workgroup) MFMA steps  +  the partial sums through HBM.
+        const int JT = (w + 15) / 16;
+        const int stride = spmm_stride(JT);
+        const size_t lds = (size_t)G * ((d + 2) & ~(int64_t)1) * 8 + (size_t)2 * SPMM_SLAB * stride * 8;
+        int best_zg = 0, best_cpb = 0;
+        double best_cost = 0;
+        const int64_t lds_fit = (int64_t)(158 * 1024 / lds);
+        for (int R = 1; R <= 3 && R <= lds_fit; ++R) {
+            int64_t z0 = 256 * R / rb;
+            static const int z_env = getenv("SDPSR_SPMM_Z") ? atoi(getenv("SDPSR_SPMM_Z")) : 0;  // measurement knob
+            if (z_env) z0 = z_env;
+            if (z0 < 1) z0 = 1;
+            if (z0 * 32 > n) z0 = std::max<int64_t>(1, n / 32);
+            if (z0 * G * w > (int64_t)zg_cap * 64) z0 = (int64_t)zg_cap * 64 / (G * w);
+            int cp = (int)((n + z0 - 1) / z0);
+            cp = (cp + 3) / 4 * 4;
+            const int z = (int)((n + cp - 1) / cp);
+            const int64_t per_cu = ((int64_t)rb * z + 255) / 256;
+            // microseconds: 64 clocks per MFMA at 2.4 GHz; partial sums written and read at ~4 TB/s
+            const double t_mfma = (double)per_cu * (cp / 4) * (JT * G) * 64.0 / 2400.0 * (per_cu == 1 ? 1.5 : 1.0);
+            const double t_part = (double)z * n * G * w * 16.0 / 4.0e6;
+            const double cost = t_mfma + t_part;
+            if (!best_zg || cost < best_cost) {
+                best_zg = z;
+                best_cpb = cp;
+                best_cost = cost;
+            }
+        }
+        if (best_zg && lds <= (JT == 4 ? 150 : 64) * 1024) {
+            double* Wt = partials + (size_t)zg_cap * n * 64;
+            const int64_t rows = (int64_t)best_zg * best_cpb + SPMM_SLAB;
+            transpose_w_rowmajor_kernel<<<dim3((unsigned)((rows + 31) / 32), (unsigned)((stride + 31) / 32)), dim3(32, 8), 0, s>>>(
+                (int)n, rows, w, stride, W, ldw, Wt);
+            SpmmKeys kk;
+            for (int i = 0; i < 4; ++i) kk.k[i] = keys[i < G ? i : 0];
+            dim3 g((unsigned)rb, (unsigned)best_zg);
+            auto go = [&](auto kern) { kern<<<g, 256, lds, s>>>((int)n, L, kk, (int)d, Wt, w, best_cpb, partials); };
+            if (G == 1) {
+                if (JT == 1) go(label_spmm_mfma_kernel<1, 1>);
+                else if (JT == 2) go(label_spmm_mfma_kernel<2, 1>);
+                else if (JT == 3) go(label_spmm_mfma_kernel<3, 1>);
+                else go(label_spmm_mfma_kernel<4, 1>);
+            } else if (G == 2) {
+                if (JT == 1) go(label_spmm_mfma_kernel<1, 2>);
+                else go(label_spmm_mfma_kernel<2, 2>);
+            } else {
+                go(label_spmm_mfma_kernel<1, 4>);
+            }
+            const int wt = G * w;
+            int64_t gr = ((int64_t)n * wt + 255) / 256;
+            if (gr > 2048) gr = 2048;
+            label_spmm_reduce_kernel<<<(unsigned)gr, 256, 0, s>>>((int)n, wt, best_zg, partials, Y, ldy);
+            return true;
+        }
+    }
     int cpb = (int)((n + zg - 1) / zg);
     cpb = (cpb + 7) / 8 * 8;  // the kernel walks its columns in steps of 8 (rounding to 128 halved the grid at n = 4104)
     zg = (int)((n + cpb - 1) / cpb);

@@ -197,6 +197,7 @@ void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double*
 // them all with the ctx's device current (no process-global "already set" flags).
 void gemm_set_device_attributes();
 void blockdiag_set_device_attributes();
+void module_set_device_attributes();
 void partition_set_device_attributes();
 void sytrd_set_device_attributes();
 void small_syev_set_device_attributes();

@@ -853,3 +853,18 @@ def test_projection_on_the_lower_triangle(pkg, problems, golden):
         Pa = pkg.admissible_subspace(Cv, A2, b2, ctx=ctx, setup=s2)
         Pb = pkg.admissible_subspace(Cv, A2, b2, ctx=ctx)  # device setup, probe
         assert Pa.nparts == Pb.nparts and np.array_equal(Pa.matrix, Pb.matrix)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,w,G,d", [(4096, 34, 1, 34), (4104, 36, 1, 36), (4104, 20, 2, 36), (777, 7, 4, 11),
+                                     (100, 64, 1, 5), (1000, 48, 1, 3000), (65, 1, 1, 2), (1030, 16, 4, 200),
+                                     (513, 17, 2, 1)])
+def test_label_product_on_the_matrix_cores(pkg, gpu_ctx, n, w, G, d):
+    """Y = A(v) W straight from the labels (randomize!, src/abstract_part.jl:107-110, fused into the products of
+    the module-compression driver) on v_mfma_f64_16x16x4_f64: sampled rows against a host evaluation in
+    extended precision, all tile counts (w <= 16 ... 64), 1 / 2 / 4 elements per pass, ragged n, label 0 = 0."""
+    import ctypes as C
+    v = C.c_double(0)
+    aux = w | (G << 8) | (d << 12) | (1 << 30)
+    gpu_ctx.check(gpu_ctx._lib.sdpsr_profile_kernel(gpu_ctx._h, 9, n, aux, 1, C.byref(v)))
+    assert v.value < 1e-11 * n, v.value   # |A| <= 1, |W| <= 1: sums of n products

@@ -33,3 +33,8 @@ for d in 0 1 2 3; do echo "SDPSR_W4_DIAG=$d" >> $O/i8_w4_diag.txt; SDPSR_GEMM_I8
 python3 tools/config_times.py > $O/config_times.txt 2>&1
 python3 tools/config2_bd_phases.py > $O/config2_bd_phases.txt 2>&1
 python3 tools/small_syev_time.py > $O/small_syev_time.txt 2>&1
+# (h) the label product on the matrix cores: per shape, A/B against the VALU form, shader clock, the fp64 MFMA probe
+python3 tools/label_product_time.py > $O/label_product.txt 2>&1
+SDPSR_SPMM_VALU=1 python3 tools/label_product_time.py >> $O/label_product.txt 2>&1
+python3 tools/label_product_clock.py >> $O/label_product.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_f64_probe.hip -o /tmp/mfma_f64_probe 2> /dev/null && /tmp/mfma_f64_probe > $O/mfma_f64_probe.txt 2>&1

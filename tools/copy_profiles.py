@@ -24,7 +24,9 @@ pairs = [(stats("bench"), "r02_bench_n4096_kernel_stats.csv"), (stats("bench_the
          (os.path.join(src, "i8_w4_diag.txt"), "r02_i8_w4_diag.txt"),
          (os.path.join(src, "config_times.txt"), "r02_config_times.txt"),
          (os.path.join(src, "config2_bd_phases.txt"), "r02_config2_bd_phases.txt"),
-         (os.path.join(src, "small_syev_time.txt"), "r02_small_syev_time.txt")]
+         (os.path.join(src, "small_syev_time.txt"), "r02_small_syev_time.txt"),
+         (os.path.join(src, "label_product.txt"), "r02_label_product.txt"),
+         (os.path.join(src, "mfma_f64_probe.txt"), "r02_mfma_f64_probe.txt")]
 for a, b in pairs:
     if a and os.path.exists(a) and os.path.getsize(a) > 0:
         shutil.copyfile(a, os.path.join(dst, b))
