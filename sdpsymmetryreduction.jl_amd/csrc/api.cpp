@@ -1547,6 +1547,9 @@ constexpr int DRIVER_FALLBACK = -1000;
 namespace sdpsr {
 void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B);
 void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
+size_t gram_small_partial_doubles(int64_t k, int ma, int nb);
+void launch_gram_small(hipStream_t s, int64_t k, int ma, int nb, const double* A, int64_t lda, const double* B, int64_t ldb,
+                       double* partials, double* C, int64_t ldc, int mp, int np);
 size_t label_spmm_partial_doubles(int64_t n, int w);
 bool launch_label_spmm_multi(hipStream_t s, int64_t n, const uint32_t* L, const uint64_t* keys, int G, int64_t d, const double* W,
                              int64_t ldw, int w, double* partials, double* Y, int64_t ldy);
@@ -1719,6 +1722,22 @@ int gemm_tn_splitk(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* 
     return SDPSR_OK;
 }
 
+// C = A' B of the exact shape ma x nb (A: k x ma, B: k x nb) into the mp x np padded result (zero
+// outside ma x nb): the skinny Gram kernel when both operands fit its LDS stage, the padded split-K
+// MFMA product otherwise.
+static int gram_tn(sdpsr_ctx* c, int64_t ma, int64_t nb, int64_t k, const double* A, int64_t lda, const double* B, int64_t ldb,
+                   double* C, int64_t mp, int64_t np) {
+    static const bool padded = getenv("SDPSR_GRAM_PADDED_GEMM") != nullptr;  // A/B switch for measurements
+    const int64_t pa = (ma + 15) / 16 * 16 + 1, pb = (nb + 15) / 16 * 16 + 1;
+    if (!padded && ma >= 1 && nb >= 1 && ma <= 128 && nb <= 128 && 32 * (pa + pb) * 8 <= 64 * 1024) {
+        double* P = (double*)ctx_buf(c, "gram_partials", gram_small_partial_doubles(k, (int)ma, (int)nb) * 8);
+        if (!P) return SDPSR_OUT_OF_MEMORY;
+        launch_gram_small(c->stream, k, (int)ma, (int)nb, A, lda, B, ldb, P, C, mp, (int)mp, (int)np);
+        return SDPSR_OK;
+    }
+    return gemm_tn_splitk(c, mp, np, k, A, lda, B, ldb, C, mp);
+}
+
 // ===========================================================================
 // Module-compression driver of diagonalize (DESIGN.md "module compression").
 //
@@ -1856,10 +1875,10 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     // the stacked coefficients S = [-C X; X] ((w+mc) x r) with V_new = [W V] S.  r < 0: error.
     auto ortho_step = [&](int mc, double tol_abs, bool take_ref, std::vector<double>& stacked) -> int {
         const int64_t ap = round_up(w + mc, 128), mp = round_up(mc, 128);
-        abs_err = gemm_tn_splitk(c, ap, mp, ld, W, ld, W + (size_t)w * ld, ld, Cc, ap);
+        abs_err = gram_tn(c, w + mc, mc, ld, W, ld, W + (size_t)w * ld, ld, Cc, ap, mp);
         if (abs_err) return -1;
         hG.resize((size_t)ap * mp);
-        abs_err = d2h_sync(c, hG.data(), Cc, (size_t)ap * mp * 8);
+        abs_err = d2h_sync(c, hG.data(), Cc, (size_t)ap * mc * 8);  // the mc columns the host looks at
         if (abs_err) return -1;
         if (!sym_checked) {  // the stream has been synchronised: the verdict of the symmetric check is in
             sym_checked = true;
@@ -2022,7 +2041,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         }
         HIP_TRY(c, hipMemsetAsync(T, 0, (size_t)ld * wp * 8, s));
         { int e2 = apply_generic(w, T); if (e2) return e2; }   // T = A W
-        gemm_tn_splitk(c, wp, wp, ld, W, ld, T, ld, dst, wp);  // B = W' T  (wp x wp)
+        gram_tn(c, w, w, ld, W, ld, T, ld, dst, wp, wp);  // B = W' T  (w x w in wp x wp)
         launch_symmetrize(s, w, wp, dst);
         return SDPSR_OK;
     };

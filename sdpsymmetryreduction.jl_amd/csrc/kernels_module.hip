@@ -102,6 +102,114 @@ void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, con
 }
 
 // ---------------------------------------------------------------------------
+// Skinny Gram products of the module-compression driver:  C = A' B  with A (k x ma), B (k x nb),
+// ma, nb <= 128 (the basis and candidate columns, a few dozen each) and k = n rows.  Padded to the
+// 128 x 128 tile of the MFMA GEMM with K split over the batch this was one tile per workgroup on
+// 32-64 CUs, 7x the bytes and flop of the exact shape (22 + 9 us at n = 4096).  Here a workgroup
+// takes GS_ROWS rows of both matrices through LDS (transposed, pitch = 1 mod 16 doubles: the
+// column-major reads are coalesced, the transposed writes and the row reads conflict-free), every
+// thread accumulates a 4 x 4 register tile per 64 x 64 output block, the per-workgroup partial
+// sums (exact shape) are added in fixed order by gram_reduce_kernel, which also writes the zero
+// padding of the mp x np result the callers index.
+// ---------------------------------------------------------------------------
+constexpr int GS_ROWS = 32;
+
+__global__ void __launch_bounds__(256)
+gram_partial_kernel(int k, int ma, int nb, const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                    int pa, int pb, double* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) double gs_smem[];
+    double* sA = gs_smem;                 // [GS_ROWS][pa]
+    double* sB = gs_smem + GS_ROWS * pa;  // [GS_ROWS][pb]
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * GS_ROWS;
+    for (int e = tid; e < GS_ROWS * ma; e += 256) {
+        const int r = e & (GS_ROWS - 1), i = e / GS_ROWS;
+        sA[r * pa + i] = (row0 + r < k) ? A[row0 + r + (int64_t)i * lda] : 0.0;
+    }
+    for (int e = tid; e < GS_ROWS * nb; e += 256) {
+        const int r = e & (GS_ROWS - 1), j = e / GS_ROWS;
+        sB[r * pb + j] = (row0 + r < k) ? B[row0 + r + (int64_t)j * ldb] : 0.0;
+    }
+    __syncthreads();
+    const int ti = tid & 15, tj = tid >> 4;
+    double* p = P + (int64_t)blockIdx.x * ma * nb;
+    for (int j0 = 0; j0 < nb; j0 += 64)
+        for (int i0 = 0; i0 < ma; i0 += 64) {
+            // outputs (i0 + ti + 16 a, j0 + tj + 16 b): consecutive lanes read consecutive doubles
+            int ia[4], jb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = i0 + ti + 16 * a, j = j0 + tj + 16 * a;
+                ia[a] = i < ma ? i : ma - 1;
+                jb[a] = j < nb ? j : nb - 1;
+            }
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 4
+            for (int r = 0; r < GS_ROWS; ++r) {
+                double xa[4], yb[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) xa[a] = sA[r * pa + ia[a]];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) yb[b] = sB[r * pb + jb[b]];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(xa[a], yb[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = j0 + tj + 16 * b;
+                if (j < nb) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int i = i0 + ti + 16 * a;
+                        if (i < ma) p[i + (int64_t)j * ma] = acc[a][b];
+                    }
+                }
+            }
+        }
+}
+
+// C[i + j ldc] = sum_z P[z][i + j ma]  (i < ma, j < nb), 0 on the rest of the mp x np result
+__global__ void gram_reduce_kernel(int ma, int nb, int mp, int np, int Z, const double* __restrict__ P, double* __restrict__ C,
+                                   int64_t ldc) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= mp * np) return;
+    const int j = e / mp, i = e - j * mp;
+    double acc = 0;
+    if (i < ma && j < nb) {
+        const double* p = P + i + (int64_t)j * ma;
+        const int64_t stride = (int64_t)ma * nb;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int z = 0;
+        for (; z + 4 <= Z; z += 4) {
+            a0 += p[(int64_t)z * stride];
+            a1 += p[(int64_t)(z + 1) * stride];
+            a2 += p[(int64_t)(z + 2) * stride];
+            a3 += p[(int64_t)(z + 3) * stride];
+        }
+        for (; z < Z; ++z) a0 += p[(int64_t)z * stride];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    C[i + (int64_t)j * ldc] = acc;
+}
+
+size_t gram_small_partial_doubles(int64_t k, int ma, int nb) { return (size_t)((k + GS_ROWS - 1) / GS_ROWS) * ma * nb; }
+// ma, nb <= 128; C gets the mp x np (padded) result, ldc >= mp
+void launch_gram_small(hipStream_t s, int64_t k, int ma, int nb, const double* A, int64_t lda, const double* B, int64_t ldb,
+                       double* partials, double* C, int64_t ldc, int mp, int np) {
+    const int Z = (int)((k + GS_ROWS - 1) / GS_ROWS);
+    const int pa = ((ma + 15) / 16) * 16 + 1, pb = ((nb + 15) / 16) * 16 + 1;
+    const size_t lds = (size_t)GS_ROWS * (pa + pb) * sizeof(double);
+    gram_partial_kernel<<<Z, 256, lds, s>>>((int)k, ma, nb, A, lda, B, ldb, pa, pb, partials);
+    gram_reduce_kernel<<<(mp * np + 255) / 256, 256, 0, s>>>(ma, nb, mp, np, Z, partials, C, ldc);
+}
+
+// ---------------------------------------------------------------------------
 // Fused randomize! + product:  Y = A W  with  A[r,c] = value(L[r,c])  never materialised
 // (src/abstract_part.jl:107-110 fused into the products of the module-compression driver).
 // Reads the 4-byte labels coalesced along r, the per-class values come from a d+1 entry table
