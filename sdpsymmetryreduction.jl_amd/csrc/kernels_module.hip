@@ -122,14 +122,30 @@ gram_partial_kernel(int k, int ma, int nb, const double* __restrict__ A, int64_t
     double* sB = gs_smem + GS_ROWS * pa;  // [GS_ROWS][pb]
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * GS_ROWS;
-    for (int e = tid; e < GS_ROWS * ma; e += 256) {
-        const int r = e & (GS_ROWS - 1), i = e / GS_ROWS;
-        sA[r * pa + i] = (row0 + r < k) ? A[row0 + r + (int64_t)i * lda] : 0.0;
-    }
-    for (int e = tid; e < GS_ROWS * nb; e += 256) {
-        const int r = e & (GS_ROWS - 1), j = e / GS_ROWS;
-        sB[r * pb + j] = (row0 + r < k) ? B[row0 + r + (int64_t)j * ldb] : 0.0;
-    }
+    // batches of four loads per thread, all issued before the first LDS store; an index past the end is
+    // clamped to the last element (the same value goes to the same place twice: harmless) so that no store
+    // is guarded -- a guarded store pulls its load into the branch and the loads serialise
+    auto stage = [&](const double* __restrict__ M, int64_t ldm, int cols, int pitch, double* dst) {
+        const int total = GS_ROWS * cols;
+        for (int e0 = tid; e0 < total; e0 += 256 * 4) {
+            double v[4];
+            int at[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int e = e0 + 256 * q;
+                e = e < total ? e : total - 1;
+                const int r = e & (GS_ROWS - 1), i = e / GS_ROWS;
+                const int rr = row0 + r < k ? row0 + r : k - 1;
+                const double x = M[rr + (int64_t)i * ldm];
+                v[q] = row0 + r < k ? x : 0.0;
+                at[q] = r * pitch + i;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[at[q]] = v[q];
+        }
+    };
+    stage(A, lda, ma, pa, sA);
+    stage(B, ldb, nb, pb, sB);
     __syncthreads();
     const int ti = tid & 15, tj = tid >> 4;
     double* p = P + (int64_t)blockIdx.x * ma * nb;
@@ -174,28 +190,37 @@ gram_partial_kernel(int k, int ma, int nb, const double* __restrict__ A, int64_t
         }
 }
 
-// C[i + j ldc] = sum_z P[z][i + j ma]  (i < ma, j < nb), 0 on the rest of the mp x np result
-__global__ void gram_reduce_kernel(int ma, int nb, int mp, int np, int Z, const double* __restrict__ P, double* __restrict__ C,
-                                   int64_t ldc) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= mp * np) return;
+// C[i + j ldc] = sum_z P[z][i + j ma]  (i < ma, j < nb), 0 on the rest of the mp x np result.
+// Workgroup = 16 consecutive outputs x 16 groups of z: thread (o, g) adds P[z] for z = g, g + 16, ...
+// (independent loads, one round trip), the 16 group sums of an output are added in group order.
+__global__ void __launch_bounds__(256)
+gram_reduce_kernel(int ma, int nb, int mp, int np, int Z, const double* __restrict__ P, double* __restrict__ C, int64_t ldc) {
+    __shared__ double part[16][17];
+    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + o;  // index in the padded result
     const int j = e / mp, i = e - j * mp;
+    const bool in = e < mp * np && i < ma && j < nb;
     double acc = 0;
-    if (i < ma && j < nb) {
+    if (in) {
         const double* p = P + i + (int64_t)j * ma;
         const int64_t stride = (int64_t)ma * nb;
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int z = 0;
-        for (; z + 4 <= Z; z += 4) {
+        double a0 = 0, a1 = 0;
+        int z = g;
+        for (; z + 16 < Z; z += 32) {
             a0 += p[(int64_t)z * stride];
-            a1 += p[(int64_t)(z + 1) * stride];
-            a2 += p[(int64_t)(z + 2) * stride];
-            a3 += p[(int64_t)(z + 3) * stride];
+            a1 += p[(int64_t)(z + 16) * stride];
         }
-        for (; z < Z; ++z) a0 += p[(int64_t)z * stride];
-        acc = (a0 + a1) + (a2 + a3);
+        if (z < Z) a0 += p[(int64_t)z * stride];
+        acc = a0 + a1;
     }
-    C[i + (int64_t)j * ldc] = acc;
+    part[g][o] = acc;
+    __syncthreads();
+    if (g == 0 && e < mp * np) {
+        double t = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][o];
+        C[i + (int64_t)j * ldc] = t;
+    }
 }
 
 size_t gram_small_partial_doubles(int64_t k, int ma, int nb) { return (size_t)((k + GS_ROWS - 1) / GS_ROWS) * ma * nb; }
@@ -206,7 +231,7 @@ void launch_gram_small(hipStream_t s, int64_t k, int ma, int nb, const double* A
     const int pa = ((ma + 15) / 16) * 16 + 1, pb = ((nb + 15) / 16) * 16 + 1;
     const size_t lds = (size_t)GS_ROWS * (pa + pb) * sizeof(double);
     gram_partial_kernel<<<Z, 256, lds, s>>>((int)k, ma, nb, A, lda, B, ldb, pa, pb, partials);
-    gram_reduce_kernel<<<(mp * np + 255) / 256, 256, 0, s>>>(ma, nb, mp, np, Z, partials, C, ldc);
+    gram_reduce_kernel<<<(mp * np + 15) / 16, 256, 0, s>>>(ma, nb, mp, np, Z, partials, C, ldc);
 }
 
 // ---------------------------------------------------------------------------
