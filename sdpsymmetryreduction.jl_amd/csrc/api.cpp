@@ -1546,6 +1546,7 @@ constexpr int DRIVER_FALLBACK = -1000;
 }  // namespace
 namespace sdpsr {
 void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B);
+void launch_extract_symmetric(hipStream_t s, int64_t m, int64_t mp, const double* src, int64_t lds_, double* dst);
 void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
 size_t gram_small_partial_doubles(int64_t k, int ma, int nb);
 void launch_gram_small(hipStream_t s, int64_t k, int ma, int nb, const double* A, int64_t lda, const double* B, int64_t ldb,
@@ -2033,10 +2034,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     gen.make = [&](double* dst) -> int {
         if (have_saved) {  // first element: the product of the final invariance round (see above)
             have_saved = false;
-            HIP_TRY(c, hipMemsetAsync(dst, 0, (size_t)wp * wp * 8, s));
-            HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)wp * 8, Cc, (size_t)saved_ld * 8, (size_t)w * 8, (size_t)w,
-                                        hipMemcpyDeviceToDevice, s));
-            launch_symmetrize(s, w, wp, dst);
+            launch_extract_symmetric(s, w, wp, Cc, saved_ld, dst);  // zero padding + copy + symmetrize in one launch
             return SDPSR_OK;
         }
         HIP_TRY(c, hipMemsetAsync(T, 0, (size_t)ld * wp * 8, s));

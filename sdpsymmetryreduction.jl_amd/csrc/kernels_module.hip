@@ -65,24 +65,67 @@ void launch_symmetrize(hipStream_t s, int64_t m, int64_t ld, double* B) {
     symmetrize_kernel<<<g, b, 0, s>>>((int)m, ld, B);
 }
 
+// dst (mp x mp, dense) <- symmetric part of the leading m x m block of src (ld lds_), zero elsewhere:
+// memset + 2-D copy + symmetrize of the first compressed element in one launch
+__global__ void extract_symmetric_kernel(int m, int mp, const double* __restrict__ src, int64_t lds_, double* __restrict__ dst) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= mp * mp) return;
+    const int j = e / mp, i = e - j * mp;
+    dst[e] = (i < m && j < m) ? 0.5 * (src[i + (int64_t)j * lds_] + src[j + (int64_t)i * lds_]) : 0.0;
+}
+void launch_extract_symmetric(hipStream_t s, int64_t m, int64_t mp, const double* src, int64_t lds_, double* dst) {
+    extract_symmetric_kernel<<<(unsigned)((mp * mp + 255) / 256), 256, 0, s>>>((int)m, (int)mp, src, lds_, dst);
+}
+
 // out[:, c] = beta * out[:, c] + alpha * sum_{t < kk} In[:, t] * S[t + c * lds]   (tall-skinny times small)
-__global__ void tall_times_small_kernel(int n, int64_t ldi, const double* __restrict__ In, int kk,
-                                        const double* __restrict__ S, int lds_, double alpha, double beta,
-                                        double* __restrict__ out, int64_t ldo) {
-    const int c = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double* sc = S + (int64_t)c * lds_;
-    double acc = 0;
-    for (int t = 0; t < kk; ++t) acc = fma(In[(int64_t)t * ldi + i], sc[t], acc);
-    double* o = out + i + (int64_t)c * ldo;
-    *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc;
+// One wave = 64 rows x TS_COLS output columns: a row's In values are read once per TS_COLS outputs (they
+// were read once per output: kk x ncols passes over In through L2), the coefficients are wave-uniform
+// (scalar loads), eight In loads are in flight per lane.
+constexpr int TS_COLS = 8;
+__global__ void __launch_bounds__(64)
+tall_times_small_kernel(int n, int64_t ldi, const double* __restrict__ In, int kk,
+                        const double* __restrict__ S, int lds_, int ncols, double alpha, double beta,
+                        double* __restrict__ out, int64_t ldo) {
+    const int c0 = blockIdx.y * TS_COLS;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int ic = i < n ? i : n - 1;
+    const double* in = In + ic;
+    double acc[TS_COLS];
+#pragma unroll
+    for (int q = 0; q < TS_COLS; ++q) acc[q] = 0.0;
+    // coefficient columns past ncols: clamped (their sums are not stored)
+    const double* sc[TS_COLS];
+#pragma unroll
+    for (int q = 0; q < TS_COLS; ++q) sc[q] = S + (int64_t)(c0 + q < ncols ? c0 + q : ncols - 1) * lds_;
+    int t = 0;
+    for (; t + 8 <= kk; t += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = in[(int64_t)(t + u) * ldi];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < TS_COLS; ++q) acc[q] = fma(x[u], sc[q][t + u], acc[q]);
+    }
+    for (; t < kk; ++t) {
+        const double x = in[(int64_t)t * ldi];
+#pragma unroll
+        for (int q = 0; q < TS_COLS; ++q) acc[q] = fma(x, sc[q][t], acc[q]);
+    }
+    if (i < n) {
+#pragma unroll
+        for (int q = 0; q < TS_COLS; ++q)
+            if (c0 + q < ncols) {
+                double* o = out + i + (int64_t)(c0 + q) * ldo;
+                *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc[q];
+            }
+    }
 }
 void launch_tall_times_small(hipStream_t s, int64_t n, int64_t ldi, const double* In, int kk, const double* S,
                              int lds_, int ncols, double alpha, double beta, double* out, int64_t ldo) {
     if (ncols <= 0) return;
-    dim3 g((unsigned)((n + 255) / 256), (unsigned)ncols);
-    tall_times_small_kernel<<<g, 256, 0, s>>>((int)n, ldi, In, kk, S, lds_, alpha, beta, out, ldo);
+    dim3 g((unsigned)((n + 63) / 64), (unsigned)((ncols + TS_COLS - 1) / TS_COLS));
+    tall_times_small_kernel<<<g, 64, 0, s>>>((int)n, ldi, In, kk, S, lds_, ncols, alpha, beta, out, ldo);
 }
 
 // C[e] = sum_z P[z * stride + e]  (split-K partial sums, fixed order)
