@@ -740,34 +740,60 @@ class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict_
     for (int c = threadIdx.x; c < n; c += 256) sx[c] = x[c];
     __syncthreads();
     const int rows_per_round = gridDim.x * 4;
-    for (int r0 = blockIdx.x * 4; r0 < n; r0 += rows_per_round) {
-        const int r = r0 + wave;
-        const bool row_ok = r < n;
-        for (int i = 0; i <= d; ++i) mine[i] = 0.0;
-        if (row_ok) {
-            const uint32_t* col = L + (int64_t)r * n;
-            for (int c0 = 0; c0 < n; c0 += 512) {
-                uint32_t lab[8];
+    // The work of a wave is a flat list of batches b = (row index rr, eight 64-column chunks bb): labels of
+    // (row, columns 512 bb + 64 u + lane).  Three batches are in flight while one is added -- with one batch
+    // per HBM round trip the latency was the whole time of this kernel.  The four buffers rotate by name
+    // (a register move of a buffer still in flight would wait for it).  Pure loads from clamped addresses:
+    // a row past the matrix is summed and not stored, a column past it adds 0.
+    const int bpr = (n + 511) / 512;                                       // batches per row
+    const int my_rows = (n - blockIdx.x * 4 + rows_per_round - 1) / rows_per_round;  // rounds of this workgroup (>= 1)
+    const int total = my_rows * bpr;
+    auto fetch = [&](int bq, uint32_t (&lab)[8]) {
+        const int rr = bq / bpr, bb = bq - rr * bpr;
+        const int r = blockIdx.x * 4 + rr * rows_per_round + wave;
+        const uint32_t* col = L + (int64_t)((bq < total && r < n) ? r : 0) * n;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + u * 64 + lane;
-                    lab[u] = (c < n) ? col[c] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + u * 64 + lane;
-                    if (c < n) mine[lab[u]] += sx[c];
-                }
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int c = bb * 512 + u * 64 + lane;
+            lab[u] = col[c < n ? c : n - 1];
         }
-        __syncthreads();
-        if (row_ok)
-            for (int i = 1 + lane; i <= d; i += 64) {
-                double t = 0;
-                for (int l2 = 0; l2 < 64; ++l2) t += acc[(size_t)l2 * tstride + i];
-                out[(int64_t)(i - 1) * ldo + r] = t;
-            }
-        __syncthreads();
+    };
+    auto process = [&](int bq, const uint32_t (&lab)[8]) {
+        if (bq >= total) return;  // uniform over the workgroup
+        const int rr = bq / bpr, bb = bq - rr * bpr;
+        if (bb == 0)
+            for (int i = 0; i <= d; ++i) mine[i] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = bb * 512 + u * 64 + lane;
+            mine[lab[u]] += c < n ? sx[c] : 0.0;
+        }
+        if (bb == bpr - 1) {
+            const int r = blockIdx.x * 4 + rr * rows_per_round + wave;
+            __syncthreads();
+            if (r < n)
+                for (int i = 1 + lane; i <= d; i += 64) {
+                    double t = 0;
+                    for (int l2 = 0; l2 < 64; ++l2) t += acc[(size_t)l2 * tstride + i];
+                    out[(int64_t)(i - 1) * ldo + r] = t;
+                }
+            __syncthreads();
+        }
+    };
+    uint32_t qa[8], qb[8], qc[8], qd[8];
+    fetch(0, qa);
+    fetch(1, qb);
+    fetch(2, qc);
+#pragma unroll 1
+    for (int bq = 0; bq < total; bq += 4) {
+        fetch(bq + 3, qd);
+        process(bq, qa);
+        fetch(bq + 4, qa);
+        process(bq + 1, qb);
+        fetch(bq + 5, qb);
+        process(bq + 2, qc);
+        fetch(bq + 6, qc);
+        process(bq + 3, qd);
     }
 }
 
