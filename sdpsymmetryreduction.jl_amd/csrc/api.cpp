@@ -1448,12 +1448,18 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     // the generator can, it is formed on a side stream while the (one-workgroup) eigensolver runs
     bool prefetched = false;
     info.vals.resize(n);
+    // Small compressed problems (one-workgroup eigensolver, one-workgroup Q'AQ): the eigenvalues are
+    // clustered on the device, so the status and values of the eigensolver, the eigenspaces and the block
+    // norms come back in ONE read-back (SDPSR_SMALL_TWO_READBACKS=1: one after the eigensolver for the
+    // clustering on the host, one after the norms)
+    static const bool two_readbacks = getenv("SDPSR_SMALL_TWO_READBACKS") != nullptr;
+    const bool one_readback = gen && n <= 64 && (c->opts.eig_driver == 0 || c->opts.eig_driver >= 4) && !two_readbacks;
     if (gen && gen->prefetch && gen->join && gen->fork && gen->fork() == SDPSR_OK) {
         const std::function<void()> after = [&]() { prefetched = gen->prefetch(Ap) == SDPSR_OK; };
-        st = syev_device(c, n, Q, ld, w, info.vals.data(), &after);
+        st = syev_device(c, n, Q, ld, w, one_readback ? nullptr : info.vals.data(), &after, one_readback);
     } else {
         prefetched = gen && gen->prefetch && gen->join && gen->prefetch(Ap) == SDPSR_OK;
-        st = syev_device(c, n, Q, ld, w, info.vals.data());
+        st = syev_device(c, n, Q, ld, w, one_readback ? nullptr : info.vals.data(), nullptr, one_readback);
     }
     dbg_mark("eigen_decomposition: syev returned");
     tm.end();
@@ -1461,40 +1467,81 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
         if (prefetched) gen->join();  // never leave side-stream work behind
         return st;
     }
-    tm.collect();
-    // EigenDecomposition ctor (:19-40): new eigenspace where |dv| > atol
-    info.ptrs.assign(1, 0);
-    for (int64_t i = 0; i < n; ++i) {
-        if (i == n - 1) {
-            info.ptrs.push_back((int)n);
-            break;
-        }
-        if (!(std::fabs(info.vals[i + 1] - info.vals[i]) <= atol)) info.ptrs.push_back((int)i + 1);
-    }
-    const int neig = (int)info.ptrs.size() - 1;
-    std::vector<int32_t> space_of(n);
-    for (int b = 0; b < neig; ++b)
-        for (int i = info.ptrs[b]; i < info.ptrs[b + 1]; ++i) space_of[i] = b;
-    // Step 3: second generic element, Q'AQ, block norms (:259-262, :201-205)
-    tm.begin(SDPSR_T_ISO);
-    int32_t* dspace = (int32_t*)ctx_buf(c, "bd_space", (size_t)n * 4);
-    unsigned long long* dnorms = (unsigned long long*)ctx_buf(c, "bd_norms", (size_t)neig * neig * 8);
-    if (!dspace || !dnorms) return SDPSR_OUT_OF_MEMORY;
-    st = h2d_sync(c, dspace, space_of.data(), n * 4);
-    if (st) return st;
-    HIP_TRY(c, hipMemsetAsync(dnorms, 0, (size_t)neig * neig * 8, s));
-    st = prefetched ? gen->join() : make_element(c, gen, n, ld, L, Ap);
-    if (st) return st;
-    info.t_valid = true;
-    if (n <= 64) {  // small (compressed) problems: one workgroup does Q'AQ and the block maxima (T = A Q goes to Tp)
-        launch_small_qtaq_block_norms(s, n, ld, Ap, Q, dspace, neig, dnorms, nullptr, Tp);
+    int neig = 0;
+    int32_t* dspace = (int32_t*)ctx_buf(c, "bd_space", (size_t)n * 4 + 64);
+    if (!dspace) return SDPSR_OUT_OF_MEMORY;
+    unsigned long long* dnorms = nullptr;
+    std::vector<double> norms;
+    bool have_norms = false;
+    if (one_readback) {
+        // Step 3 enqueued behind the eigensolver: second generic element, clustering + Q'AQ + block norms
+        tm.begin(SDPSR_T_ISO);
+        const size_t o_space = 64, o_vals = o_space + (((size_t)n * 4 + 63) / 64) * 64, o_norms = o_vals + (size_t)n * 8;
+        const size_t pack_bytes = small_cluster_pack_bytes(n);
+        char* dpack = (char*)ctx_buf(c, "bd_pack", pack_bytes);
+        int* dinfo = (int*)ctx_buf(c, "eig_info", 64);
+        char* hp = (char*)ctx_pinned(c, pack_bytes);
+        if (!dpack || !dinfo || !hp) return SDPSR_OUT_OF_MEMORY;
+        dspace = (int32_t*)(dpack + o_space);  // stay valid for the launches of a retry
+        dnorms = (unsigned long long*)(dpack + o_norms);
+        st = prefetched ? gen->join() : make_element(c, gen, n, ld, L, Ap);
+        if (st) return st;
+        info.t_valid = true;
+        launch_small_cluster_qtaq_block_norms(s, n, ld, Ap, Q, w, atol, dinfo, dpack, Tp);
+        tm.end();
+        HIP_TRY(c, hipMemcpyAsync(hp, dpack, pack_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        tm.collect();
+        const int hinfo = ((const int*)hp)[0];
+        if (getenv("SDPSR_DEBUG")) fprintf(stderr, "[sdpsr] small syev n=%lld: %d sweeps\n", (long long)n, ((const int*)hp)[1]);
+        if (hinfo != 0) return ctx_fail(c, SDPSR_SOLVER_ERROR, "eigensolver did not converge, info=" + std::to_string(hinfo));
+        neig = ((const int*)hp)[4];
+        if (neig < 1 || neig > n) return ctx_fail(c, SDPSR_SOLVER_ERROR, "eigenvalue clustering on the device returned nonsense");
+        memcpy(info.vals.data(), hp + o_vals, (size_t)n * 8);
+        const int32_t* hs = (const int32_t*)(hp + o_space);
+        info.ptrs.assign(1, 0);
+        for (int64_t i = 1; i < n; ++i)
+            if (hs[i] != hs[i - 1]) info.ptrs.push_back((int)i);
+        info.ptrs.push_back((int)n);
+        if ((int)info.ptrs.size() - 1 != neig) return ctx_fail(c, SDPSR_SOLVER_ERROR, "eigenvalue clustering on the device is inconsistent");
+        norms.resize((size_t)neig * neig);
+        memcpy(norms.data(), hp + o_norms, (size_t)neig * neig * 8);
+        have_norms = true;
     } else {
-        launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);   // T = A Q (A symmetric)
-        launch_gemm_tn_f64(s, ld, ld, ld, Q, ld, Tp, ld, Ap, ld, 1, 0, 0, 0);   // M = Q' T  (into Ap)
-        launch_block_norms(s, n, ld, Ap, dspace, neig, dnorms);
+        tm.collect();
+        // EigenDecomposition ctor (:19-40): new eigenspace where |dv| > atol
+        info.ptrs.assign(1, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            if (i == n - 1) {
+                info.ptrs.push_back((int)n);
+                break;
+            }
+            if (!(std::fabs(info.vals[i + 1] - info.vals[i]) <= atol)) info.ptrs.push_back((int)i + 1);
+        }
+        neig = (int)info.ptrs.size() - 1;
+        std::vector<int32_t> space_of(n);
+        for (int b2 = 0; b2 < neig; ++b2)
+            for (int i = info.ptrs[b2]; i < info.ptrs[b2 + 1]; ++i) space_of[i] = b2;
+        // Step 3: second generic element, Q'AQ, block norms (:259-262, :201-205)
+        tm.begin(SDPSR_T_ISO);
+        dnorms = (unsigned long long*)ctx_buf(c, "bd_norms", (size_t)neig * neig * 8);
+        if (!dnorms) return SDPSR_OUT_OF_MEMORY;
+        st = h2d_sync(c, dspace, space_of.data(), n * 4);
+        if (st) return st;
+        HIP_TRY(c, hipMemsetAsync(dnorms, 0, (size_t)neig * neig * 8, s));
+        st = prefetched ? gen->join() : make_element(c, gen, n, ld, L, Ap);
+        if (st) return st;
+        info.t_valid = true;
+        if (n <= 64) {  // small (compressed) problems: one workgroup does Q'AQ and the block maxima (T = A Q goes to Tp)
+            launch_small_qtaq_block_norms(s, n, ld, Ap, Q, dspace, neig, dnorms, nullptr, Tp);
+        } else {
+            launch_gemm_tn_f64(s, ld, ld, ld, Ap, ld, Q, ld, Tp, ld, 1, 0, 0, 0);   // T = A Q (A symmetric)
+            launch_gemm_tn_f64(s, ld, ld, ld, Q, ld, Tp, ld, Ap, ld, 1, 0, 0, 0);   // M = Q' T  (into Ap)
+            launch_block_norms(s, n, ld, Ap, dspace, neig, dnorms);
+        }
+        tm.end();
+        norms.resize((size_t)neig * neig);
     }
-    tm.end();
-    std::vector<double> norms((size_t)neig * neig);
     auto dimof = [&](int b) { return info.ptrs[b + 1] - info.ptrs[b]; };
     // Compressed problems (module-compression driver): every eigenspace is 1- or 2-dimensional, so
     // the coupling of an isomorphic pair under ONE generic element is a single random number (not the
@@ -1506,9 +1553,11 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     // independent generic element (block_norms accumulates maxima: a coupling can only grow) and
     // the classes are formed again, up to twice.  The common case pays nothing.
     for (int extra = 0;; ++extra) {
-        st = d2h_sync(c, norms.data(), dnorms, (size_t)neig * neig * 8);
-        if (st) return st;
-        tm.collect();
+        if (!(have_norms && extra == 0)) {
+            st = d2h_sync(c, norms.data(), dnorms, (size_t)neig * neig * 8);
+            if (st) return st;
+            tm.collect();
+        }
         // blocks between eigenspaces of different dimension count as zero (:185-186); the kernel
         // computes the (bi, bj) max with bi = row space, symmetrise like end_norm[i,j] = end_norm[j,i]
         for (int i = 0; i < neig; ++i)

@@ -99,7 +99,7 @@ void destroy_handle(sdpsr_ctx* c) {
 // A: n x n column-major with leading dimension lda, lower triangle referenced; on exit the
 // columns of A are the orthonormal eigenvectors, w ascending.
 int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, double* host_w,
-                const std::function<void()>* after_launch) {
+                const std::function<void()>* after_launch, bool defer_readback) {
     int st = ensure_handle(c);
     if (st) return st;
     rocblas_handle h = (rocblas_handle)c->rocblas;
@@ -159,6 +159,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             return ctx_fail(c, SDPSR_HIP_ERROR, "copy of eigenvectors failed");
     }
     if (after_launch) (*after_launch)();  // everything of the eigensolver is enqueued; the caller overlaps its own launches here
+    if (defer_readback) return SDPSR_OK;  // the caller reads "eig_info" (status, sweeps) and w with its own next read-back
     // read-back through the pinned scratch of the ctx (a pageable 4-byte copy costs tens of us)
     rocblas_int* hpin = (rocblas_int*)ctx_pinned(c, 64 + (host_w ? (size_t)n * sizeof(double) : 0));
     if (!hpin || hipMemcpyAsync(hpin, info, 2 * sizeof(rocblas_int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

@@ -90,6 +90,72 @@ void launch_small_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const d
     const size_t lds = (size_t)3 * (n | 1) * n * 8;
     small_qtaq_block_norms_kernel<<<1, 1024, lds, s>>>((int)n, ld, A, Q, space_of, neig, norms, Mout, Tout);
 }
+// The same with the clustering of the (ascending) eigenvalues done here, as the EigenDecomposition
+// constructor does it (src/eigen_decomposition.jl:19-40: a new eigenspace where |dv| > atol), so that the
+// host needs ONE read-back (status and values of the eigensolver, eigenspaces, block norms) instead of one
+// after the eigensolver and one after the norms.
+__global__ void __launch_bounds__(1024)
+small_cluster_qtaq_block_norms_kernel(int n, int64_t ld, const double* __restrict__ A, const double* __restrict__ Q,
+                                      const double* __restrict__ evals, double atol, int32_t* __restrict__ space_of,
+                                      int32_t* __restrict__ meta, unsigned long long* __restrict__ norms,
+                                      double* __restrict__ Tout, const int* __restrict__ einfo, double* __restrict__ vals_out) {
+    extern __shared__ __attribute__((aligned(16))) double sq[];
+    __shared__ int s_space[64];
+    __shared__ int s_neig;
+    const int ldl = n | 1;
+    double* sA = sq;
+    double* sQ = sA + (size_t)ldl * n;
+    double* sT = sQ + (size_t)ldl * n;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid == 0) {
+        int b = 0;
+        s_space[0] = 0;
+        for (int i = 1; i < n; ++i) {
+            if (!(fabs(evals[i] - evals[i - 1]) <= atol)) ++b;
+            s_space[i] = b;
+        }
+        s_neig = b + 1;
+        meta[0] = einfo[0];  // status and sweep count of the eigensolver ride along
+        meta[1] = einfo[1];
+        meta[4] = b + 1;
+    }
+    if (tid < n) vals_out[tid] = evals[tid];
+    for (int e = tid; e < n * n; e += nthr) {
+        const int j = e / n, i = e - j * n;
+        sA[i + j * ldl] = A[i + (int64_t)j * ld];
+        sQ[i + j * ldl] = Q[i + (int64_t)j * ld];
+    }
+    __syncthreads();
+    const int neig = s_neig;
+    if (tid < n) space_of[tid] = s_space[tid];
+    for (int e = tid; e < neig * neig; e += nthr) norms[e] = 0ull;
+    for (int e = tid; e < n * n; e += nthr) {  // T = A Q (A symmetric: row i = column i)
+        const int j = e / n, i = e - j * n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc = fma(sA[k + i * ldl], sQ[k + j * ldl], acc);
+        sT[i + j * ldl] = acc;
+        if (Tout) Tout[i + (int64_t)j * ld] = acc;
+    }
+    __syncthreads();  // T complete; the zeroes of norms are visible to the atomics of this workgroup
+    for (int e = tid; e < n * n; e += nthr) {  // M[a, b] = Q[:, a]' T[:, b]
+        const int b = e / n, a = e - b * n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc = fma(sQ[k + a * ldl], sT[k + b * ldl], acc);
+        const unsigned long long v = (unsigned long long)__double_as_longlong(fabs(acc));
+        if (v) atomicMax(&norms[s_space[a] * neig + s_space[b]], v);
+    }
+}
+// pack (device, one contiguous read-back): [status, sweeps, -, -, eigenspaces | pad to 64 B][space_of n, padded to
+// 64 B][values n][norms neig * neig]
+size_t small_cluster_pack_bytes(int64_t n) { return 64 + (((size_t)n * 4 + 63) / 64) * 64 + (size_t)n * 8 + (size_t)n * n * 8; }
+void launch_small_cluster_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* Q,
+                                           const double* evals, double atol, const int* einfo, char* pack, double* Tout) {
+    const size_t lds = (size_t)3 * (n | 1) * n * 8;
+    const size_t o_space = 64, o_vals = o_space + (((size_t)n * 4 + 63) / 64) * 64, o_norms = o_vals + (size_t)n * 8;
+    small_cluster_qtaq_block_norms_kernel<<<1, 1024, lds, s>>>((int)n, ld, A, Q, evals, atol, (int32_t*)(pack + o_space),
+                                                                (int32_t*)pack, (unsigned long long*)(pack + o_norms), Tout, einfo,
+                                                                (double*)(pack + o_vals));
+}
 void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
                         const int32_t* space_of, int neig, unsigned long long* norms) {
     block_norms_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, M, space_of, neig, norms);
@@ -802,6 +868,8 @@ void blockdiag_set_device_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&small_qtaq_block_norms_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_cluster_qtaq_block_norms_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_outer_mfma_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);

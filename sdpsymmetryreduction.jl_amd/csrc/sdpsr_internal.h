@@ -264,6 +264,12 @@ void launch_gemm_tn_f64(hipStream_t s, int64_t m, int64_t n, int64_t k, const do
 // index to its eigenspace.  norms must be zeroed (as uint64 bit patterns of doubles).
 void launch_small_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* Q,
                                    const int32_t* space_of, int neig, unsigned long long* norms, double* Mout, double* Tout = nullptr);
+// the same with the eigenvalue clustering on the device (|dv| > atol starts a new eigenspace) and everything the
+// host needs next in one packed device buffer: [status, sweeps, -, -, eigenspaces | 64 B][space_of n | padded to
+// 64 B][values n][norms neig * neig]  (einfo: the eigensolver's "eig_info")
+size_t small_cluster_pack_bytes(int64_t n);
+void launch_small_cluster_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* Q,
+                                           const double* evals, double atol, const int* einfo, char* pack, double* Tout);
 void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
                         const int32_t* space_of, int neig, unsigned long long* norms);
 // y = A * x for symmetric A (n x n, ld) and nv vectors (columns of X, ldx): Y[:,v]
@@ -316,8 +322,9 @@ int sort_entries_by_label(sdpsr_ctx* c, int64_t len, int64_t d, const uint32_t* 
 // A (n x n, leading dimension lda) is overwritten with the eigenvectors; w[n] ascending.
 // host_w (optional): the eigenvalues are also delivered to the host, riding on the status read-back
 // after_launch: called once the eigensolver's kernels are enqueued, before the read-back synchronises
+// defer_readback: return right after the launches; the status stays in ctx buffer "eig_info" for the caller's next read-back
 int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, double* host_w = nullptr,
-                const std::function<void()>* after_launch = nullptr);
+                const std::function<void()>* after_launch = nullptr, bool defer_readback = false);
 void* ctx_pinned(sdpsr_ctx* c, size_t bytes);
 void destroy_handle(sdpsr_ctx* c);
 
