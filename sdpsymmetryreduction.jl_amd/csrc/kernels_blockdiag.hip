@@ -696,18 +696,19 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
     __syncthreads();
     // Segment sums.  A lane owns VEC adjacent columns of Qhat (16-byte loads when VEC == 2); when
     // fewer than 64 lanes are needed for the S1 columns the wave splits into `groups` lane groups
-    // that stride the segment, and a fixed xor-tree adds the groups: fixed order, reproducible.
+    // that stride the segment, and the groups' sums are added in group order: fixed order, reproducible.
     typedef typename std::conditional<VEC == 2, double2, double>::type vec_t;
     const int cols = S1 / VEC;
-    int sub = 1;
-    while (sub < cols && sub < 64) sub <<= 1;
+    // groups of exactly `cols` lanes (not the next power of two: 17 vector columns are three entries per
+    // load instruction instead of two, 51 busy lanes instead of 34)
+    const int sub = cols < 64 ? cols : 64;
     const int groups = 64 / sub;
-    const int jl = lane & (sub - 1), g = lane / sub;
+    const int jl = lane % sub, g = lane / sub;  // g == groups: idle lanes behind the last whole group
     const vec_t* __restrict__ Qv = reinterpret_cast<const vec_t*>(Qrm);
     const uint32_t diag = lower ? col[r] : 0u;
     for (int j0 = 0; j0 < cols; j0 += sub) {
         const int j = j0 + jl;
-        const bool act = j < cols;
+        const bool act = j < cols && g < groups;
         for (int i = 1; i <= d; ++i) {
             const int p0 = s_start[i], p1 = s_start[i + 1];
             double a[8][VEC];
@@ -735,7 +736,11 @@ basis_image_rows_kernel(int n, int d, int S1, const uint32_t* __restrict__ L, co
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 double t = ((a[0][v] + a[1][v]) + (a[2][v] + a[3][v])) + ((a[4][v] + a[5][v]) + (a[6][v] + a[7][v]));
-                for (int off = sub; off < 64; off <<= 1) t += __shfl_xor(t, off, 64);
+                {  // the groups' sums in group order (lane jl of every group)
+                    double tot = __shfl(t, jl, 64);
+                    for (int g2 = 1; g2 < groups; ++g2) tot += __shfl(t, jl + g2 * sub, 64);
+                    t = tot;
+                }
                 if (act && g == 0) {
                     // the diagonal entry enters with weight 1/2: the caller forms U + U' (below)
                     if (lower && diag == (uint32_t)i) t = fma(0.5, Qrm[(int64_t)r * S1 + (int64_t)j * VEC + v], t);
