@@ -1942,6 +1942,18 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         // only rounding noise and a relative test would compare noise with noise)
         if (take_ref && ref == 0)
             for (int i = 0; i < mc; ++i) ref = std::max(ref, hG[(size_t)(w + i) + (size_t)i * ap]);
+        // rank 0 is decided by the largest diagonal entry of the projected Gram matrix alone (diagonal
+        // pivoting: it is the first pivot): the invariance round of a complete module stops here, without
+        // the mc^2 w products of the full matrix
+        {
+            double dmax = 0;
+            for (int i = 0; i < mc; ++i) {
+                double v = hG[(size_t)(w + i) + (size_t)i * ap];
+                for (int t = 0; t < w; ++t) v -= hG[(size_t)t + (size_t)i * ap] * hG[(size_t)t + (size_t)i * ap];
+                dmax = std::max(dmax, v);
+            }
+            if (!(dmax > (take_ref ? tol_abs * ref : tol_abs))) return 0;
+        }
         std::vector<double> G1((size_t)mc * mc);
         for (int j = 0; j < mc; ++j)
             for (int i = 0; i < mc; ++i) {
