@@ -20,8 +20,13 @@ Three instances of configs[3] are measured; `value` is the first, the other two 
 
 N ranks (one per GPU): every rank runs an independent random restart of the same reduction (its
 own seed), the ranks agree on the partition (128-bit checksums all-gathered; labels travel only
-on disagreement), then each rank block-diagonalises.  value = restarts finished by all ranks per
-second ("weak": per-GPU work is fixed).
+on disagreement: MIN/MAX all-reduce, then the hash-meet with the device relabel), then each rank
+block-diagonalises.  value = restarts finished by all ranks per second ("weak": per-GPU work is fixed).
+
+`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks
+itself: N fresh child processes, one per GPU, created BEFORE this process imports torch or touches
+a GPU (never a re-exec of a process that has); rank 0's JSON line is the output.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are already there.
 
 Prints ONE JSON line (rank 0).
 """
@@ -113,6 +118,33 @@ class Workload:
         self.dev = dev
 
 
+def launch_ranks(n_ranks, argv):
+    """Parent of `bench.py --gpus N`: N child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    stdout and stderr inherited (rank 0 prints the JSON line).  This process never initialises a GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:  # one rank failed: do not leave the others waiting in a collective
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +160,8 @@ def main():
     ap.add_argument("--workload", default="closed_scheme", choices=["closed_scheme", "theta_c32xk128", "theta_er7xk72"],
                     help="instance run in the timed region (the other two are measured after it, rank 0)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -178,6 +212,12 @@ def main():
         def __init__(self):
             self.phase = np.zeros(L.T_COUNT)
             self.iters = 0
+            self.meets = 0  # agreement steps that needed the hash-meet (ranks ended on different partitions)
+
+    # test hook: SDPSR_BENCH_FORCE_DISAGREE=1 makes rank 1 report a COARSER partition in the warm-up steps (classes 1
+    # and 2 merged, canonically relabelled on the device), so that the MIN/MAX all-reduce and the hash-meet with the
+    # device relabel run; the agreed partition must again be the generator's closure (the `check` below)
+    force_disagree = bool(os.environ.get("SDPSR_BENCH_FORCE_DISAGREE"))
 
     def one_step(w, acc, cx, check=False, collective=True, timers=True):
         lib = cx._lib
@@ -195,15 +235,20 @@ def main():
         if world > 1 and collective:
             # agree the partition across the restarts (canonical labels: equal w.p. 1): 128-bit
             # checksums computed on the device are all-gathered; the 64 MiB label matrix itself
-            # only travels (MIN/MAX all-reduce) if they differ
-            words = pkg.partition_checksum(w.tP, ctx=cx)
-            if not pkg.parallel.checksums_agree(words, device=dev):
-                lo = w.tP.clone()
-                hi = w.tP.clone()
-                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-                if not bool((lo == hi).all()):
-                    raise RuntimeError("ranks disagree on the partition")
+            # only travels if they differ: MIN/MAX all-reduce, and -- a rank's draws missed a split --
+            # the meet of the partitions through one SUM all-reduce of hashed labels and the
+            # library's canonical relabel on the device (parallel.agree_partition)
+            if force_disagree and check and rank == 1:
+                coarse = torch.where(w.tP == 2, torch.ones_like(w.tP), w.tP)
+                relab, dcoarse = pkg.relabel_keys(coarse.to(torch.int64), ctx=cx)
+                w.tP.copy_(relab)
+                dd.value = dcoarse
+            agreed, lab = pkg.parallel.agree_partition(
+                w.tP, lambda sig: pkg.relabel_keys(sig, ctx=cx), checksum=lambda t: pkg.partition_checksum(t, ctx=cx))
+            if not agreed:
+                acc.meets += 1
+                w.tP.copy_(lab)
+                dd.value = int(lab.max().item())
         if check:
             assert dd.value == w.d and bool((w.tP == w.golden).all()), "partition differs from the generator's closure"
         nb = C.c_int32(0)
@@ -252,6 +297,7 @@ def main():
     acc = Acc()
     for _ in range(args.warmup):
         retrying(lambda: one_step(w0, acc, ctx, check=True))
+    acc_warm = acc
     acc = Acc()
     retries = 0
     fence(ctx)
@@ -306,6 +352,7 @@ def main():
                                  "steps": args.steps, "N": w0.n, "dim": w0.d, "blocks": f"{len(w0.blocks)} x size {w0.blocks[0]}" if len(set(w0.blocks)) == 1 else w0.blocks,
                                  "iterations_per_reduction": acc_timed.iters / max(1, args.steps), "randomized_retries": retries,
                                  "phase_ms_per_step": phases(acc_timed, args.steps), "instance": w0.note, "timed_region": True}}
+    meets_warmup = acc_warm.meets
     variants = {}
     kernels = {}
     roof = None
@@ -331,7 +378,7 @@ def main():
 
     def prof(kind, nn, aux=0, reps=10):
         v = C.c_double(0)
-        ctx.check(lib.sdpsr_profile_kernel(ctx._h, kind, nn, aux, reps, C.byref(v)))
+        ctx.check(L.load_prof_library().sdpsr_profile_kernel(ctx._h, kind, nn, aux, reps, C.byref(v)))
         return v.value
 
     if rank == 0 and not args.skip_roofline:
@@ -436,13 +483,13 @@ def main():
         # beside the fraction of the nominal (2.4 GHz) peak
         try:
             co = (C.c_double * 3)()
-            ctx.check(lib.sdpsr_profile_clock(ctx._h, 0, n, 104, 40, co))
+            ctx.check(L.load_prof_library().sdpsr_profile_clock(ctx._h, 0, n, 104, 40, co))
             if co[1] > 0:
                 roof["shader_clock_mhz"] = round(co[1], 0)
                 roof["nominal_clock_mhz"] = 2400
                 roof["frac_at_measured_clock"] = round(roof["frac"] * 2400.0 / co[1], 4)
             co2 = (C.c_double * 3)()
-            ctx.check(lib.sdpsr_profile_clock(ctx._h, 1, n, 1, 10, co2))
+            ctx.check(L.load_prof_library().sdpsr_profile_clock(ctx._h, 1, n, 1, 10, co2))
             kernels["square_f32"]["shader_clock_mhz"] = round(co2[1], 0)
         except Exception as e:  # noqa: BLE001  (diagnostic only)
             roof["shader_clock_note"] = f"clock meter failed: {e!r}"
@@ -467,6 +514,8 @@ def main():
             "phase_ms_per_step": phases(acc_timed, args.steps),
             "phase_ms_source": "HIP events inside the timed steps" if args.timers_in_timed_region else
                                "an instrumented pass of the same steps right after the timed region (the timed steps carry no phase events)",
+            "partition_meets": {"warmup": meets_warmup, "timed": acc.meets,
+                                "note": "agreement steps in which the ranks' partitions differed and the hash-meet ran (rank 0's count)"},
             "workloads": workloads, "roofline": roof, "kernels": kernels, "variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

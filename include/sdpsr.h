@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define SDPSR_VERSION_MAJOR 0
-#define SDPSR_VERSION_MINOR 2
+#define SDPSR_VERSION_MINOR 3
 
 typedef struct sdpsr_ctx sdpsr_ctx;
 
@@ -48,7 +48,13 @@ typedef enum sdpsr_status {
     SDPSR_NUMERICAL_INCONSISTENCY = 2,
     /* DimensionMismatch from check_block_sizes, src/diagonalize.jl:1-11 */
     SDPSR_DIMENSION_MISMATCH = 3,
-    /* Julia's InexactError on label overflow, src/partitions.jl:63 */
+    /* Julia's InexactError on label overflow (src/partitions.jl:29,63).  Only with sdpsr_opts.label_bits = 8 / 16 / 32
+       (the width of the reference's label type T): sdpsr_partition_from_* when the class count exceeds typemax(T);
+       sdpsr_refine when the largest pair code l1 + l2 (dim(P1) + 1) does (exactly the reference's condition);
+       sdpsr_admissible_subspace when dim(S) after a refinement does -- a NECESSARY condition of the reference's
+       error there (its intermediate pair code may overflow although the refined dimension fits: the loop never
+       forms Part(X) on its own, so that case is not reproduced).  label_bits = 0 (default): never returned,
+       labels are uint32 with 64-bit signatures. */
     SDPSR_LABEL_OVERFLOW = 4,
     /* @assert n^2 == length(C) (src/partitions.jl:118), length(values)==dim(P) (:69) ... */
     SDPSR_BAD_ARGUMENT = 5,
@@ -75,14 +81,60 @@ typedef enum sdpsr_square_mode {
     SDPSR_SQUARE_F64 = 3
 } sdpsr_square_mode;
 
+/* How _clamp_round! / unsafe_round (src/utils.jl:34-53) treats the 7-digit decimal mantissa. */
+typedef enum sdpsr_round_mode {
+    SDPSR_ROUND_NEAREST = 0, /* default: round to nearest (see sdpsr_clamp_round) */
+    SDPSR_ROUND_TRUNC = 1    /* reference-literal: unsafe_trunc(Int, scale * x) / scale */
+} sdpsr_round_mode;
+
+/* Behaviour switches (sdpsr_opts.flags).  They replace the environment variables of ABI 0.2: the
+   library reads no environment variable that changes results (SDPSR_DEBUG only adds stderr traces). */
+enum {
+    /* admissible_subspace: two refinements per iteration, as src/partitions.jl:159-174 is written,
+       instead of the joint one (see sdpsr_admissible_subspace) */
+    SDPSR_FLAG_SEPARATE_REFINEMENTS = 1u << 0,
+    /* irreducible_decomposition draws its own generic element (src/eigen_decomposition.jl:306)
+       instead of reusing the products T = A2 Q of the isomorphism step */
+    SDPSR_FLAG_FRESH_IRREDUCIBLE_ELEMENT = 1u << 1,
+    /* module-compression driver: always run the second orthonormalisation step of an absorb */
+    SDPSR_FLAG_ALWAYS_REORTHOGONALIZE = 1u << 2,
+    /* refinement: signatures always through an array in HBM (no fusion into the insert pass) */
+    SDPSR_FLAG_REFINE_NO_FUSE = 1u << 3,
+    /* int8 loop: unpack the lower-triangle labels to the full matrix after every refinement */
+    SDPSR_FLAG_UNPACK_EVERY_STEP = 1u << 4,
+    /* module growth: one label product per generic element instead of one pass for all of a round */
+    SDPSR_FLAG_SPMM_ONE_BY_ONE = 1u << 5,
+    /* dense driver: never raise the coupling matrix by extra generic elements (reference-literal
+       single element, src/eigen_decomposition.jl:259-262) */
+    SDPSR_FLAG_SINGLE_COUPLING_ELEMENT = 1u << 6,
+    /* compressed problems (order <= 64): eigensolver and Murota's steps in one-workgroup kernels on
+       the device instead of on the host inside the read-back the driver makes anyway */
+    SDPSR_FLAG_SMALL_EIGEN_ON_DEVICE = 1u << 7,
+    /* dense driver: launch the kernels of the tridiagonalisation one by one instead of replaying
+       their hipGraph (per-kernel profiles) */
+    SDPSR_FLAG_NO_GRAPH = 1u << 8
+};
+
 typedef struct sdpsr_opts {
     uint32_t struct_size;   /* = sizeof(sdpsr_opts) */
     int32_t square_mode;    /* sdpsr_square_mode */
-    int32_t channels;       /* independent draws per square step (1..8), 0 = default 4 */
+    int32_t channels;       /* independent int8 / f32 draws per square step (1..8).  0 = default: 2 channels AND
+                               confirm_rounds >= 1 (a false stop needs confirm_rounds + 1 consecutive squares that
+                               miss every needed split, each w.p. <= (2/256)^channels: the (2/256)^4 of four
+                               channels, at 2 (I + 1) instead of 4 I channel squares for I iterations) */
     int32_t max_iters;      /* 0 = default (10000) */
-    int32_t confirm_rounds; /* extra no-change square rounds demanded before stopping */
+    int32_t confirm_rounds; /* extra no-change square rounds demanded before stopping (default with channels = 0: 1) */
     int32_t eig_driver;     /* 0 = default */
-    int32_t reserved[10];
+    /* ---- ABI 0.3 (reserved, zero, in 0.2) ---- */
+    uint32_t flags;             /* SDPSR_FLAG_* */
+    int32_t round_mode;         /* sdpsr_round_mode */
+    int32_t basis_image_kernel; /* 0 = by shape, 1 = two-stage (class sums per row), 2 = outer products per class,
+                                   3 = sorted chunks with partial sums */
+    int32_t refine_path;        /* 0 = by class count, 1 = hash tables only, 2 = radix-sort relabel forced */
+    int32_t label_bits;         /* 0 = no emulation; 8 / 16 / 32: width of the reference's label type T in
+                                   Partition{T} (admissible_subspace defaults to UInt16, src/partitions.jl:84):
+                                   SDPSR_LABEL_OVERFLOW where the reference throws InexactError (see below) */
+    int32_t reserved[5];
 } sdpsr_opts;
 
 /* phase_ms slots filled by sdpsr_admissible_subspace / sdpsr_block_diagonalize
@@ -126,6 +178,11 @@ int sdpsr_wait_stream(sdpsr_ctx* ctx, void* hip_stream);
 int sdpsr_hint_symmetric_basis(sdpsr_ctx* ctx, int yes);
 /* Reseed (tests; independent restarts use distinct seeds per rank). */
 int sdpsr_set_seed(sdpsr_ctx* ctx, uint64_t seed);
+/* Dimension trajectory of the last sdpsr_admissible_subspace call on ctx -- what the reference logs under
+   verbose (src/partitions.jl:150,156,187-188): dims[0] = dim(S) after S = refine!(Part(CL), Part(X0L)),
+   dims[k] = dim(S) at the end of iteration k; *count = iterations + 1 (also when capacity is smaller; at most
+   `capacity` entries are written).  Host arrays. */
+int sdpsr_dimension_trajectory(sdpsr_ctx* ctx, int64_t* dims, int32_t capacity, int32_t* count);
 
 /* ---- AbstractPartition contract (primitives) ------------------------------- */
 /* Partition{T}(M::AbstractMatrix) float ctor, src/partitions.jl:24-35: classes of
@@ -134,6 +191,12 @@ int sdpsr_partition_from_f64(sdpsr_ctx* ctx, int64_t len, const double* M,
                              uint32_t* labels, int64_t* nparts, int mem);
 /* Integer ctor + __sort_unique!, src/partitions.jl:37-60. in == out allowed. */
 int sdpsr_partition_from_u32(sdpsr_ctx* ctx, int64_t len, const uint32_t* in,
+                             uint32_t* labels, int64_t* nparts, int mem);
+/* The same for 64-bit integer entries (Partition{T}(M::AbstractMatrix{<:Integer}) is generic in the
+   entry type; also the canonical relabel of the hash-combined labels of several restarts):
+   0 stays 0, every other key is a class of its own value (told apart by a 64-bit mixing hash,
+   collision bound as for sdpsr_refine). */
+int sdpsr_partition_from_u64(sdpsr_ctx* ctx, int64_t len, const uint64_t* in,
                              uint32_t* labels, int64_t* nparts, int mem);
 /* refine!(P1, P2), src/partitions.jl:62-66: p1 <- canonical relabel of the pairs
    (p1, p2); label 0 only where both are 0.  *d1 is updated.
@@ -155,12 +218,15 @@ int sdpsr_fill(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, const double
 /* randomize!(M, P), src/abstract_part.jl:107-110: one uniform [0,1) draw per class from
    the ctx's counter-based generator (a fresh stream per call). */
 int sdpsr_randomize(sdpsr_ctx* ctx, int64_t len, const uint32_t* labels, double* M, int mem);
-/* _clamp_round!, src/utils.jl:34-53; in place.  BEHAVIOURAL DIFFERENCE a Julia caller will
-   see: the reference TRUNCATES the 7-digit decimal mantissa (unsafe_trunc, src/utils.jl:49-53),
-   this library rounds it TO NEAREST.  Values that sit on a truncation edge (0.0625 = 0.5 * 2^-3)
-   are split into two classes by last-bit noise under truncation (esc16j: 10712 classes instead
-   of the pinned 150 with NumPy's projection arithmetic); nearest rounding keeps them together.
-   Results differ from Julia's only for entries within 1 ulp of such an edge. */
+/* _clamp_round!, src/utils.jl:34-53; in place.  BEHAVIOURAL DIFFERENCE a Julia caller will see with
+   the default round_mode: the reference TRUNCATES the 7-digit decimal mantissa (unsafe_trunc,
+   src/utils.jl:49-53), SDPSR_ROUND_NEAREST rounds it to nearest -- the 7th digit differs on about every
+   second input.  What the path outputs are the CLASSES of equal rounded values, and those only differ
+   for values that sit on an edge of the rule in use: a truncation edge such as 0.0625 = 0.5 * 2^-3 is
+   split into two classes by last-bit noise (esc16j: 10712 classes instead of the pinned 150 with
+   NumPy's projection arithmetic); nearest rounding keeps them together, hence the default.
+   sdpsr_opts.round_mode = SDPSR_ROUND_TRUNC is the reference's rule bit for bit (this primitive, the
+   projection step and the fp64 square of the loop, the setup stage of sdpsr_admissible_subspace_dense). */
 int sdpsr_clamp_round(sdpsr_ctx* ctx, int64_t len, double* a, double atol, int mem);
 /* x .-= projL(x), src/partitions.jl:161 + src/utils.jl:62-66, with qr(A') folded into an
    orthonormal basis U (len x r, column-major) of rowspace(A). */
@@ -193,7 +259,7 @@ int sdpsr_gemm_tn_f64(sdpsr_ctx* ctx, int64_t m, int64_t n, int64_t k, const dou
    partition (the smallest partition subspace containing C_L and X0 that is closed under the
    projection and under squaring; P_out is canonical, so it is the same matrix); *iters_out counts
    joint steps (equal to the reference-structured count on every test problem).
-   SDPSR_SEPARATE_REFINEMENTS=1 in the environment restores two refinements per iteration. */
+   sdpsr_opts.flags & SDPSR_FLAG_SEPARATE_REFINEMENTS restores two refinements per iteration. */
 int sdpsr_admissible_subspace(sdpsr_ctx* ctx, int64_t n, const double* CL, const double* X0L,
                               const double* U, int64_t r, double atol, uint32_t* P_out,
                               int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem);
@@ -281,29 +347,6 @@ int sdpsr_eigen_decomposition_batched(sdpsr_ctx* ctx, int64_t n, const uint32_t*
    orthonormal vectors (column-major n x n, overwrites nothing of A). */
 int sdpsr_syev_f64(sdpsr_ctx* ctx, int64_t n, const double* A, double* values, double* vectors,
                    int mem);
-
-/* ---- measurement hook (bench.py roofline leg) --------------------------------- */
-/* Times `reps` back-to-back launches of one hot kernel on ctx's stream with HIP events, on
-   resident synthetic data of order n (n is rounded up to the kernel's tile).  kind:
-   0 = square int8 MFMA (one channel), 1 = square fp32 MFMA, 2 = square / Q'AQ fp64 MFMA,
-   3 = partition refine of n*n signatures with `aux` distinct classes,
-   4 = fused gather+projection+signature pass with r = aux basis vectors,
-   5 = the tridiagonalisation's symmetric-product (symv) kernel, one launch per column j = 0..n-2
-       (average over the n-1 launches), 6 = one whole tridiagonalisation of order n,
-   8 = the one-workgroup Jacobi eigensolver on a random symmetric matrix of order n <= 128,
-   9 = the label product Y = A(v) W of the module-compression driver (n x n labels with d classes,
-       W n x w, G elements per pass): aux = w | G << 8 | d << 12; with bit 30 of aux set the call
-       returns in ms_per_launch[0] the largest absolute deviation of sampled rows of Y from a host
-       evaluation in extended precision instead of the time.
-   ms_per_launch[0] = average milliseconds per launch. */
-int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps,
-                         double* ms_per_launch);
-/* The same measurement with the shader clock sampled meanwhile by a one-wave kernel on a side
-   stream (clock64 against the 100 MHz wall_clock64, ~20 us intervals): out[0] = ms per launch,
-   out[1] = median shader clock in MHz while the timed launches ran, out[2] = intervals used.
-   The int8 squares run power-limited (the clock drops under the kernel); the roofline of
-   bench.py reports the fraction of the peak both at the nominal and at this measured clock. */
-int sdpsr_profile_clock(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps, double* out);
 
 #ifdef __cplusplus
 }

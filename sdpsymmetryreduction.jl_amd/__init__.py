@@ -13,4 +13,4 @@ from .api import (BlockDiagonalization, Context, DimensionMismatch, InvalidDecom
                   LabelOverflow, NotConverged, NumericalInconsistency, Partition, SdpsrError,
                   admissible_setup, admissible_subspace, blockDiagonalize, default_context, desymmetrize, unSymmetrize,
                   diagonalize, dim, eigen_decomposition, eigen_decomposition_batched, fill, partition_checksum, randomize, reduce_constraints,
-                  refine)
+                  refine, relabel_keys)

@@ -9,11 +9,26 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdpsr_hip.so")
+PROF_LIB_PATH = os.path.join(_HERE, "libsdpsr_prof.so")  # measurement entry points, not the product
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sdpsr.h")
+PROF_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sdpsr_prof.h")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 SQUARE_AUTO, SQUARE_I8, SQUARE_F32, SQUARE_F64 = 0, 1, 2, 3
 T_TOTAL, T_PROJECT, T_SQUARE, T_REFINE, T_EIGEN, T_ISO, T_IRRED, T_IMAGE, T_COUNT = range(9)
+ROUND_NEAREST, ROUND_TRUNC = 0, 1
+# sdpsr_opts.flags
+FLAG_SEPARATE_REFINEMENTS = 1 << 0
+FLAG_FRESH_IRREDUCIBLE_ELEMENT = 1 << 1
+FLAG_ALWAYS_REORTHOGONALIZE = 1 << 2
+FLAG_REFINE_NO_FUSE = 1 << 3
+FLAG_UNPACK_EVERY_STEP = 1 << 4
+FLAG_SPMM_ONE_BY_ONE = 1 << 5
+FLAG_SINGLE_COUPLING_ELEMENT = 1 << 6
+FLAG_SMALL_EIGEN_ON_DEVICE = 1 << 7
+FLAG_NO_GRAPH = 1 << 8
+BASIS_IMAGE_KERNELS = {"auto": 0, "two_stage": 1, "outer": 2, "chunk": 3}
+REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2}
 
 STATUS = {
     0: "OK", 1: "INVALID_DECOMPOSITION_FIELD", 2: "NUMERICAL_INCONSISTENCY", 3: "DIMENSION_MISMATCH",
@@ -30,7 +45,12 @@ class Opts(C.Structure):
         ("max_iters", C.c_int32),
         ("confirm_rounds", C.c_int32),
         ("eig_driver", C.c_int32),
-        ("reserved", C.c_int32 * 10),
+        ("flags", C.c_uint32),
+        ("round_mode", C.c_int32),
+        ("basis_image_kernel", C.c_int32),
+        ("refine_path", C.c_int32),
+        ("label_bits", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -65,8 +85,10 @@ def load_library():
         "sdpsr_synchronize": (C.c_int, [vp]),
         "sdpsr_wait_stream": (C.c_int, [vp, vp]),
         "sdpsr_set_seed": (C.c_int, [vp, C.c_uint64]),
+        "sdpsr_dimension_trajectory": (C.c_int, [vp, vp, i32, pi32]),
         "sdpsr_partition_from_f64": (C.c_int, [vp, i64, vp, vp, pi64, C.c_int]),
         "sdpsr_partition_from_u32": (C.c_int, [vp, i64, vp, vp, pi64, C.c_int]),
+        "sdpsr_partition_from_u64": (C.c_int, [vp, i64, vp, vp, pi64, C.c_int]),
         "sdpsr_refine": (C.c_int, [vp, i64, vp, pi64, vp, i64, C.c_int]),
         "sdpsr_partition_checksum": (C.c_int, [vp, i64, vp, vp, C.c_int]),
         "sdpsr_fill": (C.c_int, [vp, i64, vp, vp, i64, vp, C.c_int]),
@@ -92,8 +114,6 @@ def load_library():
         "sdpsr_eigen_decomposition_batched": (C.c_int, [vp, i64, vp, i64, dbl, i64, vp, vp, vp, vp, C.c_int]),
         "sdpsr_syev_f64": (C.c_int, [vp, i64, vp, vp, vp, C.c_int]),
         "sdpsr_hint_symmetric_basis": (C.c_int, [vp, C.c_int]),
-        "sdpsr_profile_kernel": (C.c_int, [vp, C.c_int, i64, i64, C.c_int, C.POINTER(C.c_double)]),
-        "sdpsr_profile_clock": (C.c_int, [vp, C.c_int, i64, i64, C.c_int, C.POINTER(C.c_double)]),
     }
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     if missing:
@@ -103,4 +123,26 @@ def load_library():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+_prof = None
+
+
+def load_prof_library():
+    """libsdpsr_prof.so (include/sdpsr_prof.h): per-kernel timing entry points for bench.py's roofline
+    leg and tools/ -- built beside the product library, never needed by the product path."""
+    global _prof
+    if _prof is not None:
+        return _prof
+    load_library()  # libsdpsr_prof.so links against libsdpsr_hip.so ($ORIGIN rpath)
+    if not os.path.exists(PROF_LIB_PATH):
+        raise RuntimeError(f"{PROF_LIB_PATH} is missing: build it with `make -C sdpsymmetryreduction.jl_amd/csrc`")
+    lib = C.CDLL(PROF_LIB_PATH)
+    vp, i64 = C.c_void_p, C.c_int64
+    for name in ("sdpsr_profile_kernel", "sdpsr_profile_clock"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [vp, C.c_int, i64, i64, C.c_int, C.POINTER(C.c_double)]
+    _prof = lib
     return lib

@@ -66,7 +66,11 @@ class Context:
     """One device context = one HIP stream + workspace (sdpsr_create)."""
 
     def __init__(self, device=0, seed=0, square_mode=L.SQUARE_AUTO, channels=0, max_iters=0,
-                 confirm_rounds=0, eig_driver=0):
+                 confirm_rounds=0, eig_driver=0, flags=0, round_mode="nearest", basis_image_kernel="auto",
+                 refine_path="auto", label_bits=0):
+        """``flags``: OR of ``_lib.FLAG_*``; ``round_mode``: "nearest" (default) or "trunc" (the
+        reference's ``unsafe_round``, src/utils.jl:49-53); ``label_bits``: 0, or the width of the
+        reference's label type ``T`` in ``Partition{T}`` to get ``LabelOverflow`` where it would throw."""
         self._lib = L.load_library()
         o = L.Opts()
         o.struct_size = C.sizeof(L.Opts)
@@ -75,6 +79,11 @@ class Context:
         o.max_iters = int(max_iters)
         o.confirm_rounds = int(confirm_rounds)
         o.eig_driver = int(eig_driver)
+        o.flags = int(flags)
+        o.round_mode = {"nearest": L.ROUND_NEAREST, "trunc": L.ROUND_TRUNC}[round_mode] if isinstance(round_mode, str) else int(round_mode)
+        o.basis_image_kernel = L.BASIS_IMAGE_KERNELS[basis_image_kernel] if isinstance(basis_image_kernel, str) else int(basis_image_kernel)
+        o.refine_path = L.REFINE_PATHS[refine_path] if isinstance(refine_path, str) else int(refine_path)
+        o.label_bits = int(label_bits)
         h = C.c_void_p()
         st = self._lib.sdpsr_create(int(device), C.c_uint64(seed & (2 ** 64 - 1)), C.byref(o), C.byref(h))
         if st != 0:
@@ -115,6 +124,16 @@ class Context:
 
     def synchronize(self):
         self.check(self._lib.sdpsr_synchronize(self._h))
+
+    def dimension_trajectory(self):
+        """dim(S) after the initial refinement and after every iteration of the last
+        ``admissible_subspace`` on this context (what the reference logs under ``verbose``,
+        src/partitions.jl:150,156,187-188)."""
+        cnt = C.c_int32(0)
+        self.check(self._lib.sdpsr_dimension_trajectory(self._h, None, 0, C.byref(cnt)))
+        dims = np.zeros(max(cnt.value, 1), dtype=np.int64)
+        self.check(self._lib.sdpsr_dimension_trajectory(self._h, dims.ctypes.data_as(C.c_void_p), cnt.value, C.byref(cnt)))
+        return [int(x) for x in dims[:cnt.value]]
 
     def wait_for(self, *arrays):
         """Order ctx's stream behind torch's current stream when any argument is a CUDA tensor
@@ -166,10 +185,14 @@ class Partition:
             flat = _f(M, np.float64)
             ctx.check(ctx._lib.sdpsr_partition_from_f64(ctx._h, flat.size, _ptr(flat), _ptr(out), C.byref(n), L.MEM_HOST))
         else:
-            if M.size and (M.min() < 0 or M.max() >= 2 ** 32):
-                raise ValueError("labels must be in [0, 2^32)")
-            flat = _f(M, np.uint32)
-            ctx.check(ctx._lib.sdpsr_partition_from_u32(ctx._h, flat.size, _ptr(flat), _ptr(out), C.byref(n), L.MEM_HOST))
+            if M.size and M.min() < 0:  # @assert 0 <= first(M_vals), src/partitions.jl:46
+                raise ValueError("labels must be non-negative")
+            if M.size and M.max() >= 2 ** 32:
+                flat = _f(M, np.uint64)
+                ctx.check(ctx._lib.sdpsr_partition_from_u64(ctx._h, flat.size, _ptr(flat), _ptr(out), C.byref(n), L.MEM_HOST))
+            else:
+                flat = _f(M, np.uint32)
+                ctx.check(ctx._lib.sdpsr_partition_from_u32(ctx._h, flat.size, _ptr(flat), _ptr(out), C.byref(n), L.MEM_HOST))
         return cls(n.value, out.reshape(shape, order="F"))
 
     def __eq__(self, other):  # :16-17
@@ -219,6 +242,21 @@ def partition_checksum(P, ctx=None):
     out = (C.c_uint64 * 2)()
     ctx.check(ctx._lib.sdpsr_partition_checksum(ctx._h, n_entries, _ptr(lab), C.cast(out, C.c_void_p), mem))
     return int(out[0]), int(out[1])
+
+
+def relabel_keys(keys, ctx=None):
+    """Canonical relabel (first-occurrence order, 0 stays 0) of a flat torch CUDA int64 tensor of
+    arbitrary 64-bit keys, on the device: ``sdpsr_partition_from_u64``.  Returns (labels int32 CUDA
+    tensor, nparts) -- the ``relabel`` callback of ``parallel.agree_partition`` on a GPU."""
+    import torch
+    ctx = _ctx(ctx)
+    keys = keys.contiguous().view(-1)
+    assert keys.is_cuda and keys.dtype == torch.int64
+    out = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
+    n = C.c_int64(0)
+    ctx.wait_for(keys)
+    ctx.check(ctx._lib.sdpsr_partition_from_u64(ctx._h, keys.numel(), _ptr(keys), _ptr(out), C.byref(n), L.MEM_DEVICE))
+    return out, n.value
 
 
 def fill(P, values, ctx=None):
@@ -344,6 +382,7 @@ def _admissible_subspace_device_setup(C_, A, b, atol, ctx, verbose):
     out = Partition(d.value, P.reshape(n, n, order="F"))
     out.iterations = it.value
     out.phase_ms = list(ms)
+    out.dims = ctx.dimension_trajectory()
     return out
 
 
@@ -380,7 +419,11 @@ def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, se
         ctx._h, n, _ptr(CL), _ptr(X0L), _ptr(U) if r > 0 else None, r, float(atol), _ptr(P),
         C.byref(d), C.byref(it), C.cast(ms, C.c_void_p), L.MEM_DEVICE if on_dev else L.MEM_HOST)
     ctx.check(st)
+    out_dims = ctx.dimension_trajectory()
     if verbose:
+        print(f"[sdpsr] Starting the reduction. Dimensions: maximal = {(n * n + n) // 2}, initial = {out_dims[0] if out_dims else '?'}")
+        for k, dk in enumerate(out_dims[:-1]):
+            print(f"[sdpsr] Iteration {k + 1}, Current dimension: {dk}")
         print(f"[sdpsr] admissible subspace: dim {d.value} after {it.value} iterations, "
               f"{ms[L.T_TOTAL]:.3f} ms (project {ms[L.T_PROJECT]:.3f}, square {ms[L.T_SQUARE]:.3f}, "
               f"refine {ms[L.T_REFINE]:.3f})")
@@ -388,6 +431,7 @@ def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, se
     out = Partition(d.value, mat)
     out.iterations = it.value
     out.phase_ms = list(ms)
+    out.dims = out_dims
     return out
 
 

@@ -1,0 +1,270 @@
+// blockDiagonalize (src/compat.jl:46-68): diagonalize + check_block_sizes (src/diagonalize.jl:1-40),
+// then basis_image (:42-89).  Entry points sdpsr_block_diagonalize / _block_sizes / _q_hat / _block_images.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <functional>
+#include <numeric>
+
+#include "host_internal.h"
+
+using namespace sdpsr;
+
+extern "C" {
+
+int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon,
+                            int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* phase_ms,
+                            int mem) {
+    CHECK_CTX(c);
+    if (!P || n < 1 || d < 0 || !(epsilon > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    c->bd_valid = false;
+    c->bd_q_valid = false;
+    PhaseTimer tm(c, phase_ms != nullptr);
+    TotalEvents ev_total(phase_ms != nullptr, s);
+    // keep a device copy of the labels for phase 2
+    uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
+    if (!L) return SDPSR_OUT_OF_MEMORY;
+    c->bd_sym_labels = nullptr;
+    c->bd_sym_epoch = 0;
+    if (mem == SDPSR_MEM_DEVICE) {
+        if (P != L) {
+            // copy and symmetry check of the same tiles in one pass; the verdict ("bd_symflag"[0] ==
+            // epoch <=> not symmetric) is read back by the driver with its first synchronisation
+            const bool fresh = c->bufs.find("bd_symflag") == c->bufs.end();
+            uint32_t* sf = (uint32_t*)ctx_buf(c, "bd_symflag", 64);
+            if (!sf) return SDPSR_OUT_OF_MEMORY;
+            if (fresh) HIP_TRY(c, hipMemsetAsync(sf, 0, 64, s));
+            if (++c->epoch_counter == 0) ++c->epoch_counter;
+            launch_copy_check_symmetric(s, n, P, L, sf, c->epoch_counter);
+            c->bd_sym_epoch = c->epoch_counter;
+            c->bd_sym_labels = L;
+        }
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(L, P, len * 4, hipMemcpyHostToDevice, s));
+    }
+    dbg_mark(c, "block_diagonalize: entered, labels copied");
+    const double atol = epsilon;  // diagonalize(T, P; atol=epsilon), src/compat.jl:53
+    EigInfo info;
+    std::vector<int32_t> sizes;
+    int64_t S1 = 0, S = 0;
+    st = DRIVER_FALLBACK;
+    if (compression_eligible(c, n, d)) st = compressed_diagonalize(c, n, L, d, atol, info, sizes, S1, S, tm);
+    if (st == DRIVER_FALLBACK && c->opts.eig_driver == 6)
+        return ctx_fail(c, SDPSR_SOLVER_ERROR, "requested driver not applicable to this partition (" + c->err + ")");
+    if (st != SDPSR_OK && st != DRIVER_FALLBACK) return st;
+    if (st == DRIVER_FALLBACK) {
+        st = dense_diagonalize(c, n, L, nullptr, atol, info, sizes, S1, S, tm);
+        if (st) return st;
+    }
+
+    dbg_mark(c, "block_diagonalize: diagonalize done");
+    // check_block_sizes (src/diagonalize.jl:1-11)
+    int64_t final_dim = 0;
+    for (int32_t sz : sizes) final_dim += (int64_t)sz * (sz + 1) / 2;
+    c->bd_n = n;
+    c->bd_d = d;
+    c->bd_sizes = sizes;
+    c->bd_sum_s = S1;
+    c->bd_sum_sq = S;
+    c->bd_q_valid = true;
+    if (nblocks) *nblocks = (int32_t)sizes.size();
+    if (sum_sq) *sum_sq = S;
+    if (sum_s) *sum_s = S1;
+    if (phase_ms) {
+        const float ms = ev_total.stop(s);
+        tm.collect();
+        for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = tm.acc[i];
+        phase_ms[SDPSR_T_TOTAL] = ms;
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    if (final_dim != d) {
+        std::string szs;
+        for (int32_t sz : sizes) szs += std::to_string(sz) + " ";
+        return ctx_fail(c, SDPSR_DIMENSION_MISMATCH,
+                        "final_dim=" + std::to_string(final_dim) + " block_sizes=[" + szs + "] expected dim(P)=" +
+                            std::to_string(d) + " (rounding error: try another epsilon or try again; or the algebra is not block-diagonalizable over the reals)");
+    }
+    c->bd_valid = true;
+    return SDPSR_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int sdpsr_block_sizes(sdpsr_ctx* c, int32_t* blk_sizes) {
+    if (!c || !blk_sizes) return SDPSR_BAD_ARGUMENT;
+    if (c->bd_sizes.empty()) return ctx_fail(c, SDPSR_BAD_STATE, "no block diagonalisation available");
+    memcpy(blk_sizes, c->bd_sizes.data(), c->bd_sizes.size() * sizeof(int32_t));
+    return SDPSR_OK;
+}
+
+int sdpsr_q_hat(sdpsr_ctx* c, double* Q_hat, int mem) {
+    CHECK_CTX(c);
+    if (!c->bd_q_valid) return ctx_fail(c, SDPSR_BAD_STATE, "no diagonalisation available on this ctx");
+    if (!Q_hat) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    const size_t cnt = (size_t)c->bd_n * c->bd_sum_s;
+    double* Qhat = (double*)ctx_buf(c, "bd_qhat", cnt * 8);
+    if (!Qhat) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, cnt * 8, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SDPSR_OK;
+}
+
+int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_ms, int mem) {
+    CHECK_CTX(c);
+    if (!c->bd_valid) return ctx_fail(c, SDPSR_BAD_STATE, "sdpsr_block_diagonalize has not succeeded on this ctx");
+    if (!blks) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    hipStream_t s = c->stream;
+    const int64_t n = c->bd_n, d = c->bd_d, S1 = c->bd_sum_s, S = c->bd_sum_sq, len = n * n;
+    TotalEvents ev_total(phase_ms != nullptr, s);
+    int st = SDPSR_OK;
+    uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
+    double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
+    double* Qrm = (double*)ctx_buf(c, "bd_qrm", (size_t)n * S1 * 8);
+    double* out = out_dev(c, "bd_blks", blks, (size_t)d * S, mem, &st);
+    if (st || !L || !Qhat || !Qrm) return st ? st : SDPSR_OUT_OF_MEMORY;
+    launch_transpose_to_rowmajor(s, n, S1, Qhat, Qrm);
+    const double atol = 1e-12 * (double)n;  // basis_image default atol (src/diagonalize.jl:67)
+    // opts.basis_image_kernel = 1 two_stage | 2 outer | 3 chunk forces one of the three kernels (tests: the
+    // automatic choice reaches `outer` / `chunk` only for shapes far beyond the test sizes)
+    const int force = c->opts.basis_image_kernel;
+    const bool f_two = force == 1, f_outer = force == 2, f_chunk = force == 3;
+    if (basis_image_two_stage_fits(n, d, S1) && !f_outer && !f_chunk) {
+        // two-stage form (class sums per row, then the s_k x s_k dots): descriptor = the two
+        // columns of Q_hat every output multiplies, blocks side by side, column-major inside
+        std::vector<int32_t> hdesc(2 * (size_t)S);
+        {
+            int64_t o = 0, colbase = 0;
+            for (int32_t sz : c->bd_sizes) {
+                for (int b2 = 0; b2 < sz; ++b2)
+                    for (int a2 = 0; a2 < sz; ++a2) {
+                        hdesc[o] = (int32_t)(colbase + a2);
+                        hdesc[S + o] = (int32_t)(colbase + b2);
+                        ++o;
+                    }
+                colbase += sz;
+            }
+        }
+        int32_t* d_desc = (int32_t*)ctx_buf(c, "bi_desc", (size_t)2 * S * 4);
+        double* Tb = (double*)ctx_buf(c, "bi_T", (size_t)d * n * S1 * 8);
+        if (!d_desc || !Tb) return SDPSR_OUT_OF_MEMORY;
+        st = h2d_sync(c, d_desc, hdesc.data(), (size_t)2 * S * 4);
+        if (st) return st;
+        launch_basis_image_two_stage(s, n, d, S1, S, L, Qrm, Tb, d_desc, d_desc + S, atol, out);
+    } else {
+    // _constraints(P): entries grouped by class (src/diagonalize.jl:42-50)
+    uint32_t* ent = nullptr;
+    int64_t* class_ptr = nullptr;  // host, size d+2: class_ptr[l]..class_ptr[l+1] = label l
+    st = sort_entries_by_label(c, len, d, L, &ent, &class_ptr);
+    if (st) return st;
+    int max_s = 0;
+    for (int32_t sz : c->bd_sizes) max_s = std::max(max_s, (int)sz);
+    // many small classes (average class below 4096 entries) and blocks up to 256: outer-product
+    // kernel, one workgroup per (class, block), every output written once, no partial sums
+    (void)f_two;
+    if (max_s <= 256 && d > 0 && (len / d < 4096 || f_outer) && !f_chunk && d <= 0x7FFFFFFF && c->bd_sizes.size() <= 65535) {
+        const int nb = (int)c->bd_sizes.size();
+        std::vector<int32_t> hcol(nb), hsz(nb);
+        std::vector<int64_t> hoff(nb);
+        int64_t colbase = 0, off = 0;
+        for (int k2 = 0; k2 < nb; ++k2) {
+            hcol[k2] = (int32_t)colbase;
+            hsz[k2] = c->bd_sizes[k2];
+            hoff[k2] = off;
+            colbase += hsz[k2];
+            off += (int64_t)hsz[k2] * hsz[k2];
+        }
+        int32_t* d_col = (int32_t*)ctx_buf(c, "bi_col", (size_t)nb * 4);
+        int32_t* d_sz = (int32_t*)ctx_buf(c, "bi_sz", (size_t)nb * 4);
+        int64_t* d_off = (int64_t*)ctx_buf(c, "bi_off", (size_t)nb * 8);
+        int64_t* d_cls = (int64_t*)ctx_buf(c, "bi_cls_ptr", (size_t)(d + 2) * 8);
+        if (!d_col || !d_sz || !d_off || !d_cls) {
+            free(class_ptr);
+            return SDPSR_OUT_OF_MEMORY;
+        }
+        st = h2d_sync(c, d_col, hcol.data(), (size_t)nb * 4);
+        if (!st) st = h2d_sync(c, d_sz, hsz.data(), (size_t)nb * 4);
+        if (!st) st = h2d_sync(c, d_off, hoff.data(), (size_t)nb * 8);
+        if (!st) st = h2d_sync(c, d_cls, class_ptr, (size_t)(d + 2) * 8);
+        free(class_ptr);
+        if (st) return st;
+        launch_basis_image_outer(s, n, d, S1, S, nb, max_s, Qrm, ent, d_cls, d_col, d_sz, d_off, atol, out);
+    } else {
+    // chunks + output descriptors
+    const int64_t CH = 4096;
+    std::vector<int64_t> chunk_ptr(d + 1, 0), cb, ce;
+    for (int64_t i = 1; i <= d; ++i) {
+        chunk_ptr[i - 1] = (int64_t)cb.size();
+        for (int64_t p = class_ptr[i]; p < class_ptr[i + 1]; p += CH) {
+            cb.push_back(p);
+            ce.push_back(std::min(p + CH, class_ptr[i + 1]));
+        }
+    }
+    chunk_ptr[d] = (int64_t)cb.size();
+    free(class_ptr);
+    std::vector<int32_t> dA(S), dB(S);
+    {
+        int64_t o = 0, colbase = 0;
+        for (int32_t sz : c->bd_sizes) {
+            for (int b = 0; b < sz; ++b)
+                for (int a = 0; a < sz; ++a) {
+                    dA[o] = (int32_t)(colbase + a);
+                    dB[o] = (int32_t)(colbase + b);
+                    ++o;
+                }
+            colbase += sz;
+        }
+    }
+    const int64_t nch = (int64_t)cb.size();
+    int64_t* d_chunk_ptr = (int64_t*)ctx_buf(c, "bi_chunk_ptr", (d + 1) * 8);
+    int64_t* d_cb = (int64_t*)ctx_buf(c, "bi_cb", std::max<int64_t>(nch, 1) * 8);
+    int64_t* d_ce = (int64_t*)ctx_buf(c, "bi_ce", std::max<int64_t>(nch, 1) * 8);
+    int32_t* d_dA = (int32_t*)ctx_buf(c, "bi_da", std::max<int64_t>(S, 1) * 4);
+    int32_t* d_dB = (int32_t*)ctx_buf(c, "bi_db", std::max<int64_t>(S, 1) * 4);
+    double* partial = (double*)ctx_buf(c, "bi_partial", (size_t)std::max<int64_t>(nch * S, 1) * 8);
+    if (!d_chunk_ptr || !d_cb || !d_ce || !d_dA || !d_dB || !partial) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(d_chunk_ptr, chunk_ptr.data(), (d + 1) * 8, hipMemcpyHostToDevice, s));
+    if (nch) {
+        HIP_TRY(c, hipMemcpyAsync(d_cb, cb.data(), nch * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d_ce, ce.data(), nch * 8, hipMemcpyHostToDevice, s));
+    }
+    if (S) {
+        HIP_TRY(c, hipMemcpyAsync(d_dA, dA.data(), S * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d_dB, dB.data(), S * 4, hipMemcpyHostToDevice, s));
+    }
+    launch_basis_image(s, n, d, S1, S, Qrm, ent, nullptr, d_dA, d_dB, d_chunk_ptr, nch, nullptr, d_cb, d_ce,
+                       partial, out, atol);
+    }
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));  // host vectors above must outlive the copies
+    st = out_finish(c, blks, out, (size_t)d * S, mem);
+    if (st) return st;
+    if (Q_hat) {
+        if (mem == SDPSR_MEM_DEVICE)
+            HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, hipMemcpyDeviceToDevice, s));
+        else
+            HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    if (phase_ms) {
+        const float ms = ev_total.stop(s);
+        for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = 0;
+        phase_ms[SDPSR_T_IMAGE] = ms;
+        phase_ms[SDPSR_T_TOTAL] = ms;
+    }
+    return SDPSR_OK;
+}
+
+}  // extern "C"

@@ -10,7 +10,7 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
-#include "sdpsr_internal.h"
+#include "host_internal.h"
 
 namespace sdpsr {
 
@@ -168,7 +168,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
         return ctx_fail(c, SDPSR_HIP_ERROR, "eigensolver info read-back failed");
     if (host_w) memcpy(host_w, (char*)hpin + 64, (size_t)n * sizeof(double));
     const rocblas_int hinfo = hpin[0];
-    if (getenv("SDPSR_DEBUG") && n <= 128) fprintf(stderr, "[sdpsr] small syev n=%lld: %d sweeps\n", (long long)n, (int)hpin[1]);
+    if (dbg_on() && n <= 128) fprintf(stderr, "[sdpsr] small syev n=%lld: %d sweeps\n", (long long)n, (int)hpin[1]);
     if (hinfo != 0)
         return ctx_fail(c, SDPSR_SOLVER_ERROR, "eigensolver did not converge, info=" + std::to_string(hinfo));
     return SDPSR_OK;

@@ -586,8 +586,7 @@ void launch_basis_image_outer(hipStream_t s, int64_t n, int64_t d, int64_t S1, i
                               const int32_t* blk_col, const int32_t* blk_size, const int64_t* blk_off, double atol,
                               double* out) {
     dim3 g((unsigned)d, (unsigned)nblocks);
-    static const bool no_mfma = getenv("SDPSR_BASIS_IMAGE_VALU") != nullptr;  // A/B switch for measurements
-    if (max_s >= 16 && max_s <= 128 && n < 65536 && !no_mfma) {
+    if (max_s >= 16 && max_s <= 128 && n < 65536) {
         // matrix-core form: worth it once a block spans at least one full MFMA tile
         const int spmax = ((max_s + 15) / 16) * 16;
         const size_t lds_m = (size_t)2 * BM_EB * spmax * sizeof(double) + (size_t)2 * BM_EB * sizeof(int);

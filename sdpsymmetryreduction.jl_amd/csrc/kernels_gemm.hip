@@ -662,190 +662,6 @@ gemm_tn_dma256_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restri
         }
 }
 
-// ---------------------------------------------------------------------------
-// int8, 256 x 256 C tile, FOUR waves (2 x 2, a wave owns 128 x 128 = 4 x 4 MFMA tiles of 32 x 32).
-// Against the 8-wave kernel above: a K-step of 32 costs a wave 8 fragment reads for 16 MFMAs
-// (0.5 LDS bytes per MFMA byte instead of 0.75), i.e. 128 KiB of fragment reads per 128 bytes of
-// K against 2048 MFMA clocks -- the LDS pipe is at 50 % (+25 % for the DMA writes) instead of
-// saturated.  One wave per SIMD has nobody to hide its latencies behind, so the pipeline is
-// explicit: K-stages of 64 bytes, FOUR stages of 32 KiB in flight (a stage is consumed ~3000
-// clocks after it was requested), fragment registers double-buffered across the half stages, one
-// barrier per stage placed between the two MFMA batches of the stage.
-// ---------------------------------------------------------------------------
-constexpr int W4_NT = 256, W4_STAGES = 4, W4_KB = 64, W4_OPB = 256 * W4_KB, W4_STB = 2 * W4_OPB;
-
-// DIAG (measurement builds): 1 = no DMA (fragment reads + MFMAs), 2 = MFMAs only, 3 = DMA + barriers only
-template <int DIAG>
-__global__ void __launch_bounds__(W4_NT, 1)
-gemm_i8_w4_kernel(int64_t k, const int8_t* __restrict__ Ag, int64_t lda, const int8_t* __restrict__ Bg, int64_t ldb,
-                  int32_t* __restrict__ Cg, int64_t ldc, int64_t strideA, int64_t strideB, int64_t strideC,
-                  const uint32_t* __restrict__ nonsym_flag) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave & 1, wj = wave >> 1;
-    int bi = blockIdx.x, bj = blockIdx.y;
-    if (nonsym_flag && *nonsym_flag == 0u) {  // lower-triangle tiles only (see gemm_tn_dma256_kernel)
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const int gm = gridDim.x;
-        const int ntri = gm * (gm + 1) / 2;
-        if (lin >= ntri) return;
-        const int per = ntri >> 3;
-        const int t = (lin < 8 * per) ? (lin & 7) * per + (lin >> 3) : lin;
-        int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (row * (row + 1) / 2 > t) --row;
-        while ((row + 1) * (row + 2) / 2 <= t) ++row;
-        bi = row;
-        bj = t - row * (row + 1) / 2;
-    } else {
-        const int gm = gridDim.x, gn = gridDim.y;
-        const int nwg = gm * gn;
-        if ((nwg & 7) == 0 && (gm & 7) == 0) {
-            const int lin = blockIdx.y * gm + blockIdx.x;
-            const int swz = (lin & 7) * (nwg >> 3) + (lin >> 3);
-            const int per_group = 8 * gn;
-            const int grp = swz / per_group, within = swz - grp * per_group;
-            bi = grp * 8 + (within & 7);
-            bj = within >> 3;
-        }
-    }
-    const int64_t i0 = (int64_t)bi * 256;
-    const int64_t j0 = (int64_t)bj * 256;
-    const char* Ab = reinterpret_cast<const char*>(Ag + (int64_t)blockIdx.z * strideA + i0 * lda);
-    const char* Bb = reinterpret_cast<const char*>(Bg + (int64_t)blockIdx.z * strideB + j0 * ldb);
-    int32_t* C = Cg + (int64_t)blockIdx.z * strideC;
-
-    // DMA: one wave instruction = 16 rows x 64 B (lane-linear in LDS: row l >> 2, slot l & 3); slot
-    // s of row r holds global chunk s ^ ((r >> 2) & 3).  An operand stage is 16 instructions, this
-    // wave issues 4 of them per operand (its 64 rows).
-    const char* srcA[4];
-    const char* srcB[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int r = wave * 64 + u * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((r >> 2) & 3);
-        srcA[u] = Ab + (int64_t)r * lda + c * 16;
-        srcB[u] = Bb + (int64_t)r * ldb + c * 16;
-    }
-    auto issue = [&](int stage, int64_t kt) {
-        char* base = smem + stage * W4_STB + wave * 4096;
-        const int64_t kb = kt * W4_KB;
-        if (DIAG == 1 || DIAG == 2) return;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            glds16(srcA[u] + kb, base + u * 1024);
-            glds16(srcB[u] + kb, base + W4_OPB + u * 1024);
-        }
-    };
-    // fragment byte offsets inside a stage: [t][q], row * 64 + ((2 q + h) ^ sw(row)) * 16
-    const int r32 = lane & 31, h = lane >> 5;
-    int offA[4][2], offB[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ra = wi * 128 + t * 32 + r32, rb = wj * 128 + t * 32 + r32;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            offA[t][q] = ra * W4_KB + (((2 * q + h) ^ ((ra >> 2) & 3)) << 4);
-            offB[t][q] = W4_OPB + rb * W4_KB + (((2 * q + h) ^ ((rb >> 2) & 3)) << 4);
-        }
-    }
-    v16i acc[4][4];  // [tj][ti]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
-
-    const int64_t nk = k / W4_KB;
-    long long dg_c0 = 0, dg_w0 = 0;
-    if (DIAG == 4) dg_c0 = clock64(), dg_w0 = wall_clock64();
-    // prologue: three stages in flight, the first one landed
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 2) issue(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    uint4 f0a[4], f0b[4], f1a[4], f1b[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        f0a[t] = *reinterpret_cast<const uint4*>(smem + offA[t][0]);
-        f0b[t] = *reinterpret_cast<const uint4*>(smem + offB[t][0]);
-        if (DIAG >= 2) f1a[t] = f0a[t], f1b[t] = f0b[t];
-    }
-    for (int64_t kt = 0; kt < nk; ++kt) {
-        const char* st = smem + (int)(kt & 3) * W4_STB;
-        // the DMA instructions of stage kt+3 (its buffer was released by the barrier of stage kt-1)
-        // are issued one per two MFMAs: the inline asm is a scheduling barrier, a block of eight
-        // (address arithmetic + M0 moves, ~300 clocks) in front of the MFMAs would leave the matrix
-        // pipe idle for that long every stage
-        const bool more = kt + 3 < nk;
-        char* dbase = smem + (int)((kt + 3) & 3) * W4_STB + wave * 4096;
-        const int64_t dkb = (kt + 3) * W4_KB;
-        if (DIAG < 2) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f1a[t] = *reinterpret_cast<const uint4*>(st + offA[t][1]);
-                f1b[t] = *reinterpret_cast<const uint4*>(st + offB[t][1]);
-            }
-        }
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                v4i a = {(int)f0b[tj].x, (int)f0b[tj].y, (int)f0b[tj].z, (int)f0b[tj].w};
-                v4i b = {(int)f0a[ti].x, (int)f0a[ti].y, (int)f0a[ti].z, (int)f0a[ti].w};
-                if (DIAG != 3) acc[tj][ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[tj][ti], 0, 0, 0);
-                const int m = tj * 4 + ti;
-                if (DIAG != 1 && DIAG != 2 && (m & 1) && more) {
-                    const int u = m >> 2;  // 0..3
-                    if (m & 2) glds16(srcB[u] + dkb, dbase + W4_OPB + u * 1024);
-                    else glds16(srcA[u] + dkb, dbase + u * 1024);
-                }
-            }
-        // stage kt+1 must have landed (own share; the barrier extends that to every wave's) and this
-        // wave's reads of stage kt must be complete before anyone may overwrite it
-        if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (DIAG < 2 && kt + 1 < nk) {
-            const char* sn = smem + (int)((kt + 1) & 3) * W4_STB;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f0a[t] = *reinterpret_cast<const uint4*>(sn + offA[t][0]);
-                f0b[t] = *reinterpret_cast<const uint4*>(sn + offB[t][0]);
-            }
-        }
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                v4i a = {(int)f1b[tj].x, (int)f1b[tj].y, (int)f1b[tj].z, (int)f1b[tj].w};
-                v4i b = {(int)f1a[ti].x, (int)f1a[ti].y, (int)f1a[ti].z, (int)f1a[ti].w};
-                if (DIAG != 3) acc[tj][ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[tj][ti], 0, 0, 0);
-            }
-    }
-    if (DIAG == 4 && tid == 0 && (blockIdx.x + blockIdx.y * gridDim.x) % 97 == 0 && blockIdx.z == 0) {
-        const long long dc = clock64() - dg_c0, dw = wall_clock64() - dg_w0;
-        printf("[w4] wg (%d,%d): %lld shader clk / %lld stages = %.0f clk per stage, %.0f MHz\n", (int)blockIdx.x, (int)blockIdx.y, dc,
-               (long long)nk, (double)dc / (double)nk, (double)dc / (double)dw * 100.0);
-    }
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            const int64_t ii = i0 + wi * 128 + ti * 32 + r32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t jj = j0 + wj * 128 + tj * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                C[ii + jj * ldc] = acc[tj][ti][r];
-            }
-        }
-}
 
 // Dynamic-LDS limits are a per-device property of a kernel: sdpsr_create() calls this with the
 // ctx's device current, so a process may hold ctxs on several GPUs (no process-global flags).
@@ -864,16 +680,6 @@ static void gemm_set_attributes_kind() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM2 * 128);
 }
 void gemm_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8_w4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        W4_STAGES * W4_STB);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8_w4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        W4_STAGES * W4_STB);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8_w4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        W4_STAGES * W4_STB);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8_w4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        W4_STAGES * W4_STB);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8_w4_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        W4_STAGES * W4_STB);
     gemm_set_attributes_kind<KIND_I8>();
     gemm_set_attributes_kind<KIND_F32>();
     gemm_set_attributes_kind<KIND_F64>();
@@ -894,27 +700,11 @@ static void launch_gemm(hipStream_t s, int64_t m, int64_t n, int64_t k,
         ((strideA * ESZ) % 16) == 0 && ((strideB * ESZ) % 16) == 0 &&
         (reinterpret_cast<uintptr_t>(A) % 16) == 0 && (reinterpret_cast<uintptr_t>(B) % 16) == 0) {
         if constexpr (KIND == KIND_I8 || KIND == KIND_F32) {
-            static const bool only128 = getenv("SDPSR_GEMM128") != nullptr;  // A/B switch for measurements
             // 256 x 256 tiles pay off (6-15 % measured) once the launch has >= 4 workgroups per CU
             // (one resident workgroup per CU: fewer leave a ragged last round)
             const int64_t t2 = m / BM2;
             const int64_t wgs = (nonsym_flag ? t2 * (t2 + 1) / 2 : t2 * (n / BM2)) * batch;
-            static const int64_t min256 = getenv("SDPSR_GEMM256_MIN_WGS") ? atoll(getenv("SDPSR_GEMM256_MIN_WGS")) : 1024;  // measurement knob
-            if constexpr (KIND == KIND_I8) {
-                static const bool w4 = getenv("SDPSR_GEMM_I8_W4") != nullptr;  // measurement knob
-                if (w4 && m % 256 == 0 && n % 256 == 0 && k % W4_KB == 0) {
-                    dim3 grid4((unsigned)(m / 256), (unsigned)(n / 256), (unsigned)batch);
-                    static const int diag = getenv("SDPSR_W4_DIAG") ? atoi(getenv("SDPSR_W4_DIAG")) : 0;
-                    const size_t l4 = W4_STAGES * W4_STB;
-                    if (diag == 1) gemm_i8_w4_kernel<1><<<grid4, W4_NT, l4, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
-                    else if (diag == 2) gemm_i8_w4_kernel<2><<<grid4, W4_NT, l4, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
-                    else if (diag == 4) gemm_i8_w4_kernel<4><<<grid4, W4_NT, l4, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
-                    else if (diag == 3) gemm_i8_w4_kernel<3><<<grid4, W4_NT, l4, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
-                    else gemm_i8_w4_kernel<0><<<grid4, W4_NT, l4, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
-                    return;
-                }
-            }
-            if (!only128 && m % BM2 == 0 && n % BM2 == 0 && wgs >= min256) {
+            if (m % BM2 == 0 && n % BM2 == 0 && wgs >= 1024) {
                 constexpr size_t lds256 = 2 * 2 * BM2 * 128;  // 128 KiB
                 dim3 grid2((unsigned)(m / BM2), (unsigned)(n / BM2), (unsigned)batch);
                 gemm_tn_dma256_kernel<KIND><<<grid2, NT2, lds256, s>>>(k, A, lda, B, ldb, C, ldc, strideA, strideB, strideC, nonsym_flag);
@@ -966,39 +756,5 @@ void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X,
     launch_gemm<KIND_F32>(s, n, n, k, X, ldx, X, ldx, C, ldc, batch, strideX, strideX, strideC, nonsym_flag);
 }
 
-
-// ---------------------------------------------------------------------------
-// Shader-clock meter (diagnostic, sdpsr_profile_clock): one wave on a side stream samples
-// (clock64 = shader cycles, wall_clock64 = 100 MHz) every ~20 us while the kernels under test run
-// on the main stream.  The int8 squares are power-limited on this part: the clock they run at,
-// not their cycle count, decides the rate (measured: 2.1-2.2 GHz under MFMAs alone, ~1.4 GHz
-// under the full kernel).  Terminates on the flag, after ns samples or after max_ticks.
-// ---------------------------------------------------------------------------
-__global__ void clock_sampler_kernel(long long* __restrict__ buf, int ns, const unsigned* flag, long long max_ticks,
-                                     int* __restrict__ count) {
-    if (threadIdx.x != 0) return;
-    const long long w0 = wall_clock64();
-    long long next = w0;
-    int i = 0;
-    while (i < ns) {
-        const long long w = wall_clock64();
-        if (w >= next) {
-            buf[2 * i] = clock64();
-            buf[2 * i + 1] = w;
-            ++i;
-            next = w + 2000;
-        }
-        if (__builtin_nontemporal_load(flag) != 0u) break;
-        if (w - w0 > max_ticks) break;
-        __builtin_amdgcn_s_sleep(16);
-    }
-    *count = i;
-}
-__global__ void wall_marker_kernel(long long* out) { *out = wall_clock64(); }
-
-void launch_clock_sampler(hipStream_t s, long long* buf, int ns, const unsigned* flag, long long max_ticks, int* count) {
-    clock_sampler_kernel<<<1, 64, 0, s>>>(buf, ns, flag, max_ticks, count);
-}
-void launch_wall_marker(hipStream_t s, long long* out) { wall_marker_kernel<<<1, 1, 0, s>>>(out); }
 
 }  // namespace sdpsr

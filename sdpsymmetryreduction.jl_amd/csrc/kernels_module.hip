@@ -572,8 +572,7 @@ bool launch_label_spmm_multi(hipStream_t s, int64_t n, const uint32_t* L, const 
     if (zg < 1) zg = 1;
     if (zg > 32) zg = 32;
     const int zg_cap = zg;
-    static const bool valu = getenv("SDPSR_SPMM_VALU") != nullptr;  // A/B switch for measurements
-    if (!valu && n >= 64) {
+    if (n >= 64) {
         // matrix-core form.  Column split z: R = 2 or 3 workgroups on every CU, all resident at once (LDS:
         // class values + two slabs; registers: >= 4 waves per SIMD for every instantiation), the smallest
         // estimated time of  R x (columns per workgroup) MFMA steps  +  the partial sums through HBM.
@@ -585,8 +584,6 @@ bool launch_label_spmm_multi(hipStream_t s, int64_t n, const uint32_t* L, const 
         const int64_t lds_fit = (int64_t)(158 * 1024 / lds);
         for (int R = 1; R <= 3 && R <= lds_fit; ++R) {
             int64_t z0 = 256 * R / rb;
-            static const int z_env = getenv("SDPSR_SPMM_Z") ? atoi(getenv("SDPSR_SPMM_Z")) : 0;  // measurement knob
-            if (z_env) z0 = z_env;
             if (z0 < 1) z0 = 1;
             if (z0 * 32 > n) z0 = std::max<int64_t>(1, n / 32);
             if (z0 * G * w > (int64_t)zg_cap * 64) z0 = (int64_t)zg_cap * 64 / (G * w);

@@ -637,6 +637,19 @@ void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_
     sig_u32_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, L, k, sig);
 }
 
+// 64-bit integer keys (labels of an Int64 partition, or the hash-combined labels of several
+// restarts): key 0 -> signature 0 (the zero class), any other key -> its mixed value
+__global__ void sig_u64_kernel(int64_t len, const uint64_t* __restrict__ k, uint64_t* __restrict__ sig) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const uint64_t kk = k[e];
+        sig[e] = finish_sig(0u, kk == 0, sdpsr_sig_mix(sdpsr_sig_start(0u), kk));
+    }
+}
+void launch_sig_u64(hipStream_t s, int64_t len, const uint64_t* k, uint64_t* sig) {
+    sig_u64_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, k, sig);
+}
+
 // grid (row chunks, columns): no 64-bit division per entry
 template <typename CT>
 __global__ void sig_channels_kernel(int64_t n, int64_t ld, int T, const uint32_t* __restrict__ L,
@@ -842,7 +855,7 @@ struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by c
 // elements are drawn from the same partition S; the loop reaches the same fixed point as the
 // reference's two refinements per iteration (a class is only ever split when it has to be), with
 // one insert pass per iteration instead of two.
-template <int R>
+template <int R, int T>  // T = 2 or 4 channels
 struct SrcJoint {
     static constexpr bool kIJ = true;
     const double* __restrict__ U;
@@ -850,22 +863,23 @@ struct SrcJoint {
     const double* __restrict__ coef;
     uint64_t key;
     double atol, scale;
-    const int32_t* __restrict__ C;  // 4 channels, ld x ld each
+    const int32_t* __restrict__ C;  // T channels, ld x ld each
     int64_t ld;
     int n, lab_packed;
     __device__ __forceinline__ bool walks() const { return true; }
     __device__ __forceinline__ bool lower() const { return true; }
     __device__ __forceinline__ int order() const { return n; }
     __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const {
+        static_assert(T == 2 || T == 4, "joint signatures: 2 or 4 channels");
         const int64_t ef = (int64_t)i + (int64_t)j * n;
         const uint32_t l = lab_packed ? L[e] : L[ef];
         double u[R > 0 ? R : 1];
 #pragma unroll
         for (int k = 0; k < R; ++k) u[k] = __builtin_nontemporal_load(&U[(int64_t)k * n * n + ef]);
         const int32_t* Cij = C + (int64_t)j * ld + i;
-        int32_t c[4];
+        int32_t c[T];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) c[t] = __builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
+        for (int t = 0; t < T; ++t) c[t] = __builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
         const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
         double p = 0;
 #pragma unroll
@@ -873,9 +887,13 @@ struct SrcJoint {
         const double y = sdpsr_clamp_round(x - p, atol, scale);
         const uint64_t kb = (uint64_t)__double_as_longlong(y);
         uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
-        h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[0] | ((uint64_t)(uint32_t)c[1] << 32));
-        h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[2] | ((uint64_t)(uint32_t)c[3] << 32));
-        return finish_sig(l, kb == 0 && c[0] == 0 && c[1] == 0 && c[2] == 0 && c[3] == 0, h);
+        bool allz = kb == 0;
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[t] | ((uint64_t)(uint32_t)c[t + 1] << 32));
+            allz = allz && c[t] == 0 && c[t + 1] == 0;
+        }
+        return finish_sig(l, allz, h);
     }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         uint32_t i, j;
@@ -1350,8 +1368,7 @@ template <class SRC, int PER, int SLOTS = 1024>
 static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SRC& src, uint32_t* slot, const RefineWs& ws,
                           size_t cap) {
     const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
-    static const int per_cu_env = getenv("SDPSR_INSERT_WGS_PER_CU") ? atoi(getenv("SDPSR_INSERT_WGS_PER_CU")) : 0;  // measurement knob
-    if (SLOTS == 1024) g_chunks_cap = 256 * (per_cu_env > 0 ? per_cu_env : 5);  // measured 2..8: 5 is the minimum of a flat curve
+    if (SLOTS == 1024) g_chunks_cap = 256 * 5;  // resident workgroups per CU, measured 2..8: 5 is the minimum of a flat curve
     const int g = (int)(nchunk < g_chunks_cap ? nchunk : g_chunks_cap);
     refine_insert_kernel<SRC, PER, SLOTS><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                                 (uint32_t)(cap - 1), ws.counters);
@@ -1370,8 +1387,8 @@ static bool launch_insert_chan(hipStream_t s, int gcap, int64_t len, const SigSo
     }
 }
 
-// stand-alone form of SrcJoint (sort path)
-__global__ void sig_joint_lower_kernel(int n, int64_t ld, int r, const double* __restrict__ U, const uint32_t* __restrict__ L,
+// stand-alone form of SrcJoint (sort path); T = 2 or 4 channels
+__global__ void sig_joint_lower_kernel(int n, int64_t ld, int r, int T, const double* __restrict__ U, const uint32_t* __restrict__ L,
                                        int lab_packed, uint64_t key, const double* __restrict__ coef, double atol, double scale,
                                        const int32_t* __restrict__ C, uint64_t* __restrict__ sig) {
     const int64_t len = (int64_t)n * n;
@@ -1386,18 +1403,21 @@ __global__ void sig_joint_lower_kernel(int n, int64_t ld, int r, const double* _
             const double y = sdpsr_clamp_round(x - p, atol, scale);
             const uint64_t kb = (uint64_t)__double_as_longlong(y);
             const int32_t* Cij = C + (int64_t)j * ld + i;
-            const int32_t c0 = Cij[0], c1 = Cij[ld * ld], c2 = Cij[2 * ld * ld], c3 = Cij[3 * ld * ld];
             uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
-            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c0 | ((uint64_t)(uint32_t)c1 << 32));
-            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c2 | ((uint64_t)(uint32_t)c3 << 32));
-            sig[poff + i] = finish_sig(l, kb == 0 && c0 == 0 && c1 == 0 && c2 == 0 && c3 == 0, h);
+            bool allz = kb == 0;
+            for (int t = 0; t < T; t += 2) {
+                const int32_t c0 = Cij[(int64_t)t * ld * ld], c1 = Cij[(int64_t)(t + 1) * ld * ld];
+                h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c0 | ((uint64_t)(uint32_t)c1 << 32));
+                allz = allz && c0 == 0 && c1 == 0;
+            }
+            sig[poff + i] = finish_sig(l, allz, h);
         }
     }
 }
 
 bool sig_source_fusable(const SigSource& q) {
     switch (q.kind) {
-        case SIG_JOINT_I32: return q.r >= 0 && q.r <= 4 && q.T == 4 && q.packed;
+        case SIG_JOINT_I32: return q.r >= 0 && q.r <= 4 && (q.T == 2 || q.T == 4) && q.packed;
         case SIG_ARRAY: return true;
         case SIG_PAIR: return true;
         case SIG_PROJ: return q.r >= 0 && q.r <= 4;
@@ -1420,7 +1440,7 @@ void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint
             else launch_proj_apply(s, len, q.r, q.U, q.L, q.key, nullptr, q.coef, q.atol, q.scale, 1, nullptr, sig);
             break;
         case SIG_JOINT_I32:
-            sig_joint_lower_kernel<<<(int)(q.n < 2048 ? q.n : 2048), 256, 0, s>>>((int)q.n, q.ld, q.r, q.U, q.L, q.lab_packed, q.key, q.coef,
+            sig_joint_lower_kernel<<<(int)(q.n < 2048 ? q.n : 2048), 256, 0, s>>>((int)q.n, q.ld, q.r, q.T, q.U, q.L, q.lab_packed, q.key, q.coef,
                                                                                  q.atol, q.scale, (const int32_t*)q.C, sig);
             break;
         case SIG_CHAN_I32: launch_sig_i32(s, q.n, q.ld, q.T, q.L, (const int32_t*)q.C, sig, q.zero_flag, q.packed, q.lab_packed); break;
@@ -1452,13 +1472,28 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
             break;
         case SIG_JOINT_I32: {
             const int32_t* Cj = (const int32_t*)q.C;
-            switch (q.r) {
-                case 0: launch_insert<SrcJoint<0>, 8>(s, gcap, len, SrcJoint<0>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
-                case 1: launch_insert<SrcJoint<1>, 8>(s, gcap, len, SrcJoint<1>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
-                case 2: launch_insert<SrcJoint<2>, 8>(s, gcap, len, SrcJoint<2>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
-                case 3: launch_insert<SrcJoint<3>, 8>(s, gcap, len, SrcJoint<3>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
-                default: launch_insert<SrcJoint<4>, 8>(s, gcap, len, SrcJoint<4>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed}, slot, ws, cap); break;
+#define SDPSR_JOINT_CASE(RR, TT)                                                                                                   \
+    launch_insert<SrcJoint<RR, TT>, 8>(s, gcap, len, SrcJoint<RR, TT>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, \
+                                                                      q.lab_packed}, slot, ws, cap)
+            const int rr = q.r < 0 ? 0 : (q.r > 4 ? 4 : q.r);
+            if (q.T == 2) {
+                switch (rr) {
+                    case 0: SDPSR_JOINT_CASE(0, 2); break;
+                    case 1: SDPSR_JOINT_CASE(1, 2); break;
+                    case 2: SDPSR_JOINT_CASE(2, 2); break;
+                    case 3: SDPSR_JOINT_CASE(3, 2); break;
+                    default: SDPSR_JOINT_CASE(4, 2); break;
+                }
+            } else {
+                switch (rr) {
+                    case 0: SDPSR_JOINT_CASE(0, 4); break;
+                    case 1: SDPSR_JOINT_CASE(1, 4); break;
+                    case 2: SDPSR_JOINT_CASE(2, 4); break;
+                    case 3: SDPSR_JOINT_CASE(3, 4); break;
+                    default: SDPSR_JOINT_CASE(4, 4); break;
+                }
             }
+#undef SDPSR_JOINT_CASE
             break;
         }
         case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;
@@ -1484,6 +1519,31 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
     } else {
         refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small);
     }
+}
+
+// ---------------------------------------------------------------------------
+// largest pair code l1 + l2 (d1 + 1) of refine!(P1, P2) (src/partitions.jl:63): what the reference
+// stores into its label type T before renumbering -- InexactError when it exceeds typemax(T)
+// (sdpsr_opts.label_bits).  out[0] must be zero.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+max_pair_code_kernel(int64_t len, const uint32_t* __restrict__ p1, const uint32_t* __restrict__ p2, unsigned long long d1p1,
+                     unsigned long long* __restrict__ out) {
+    unsigned long long m = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+        const unsigned long long v = (unsigned long long)p1[e] + (unsigned long long)p2[e] * d1p1;
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_down(m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+void launch_max_pair_code(hipStream_t s, int64_t len, const uint32_t* p1, const uint32_t* p2, uint64_t d1, uint64_t* out) {
+    max_pair_code_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, p1, p2, (unsigned long long)d1 + 1ull, (unsigned long long*)out);
 }
 
 // ---------------------------------------------------------------------------
@@ -1759,18 +1819,6 @@ __global__ void sub_round_kernel(int64_t len, const double* __restrict__ a, cons
 }
 void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double* b, double atol, double scale, double* out) {
     sub_round_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, a, b, atol, scale, out);
-}
-
-// synthetic signatures with `nclasses` distinct non-zero values (measurement hook)
-__global__ void fill_test_sig_kernel(int64_t len, int64_t nclasses, uint64_t* __restrict__ sig) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
-        uint64_t cls = sdpsr_fmix64((uint64_t)e * 0x9E3779B97F4A7C15ULL + 17) % (uint64_t)nclasses;
-        sig[e] = sdpsr_fmix64(cls + 1) | 1ull;
-    }
-}
-void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t* sig) {
-    fill_test_sig_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, nclasses, sig);
 }
 
 }  // namespace sdpsr

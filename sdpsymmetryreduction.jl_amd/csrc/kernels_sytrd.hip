@@ -848,7 +848,7 @@ void sytrd_graph_cache_destroy(SytrdGraphCache* g) {
 
 void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
     hipStream_t s = c->stream;
-    const bool no_graph = getenv("SDPSR_NO_GRAPH") != nullptr;
+    const bool no_graph = (c->opts.flags & SDPSR_FLAG_NO_GRAPH) != 0;  // profiling: per-kernel statistics of the launches
     if (no_graph || n64 < 64) {
         launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
         return;
@@ -1158,9 +1158,7 @@ bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double*
         int threads = (half * half + 63) / 64 * 64;
         if (threads < 64) threads = 64;
         const size_t lds64 = 4 * (size_t)(mm | 1) * mm * sizeof(double) + 64;
-        static const bool old_core = getenv("SDPSR_JACOBI_TWO_BARRIERS") != nullptr;  // diagnostic
-        if (old_core) small_syev_jacobi64_kernel<false><<<1, threads, lds64, s>>>((int)n, A, lda, w, info);
-        else small_syev_jacobi64_kernel<true><<<1, threads, lds64, s>>>((int)n, A, lda, w, info);
+        small_syev_jacobi64_kernel<true><<<1, threads, lds64, s>>>((int)n, A, lda, w, info);
         return true;
     }
     const int v_in_lds = (2 * lds <= 150 * 1024) ? 1 : 0;

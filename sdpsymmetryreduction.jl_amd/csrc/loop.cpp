@@ -1,0 +1,577 @@
+// admissible_subspace (src/partitions.jl:109-190): the Jordan-reduction loop on the device, the
+// setup stage for dense problems, desymmetrize (:197-223) and the reduced-SDP assembly A * PMat.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <functional>
+#include <numeric>
+
+#include "host_internal.h"
+
+using namespace sdpsr;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// admissible_subspace loop, src/partitions.jl:145-185
+// ---------------------------------------------------------------------------
+int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L,
+                              const double* U, int64_t r, double atol, uint32_t* P_out,
+                              int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem) {
+    CHECK_CTX(c);
+    const int hint = c->hint_symmetric_basis;  // one call only, whatever happens below
+    c->hint_symmetric_basis = 0;
+    c->adm_dims.clear();
+    if (!CL || !X0L || !P_out || !dim_out || n < 1 || r < 0 || (r > 0 && !U) || !(atol > 0))
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    PhaseTimer tm(c, phase_ms != nullptr);
+    TotalEvents ev_total(phase_ms != nullptr, s);
+
+    const double* dCL = in_dev(c, "adm_cl", CL, len, mem, &st);
+    const double* dX0 = in_dev(c, "adm_x0", X0L, len, mem, &st);
+    const double* dU = in_dev(c, "adm_u", U, (size_t)len * std::max<int64_t>(r, 1), mem, &st);
+    uint32_t* L = out_dev(c, "adm_labels", P_out, len, mem, &st);
+    uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+    const int nblk = 2048;
+    double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)2 * std::max<int64_t>(r, 1) * nblk * 8);  // + the symmetry probes
+    double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)2 * std::max<int64_t>(r, 1) * 8);
+    uint32_t* symflag = (uint32_t*)ctx_buf(c, "adm_symflag", 64);  // [0] verdict of the last check, [8] constant 0
+    if (st || !sig || !partial || !coef || !symflag) return st ? st : SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemsetAsync(symflag, 0, 64, s));
+    const uint32_t* zero_flag = symflag + 8;  // "symmetric" for the kernels that take a device flag
+    int labels_sym = 0;
+
+    const int mode = c->opts.square_mode;
+    const int T = (mode == SDPSR_SQUARE_F64) ? 1 : c->opts.channels;
+    const int64_t ld = round_up(n, 128);
+    void* Xp = nullptr;
+    void* Cp = nullptr;
+    double* Y = nullptr;
+    int vmax = 0;
+    if (mode == SDPSR_SQUARE_I8) {
+        Xp = ctx_buf(c, "adm_xi8", (size_t)T * ld * ld);
+        Cp = ctx_buf(c, "adm_ci32", (size_t)T * ld * ld * 4);
+    } else if (mode == SDPSR_SQUARE_F32) {
+        Xp = ctx_buf(c, "adm_xf32", (size_t)T * ld * ld * 4);
+        Cp = ctx_buf(c, "adm_cf32", (size_t)T * ld * ld * 4);
+        vmax = (int)std::floor(std::sqrt(16777216.0 / (double)n));
+        if (vmax > 127) vmax = 127;
+        if (vmax < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "n too large for the exact fp32 square");
+    } else if (mode == SDPSR_SQUARE_F64) {
+        Xp = ctx_buf(c, "adm_xf64", (size_t)ld * ld * 8);
+        Cp = ctx_buf(c, "adm_cf64", (size_t)ld * ld * 8);
+        Y = (double*)ctx_buf(c, "adm_y", (size_t)len * 8);
+        if (!Y) return SDPSR_OUT_OF_MEMORY;
+    } else {
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "unknown square_mode");
+    }
+    if (!Xp || !Cp) return SDPSR_OUT_OF_MEMORY;
+
+    const double scale = round_scale(c, atol);  // src/utils.jl:37
+
+    // Symmetric labels live as the packed lower triangle Lp (column j at offset j n - j (j - 1) / 2)
+    // between the refinements of the int8 loop: every consumer there reads the packed form (the
+    // channel gather mirrors it tile by tile), the full matrix L is formed once at the end -- or
+    // whenever a step needs it (non-symmetric basis, other square modes).
+    const int64_t lenp = n * (n + 1) / 2;
+    const bool int_modes = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
+    uint32_t* Lp = int_modes ? (uint32_t*)ctx_buf(c, "adm_lpacked", (size_t)lenp * 4) : nullptr;
+    if (int_modes && !Lp) return SDPSR_OUT_OF_MEMORY;
+    const bool keep_packed = mode == SDPSR_SQUARE_I8 && (T == 1 || T == 2 || T == 4) && !(c->opts.flags & SDPSR_FLAG_UNPACK_EVERY_STEP);
+    bool full_valid = true, packed_valid = false;
+    auto need_full = [&]() {
+        if (!full_valid) {
+            launch_unpack_symmetric_labels(s, n, Lp, L);
+            full_valid = true;
+        }
+    };
+    // S = Part(CL); S = refine!(S, Part(X0L))   (:145-146)
+    int64_t d = 0;
+    tm.begin(SDPSR_T_REFINE);
+    {  // both refinements in one canonical relabel; the pair signature is computed inside the insert pass
+        SigSource q;
+        q.kind = SIG_PAIR;
+        q.sig = sig;
+        q.a = dCL;
+        q.b = dX0;
+        if ((hint & 2) && Lp && len < (int64_t(1) << 32)) {
+            // the caller vouches for symmetric CL / X0L (the reference symmetrises both,
+            // src/partitions.jl:128-141): the initial partition from the lower triangle, mirrored
+            q.n = n;
+            q.packed = 1;
+            st = refine_signatures(c, lenp, q, Lp, &d);
+            labels_sym = 1;
+            packed_valid = true;
+            full_valid = false;
+            if (!st && !keep_packed) need_full();
+        } else {
+            st = refine_signatures(c, len, q, L, &d, n, symflag, &labels_sym);  // + symmetry verdict of the initial partition
+        }
+    }
+    tm.end();
+    if (st) return st;
+    HIP_TRY(c, hipStreamSynchronize(s));
+    tm.collect();
+    c->adm_dims.assign(1, d);
+    if (label_overflows(c, (uint64_t)d)) return label_overflow_fail(c, "admissible_subspace: dim(S)", (uint64_t)d);
+    // Projection on the lower triangle (half the bytes and hashes of the step) needs symmetric
+    // labels AND symmetric basis matrices U_k.  The caller may vouch for the latter
+    // (sdpsr_hint_symmetric_basis); otherwise the first iteration's dot-product pass carries a
+    // randomized symmetry probe and the following iterations use its verdict.
+    bool basis_sym = (r == 0) || (hint & 1) != 0;
+    bool probe_pending = !basis_sym;
+    double* probe_host = nullptr;
+
+    const int64_t maximal = (len + n) / 2;  // :148
+    int64_t current = d;
+    int it = 0;
+    int confirm_left = c->opts.confirm_rounds;
+    bool converged = current >= maximal;
+    while (current < maximal) {  // :154
+        if (it >= c->opts.max_iters) break;
+        ++it;
+        // --- random projection (:159-164) ---
+        tm.begin(SDPSR_T_PROJECT);
+        const uint64_t key = next_key(c);
+        const bool int_mode = (mode == SDPSR_SQUARE_I8 || mode == SDPSR_SQUARE_F32);
+        const bool packed_proj = int_mode && labels_sym && basis_sym && r <= 4 && len < (int64_t(1) << 32);
+        // Joint iteration (int8, everything symmetric, few classes): the projected element and the
+        // square -- two independent random elements of the SAME partition S -- refine S in ONE
+        // canonical relabel of the signature (label, rounded projection, channel values).  The
+        // reference refines twice per iteration and draws the squared element from the already
+        // refined partition (:159-174); both loops stop at the same fixed point (the smallest
+        // partition subspace containing C_L, X0 that is closed under the projection and under
+        // squaring), since a class is only ever split when generic elements of the closure force
+        // it.  An "iteration" is then one joint step.
+        const bool separate = (c->opts.flags & SDPSR_FLAG_SEPARATE_REFINEMENTS) != 0;
+        if (!separate && packed_proj && keep_packed && (T == 2 || T == 4) && c->table_log2_hint < 21) {
+            const bool jl = packed_valid;
+            if (!jl) need_full();
+            launch_proj_coef_lower(s, n, r, dU, jl ? Lp : L, jl ? 1 : 0, key, partial, nblk, coef);
+            tm.end();
+            int64_t dj = current;
+            for (;;) {
+                tm.begin(SDPSR_T_SQUARE);
+                const uint64_t key2 = next_key(c);
+                const bool jl2 = packed_valid;
+                if (jl2) launch_gather_i8_sym_packed(s, n, ld, T, Lp, key2, (int8_t*)Xp, current);
+                else launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp, current);
+                launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, zero_flag);
+                tm.end();
+                tm.begin(SDPSR_T_REFINE);
+                SigSource qj;
+                qj.kind = SIG_JOINT_I32;
+                qj.sig = sig;
+                qj.U = dU;
+                qj.coef = coef;
+                qj.r = (int)r;
+                qj.key = key;
+                qj.atol = atol;
+                qj.scale = scale;
+                qj.n = n;
+                qj.ld = ld;
+                qj.T = T;
+                qj.C = Cp;
+                qj.packed = 1;
+                qj.L = jl2 ? Lp : L;
+                qj.lab_packed = jl2 ? 1 : 0;
+                st = refine_signatures(c, lenp, qj, Lp, &dj);
+                packed_valid = true;
+                full_valid = false;
+                tm.end();
+                if (st) return st;
+                tm.collect();
+                if (dj == current && confirm_left > 0) {  // extra independent draws before stopping
+                    --confirm_left;
+                    continue;  // (same projected element, a fresh square: the projection did not refine either)
+                }
+                break;
+            }
+            c->adm_dims.push_back(dj);
+            if (label_overflows(c, (uint64_t)dj)) return label_overflow_fail(c, "admissible_subspace: dim(S)", (uint64_t)dj);
+            if (dj == current) {
+                converged = true;
+                break;
+            }
+            confirm_left = c->opts.confirm_rounds;
+            current = dj;
+            if (current >= maximal) converged = true;
+            continue;
+        }
+        bool probed = false;
+        const bool plab = packed_proj && packed_valid;  // the projection reads the packed labels
+        if (!plab) need_full();
+        if (packed_proj) {
+            launch_proj_coef_lower(s, n, r, dU, plab ? Lp : L, plab ? 1 : 0, key, partial, nblk, coef);
+        } else if (probe_pending && int_mode && len < (int64_t(1) << 32)) {
+            launch_proj_coef_probe(s, len, n, r, dU, L, key, partial, nblk, coef);
+            probe_host = (double*)c->pinned + 64;  // c->pinned[0..63] carries the refinement's counters
+            if ((size_t)(r + 64) * 8 > c->pinned_bytes) probe_host = nullptr;
+            if (probe_host) {
+                HIP_TRY(c, hipMemcpyAsync(probe_host, coef + r, (size_t)r * 8, hipMemcpyDeviceToHost, s));
+                probed = true;
+            }
+        } else {
+            launch_proj_coef(s, len, r, dU, L, key, nullptr, partial, nblk, coef);
+        }
+        SigSource qp;  // integer modes: y = round(x - U coef) exists only inside the insert pass of the refinement
+        qp.sig = sig;
+        if (Y) {
+            launch_proj_apply(s, len, r, dU, L, key, nullptr, coef, atol, scale, 1, Y, sig);
+        } else {
+            qp.kind = SIG_PROJ;
+            qp.U = dU;
+            qp.coef = coef;
+            qp.L = L;
+            qp.r = (int)r;
+            qp.key = key;
+            qp.atol = atol;
+            qp.scale = scale;
+            qp.n = n;
+            qp.packed = packed_proj ? 1 : 0;
+            if (plab) {
+                qp.L = Lp;
+                qp.lab_packed = 1;
+            }
+        }
+        tm.end();
+        tm.begin(SDPSR_T_REFINE);
+        int64_t d1 = 0;
+        if (packed_proj) {
+            // symmetric by construction: refine the packed lower triangle (in place when the labels were packed)
+            st = refine_signatures(c, lenp, qp, Lp, &d1);
+            packed_valid = true;
+            full_valid = false;
+            if (!st && !keep_packed) need_full();
+        } else {
+            st = refine_signatures(c, len, qp, L, &d1, int_mode ? n : 0, symflag, &labels_sym);
+            full_valid = true;
+            packed_valid = false;
+        }
+        tm.end();
+        if (st) return st;
+        if (probed) {  // the refinement has synchronised the stream: the probes are in
+            probe_pending = false;
+            basis_sym = true;
+            for (int64_t k = 0; k < r; ++k)
+                if (!(std::fabs(probe_host[k]) <= 1e-10)) basis_sym = false;  // |U_k| = 1 (orthonormal basis)
+        }
+        // --- random square (:166-174) ---
+        int64_t d2 = d1;
+        for (;;) {
+            tm.begin(SDPSR_T_SQUARE);
+            const uint64_t key2 = next_key(c);
+            // Integer modes.  Symmetric labels (the Jordan-algebra case; the verdict came back
+            // with the counters of the last refinement): X is symmetric, X X = X'X is symmetric
+            // and exact, so only the lower-triangle tiles are computed, only entries i >= j get
+            // a signature, and the strict upper triangle of the new labels is mirrored after the
+            // refinement (first occurrences in column-major order always sit in the lower
+            // triangle: same canonical numbering).  Non-symmetric labels: X X literally, with
+            // the K-contiguous left operand gathered from the transposed labels (same draw).
+            const uint32_t* lower = labels_sym ? zero_flag : nullptr;
+            const bool slab = keep_packed && labels_sym && packed_valid;  // the square step reads the packed labels
+            if (!slab) need_full();
+            const uint32_t* Lleft = L;
+            // signatures of the squares: computed inside the insert pass of the refinement (integer
+            // modes), an array for the fp64 mode
+            SigSource qs;
+            qs.sig = sig;
+            qs.L = L;
+            qs.n = n;
+            qs.ld = ld;
+            qs.T = T;
+            qs.C = Cp;
+            qs.packed = labels_sym;
+            qs.zero_flag = lower;
+            if (slab) {
+                qs.L = Lp;
+                qs.lab_packed = 1;
+            }
+            if (int_mode && !labels_sym) {
+                uint32_t* Lt = (uint32_t*)ctx_buf(c, "des_lt", len * 4);
+                if (!Lt) return SDPSR_OUT_OF_MEMORY;
+                launch_transpose_labels(s, n, L, Lt);
+                Lleft = Lt;
+            }
+            if (mode == SDPSR_SQUARE_I8) {
+                int8_t* Xl = (int8_t*)Xp;
+                if (slab) launch_gather_i8_sym_packed(s, n, ld, T, Lp, key2, (int8_t*)Xp, d2);  // d2 = current dimension
+                else launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp, d2);
+                if (!labels_sym) {
+                    Xl = (int8_t*)ctx_buf(c, "des_yi8", (size_t)T * ld * ld);
+                    if (!Xl) return SDPSR_OUT_OF_MEMORY;
+                    launch_gather_i8(s, n, ld, T, Lleft, key2, Xl, d2);
+                    launch_gemm_tn_i8(s, ld, ld, ld, Xl, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
+                } else {
+                    launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, lower);
+                }
+                qs.kind = SIG_CHAN_I32;
+            } else if (mode == SDPSR_SQUARE_F32) {
+                launch_gather_f32(s, n, ld, T, vmax, L, key2, (float*)Xp);
+                if (!labels_sym) {
+                    float* Xl = (float*)ctx_buf(c, "adm_xlf32", (size_t)T * ld * ld * 4);
+                    if (!Xl) return SDPSR_OUT_OF_MEMORY;
+                    launch_gather_f32(s, n, ld, T, vmax, Lleft, key2, Xl);
+                    launch_gemm_tn_f32(s, ld, ld, ld, Xl, ld, (const float*)Xp, ld, (float*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
+                } else {
+                    launch_gemm_tn_f32_sym(s, ld, ld, (const float*)Xp, ld, (float*)Cp, ld, T, ld * ld, ld * ld, lower);
+                }
+                qs.kind = SIG_CHAN_F32;
+            } else {
+                // reference-literal: the projected element is squared when the projection
+                // step did not refine S (X is overwritten in place at :160-163), a fresh
+                // random element otherwise (:166-168)
+                if (d1 != current || confirm_left != c->opts.confirm_rounds)
+                    launch_gather_f64_padded(s, n, ld, L, key2, (double*)Xp);
+                else
+                    launch_pad_copy(s, n, ld, Y, Xp, 8);
+                launch_gemm_tn_f64(s, ld, ld, ld, (const double*)Xp, ld, (const double*)Xp, ld,
+                                   (double*)Cp, ld, 1, 0, 0, 0);
+                launch_sig_f64_rounded(s, n, ld, L, (const double*)Cp, atol, scale, sig);
+            }
+            tm.end();
+            tm.begin(SDPSR_T_REFINE);
+            if (int_mode && labels_sym) {
+                // symmetric labels: the signatures exist for the packed lower triangle only;
+                // refine n (n + 1) / 2 entries (same relative order, same canonical numbering);
+                // the full symmetric matrix is formed when somebody needs it
+                st = refine_signatures(c, lenp, qs, Lp, &d2);
+                packed_valid = true;
+                full_valid = false;
+                if (!st && !keep_packed) need_full();
+            } else {
+                st = refine_signatures(c, len, qs, L, &d2);
+                full_valid = true;
+                packed_valid = false;
+            }
+            tm.end();
+            if (st) return st;
+            tm.collect();
+            if (d2 == current && confirm_left > 0) {  // extra independent draws before stopping
+                --confirm_left;
+                continue;
+            }
+            break;
+        }
+        c->adm_dims.push_back(d2);
+        if (label_overflows(c, (uint64_t)d2)) return label_overflow_fail(c, "admissible_subspace: dim(S)", (uint64_t)d2);
+        if (d2 == current) {  // :180-182
+            converged = true;
+            break;
+        }
+        confirm_left = c->opts.confirm_rounds;
+        current = d2;  // :184
+        if (current >= maximal) converged = true;
+    }
+    need_full();
+    HIP_TRY(c, hipGetLastError());
+    *dim_out = current;
+    if (iters_out) *iters_out = it;
+    st = out_finish(c, P_out, L, len, mem);
+    if (st) return st;
+    if (phase_ms) {
+        const float ms = ev_total.stop(s);
+        tm.collect();
+        for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = tm.acc[i];
+        phase_ms[SDPSR_T_TOTAL] = ms;
+    }
+    if (!converged) return ctx_fail(c, SDPSR_NOT_CONVERGED, "max_iters reached");
+    return SDPSR_OK;
+}
+
+// desymmetrize, src/partitions.jl:197-223
+int sdpsr_desymmetrize(sdpsr_ctx* c, int64_t n, uint32_t* P, int64_t* dim, int32_t* iters, int mem) {
+    CHECK_CTX(c);
+    if (!P || !dim || n < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    uint32_t* L = (mem == SDPSR_MEM_DEVICE) ? P : (uint32_t*)in_dev(c, "adm_labels", (const uint32_t*)P, len, mem, &st);
+    if (st) return st;
+    const int T = c->opts.channels;
+    const int64_t ld = round_up(n, 128);
+    uint32_t* Lt = (uint32_t*)ctx_buf(c, "des_lt", len * 4);
+    int8_t* X = (int8_t*)ctx_buf(c, "adm_xi8", (size_t)T * ld * ld);
+    int8_t* Y = (int8_t*)ctx_buf(c, "des_yi8", (size_t)T * ld * ld);
+    int32_t* Cp = (int32_t*)ctx_buf(c, "adm_ci32", (size_t)T * ld * ld * 4);
+    uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+    if (!Lt || !X || !Y || !Cp || !sig) return SDPSR_OUT_OF_MEMORY;
+    int64_t current = *dim;
+    int it = 0;
+    int confirm_left = c->opts.confirm_rounds;  // extra independent products before a stall is believed (as in the loop above)
+    for (;;) {  // :208-220
+        if (it >= c->opts.max_iters) return ctx_fail(c, SDPSR_NOT_CONVERGED, "max_iters reached");
+        ++it;
+        launch_transpose_labels(s, n, L, Lt);
+        launch_gather_i8(s, n, ld, T, Lt, next_key(c), X);  // X' as the K-contiguous operand
+        launch_gather_i8(s, n, ld, T, L, next_key(c), Y);
+        launch_gemm_tn_i8(s, ld, ld, ld, X, ld, Y, ld, Cp, ld, T, ld * ld, ld * ld, ld * ld);  // (X')' Y = X Y
+        launch_sig_i32(s, n, ld, T, L, Cp, sig);
+        int64_t d2 = 0;
+        st = refine_signatures(c, len, sig, L, &d2);
+        if (st) return st;
+        if (d2 == current) {
+            if (confirm_left > 0) {
+                --confirm_left;
+                --it;  // a confirm round is not an iteration of the reference's loop
+                continue;
+            }
+            break;
+        }
+        confirm_left = c->opts.confirm_rounds;
+        current = d2;
+    }
+    *dim = current;
+    if (iters) *iters = it;
+    return out_finish(c, P, L, len, mem);
+}
+
+// A * PMat (README.md:57-60)
+int sdpsr_reduce_constraints(sdpsr_ctx* c, int64_t len, const uint32_t* labels, int64_t d, int64_t m, const double* A,
+                             double* out, int mem) {
+    CHECK_CTX(c);
+    if (!labels || !A || !out || d < 1 || m < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = check_len(c, len);
+    if (st) return st;
+    const uint32_t* dL = in_dev(c, "prim_in_a", labels, len, mem, &st);
+    const double* dA = in_dev(c, "red_a", A, (size_t)len * m, mem, &st);
+    double* dO = out_dev(c, "red_out", out, (size_t)m * d, mem, &st);
+    const int64_t chunk = reduce_columns_chunk(len, m, d);
+    double* part = (double*)ctx_buf(c, "red_part", (size_t)((len + chunk - 1) / chunk) * d * m * 8);
+    if (st || !part) return st ? st : SDPSR_OUT_OF_MEMORY;
+    if (!launch_reduce_columns(c->stream, len, m, d, dL, dA, part, dO))
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "dim(P) * min(m, 64) too large for the LDS accumulators");
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, out, dO, (size_t)m * d, mem);
+}
+
+// Setup stage for dense problems on the device, src/partitions.jl:117-142:
+//   U    orthonormal basis of rowspace(A): modified Gram-Schmidt on the residual rows with
+//        pivoting by residual norm and one re-orthogonalisation pass (stands in for qr(A'));
+//   C_L  = symmetrize(round(c - U U'c));   X0_L = round(U U' symmetrize(x0)),  x0 = U R^-T b
+// All vectors of length n^2 stay in HBM; the host sees m-vectors of dot products only.
+int sdpsr_admissible_subspace_dense(sdpsr_ctx* c, int64_t n, int64_t m, const double* C,
+                                    const double* A, const double* b, double atol, uint32_t* P_out,
+                                    int64_t* dim_out, int32_t* iters_out, double* phase_ms,
+                                    int mem_out) {
+    CHECK_CTX(c);
+    c->hint_symmetric_basis = 0;  // hints describe caller-made CL / X0L / U; here the library makes them itself
+    if (!C || !A || !b || n < 1 || m < 0 || !(atol > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    const int64_t mm = std::max<int64_t>(m, 1);
+    const int nblk = 2048;
+    double* dA = (double*)ctx_buf(c, "set_a", (size_t)len * mm * 8);   // m x len as given
+    double* R = (double*)ctx_buf(c, "set_r", (size_t)len * mm * 8);    // residual rows, len x m
+    double* U = (double*)ctx_buf(c, "adm_u", (size_t)len * mm * 8);    // basis, len x r
+    double* v1 = (double*)ctx_buf(c, "set_v1", (size_t)len * 8);
+    double* v2 = (double*)ctx_buf(c, "set_v2", (size_t)len * 8);
+    double* dCL = (double*)ctx_buf(c, "adm_cl", (size_t)len * 8);
+    double* dX0 = (double*)ctx_buf(c, "adm_x0", (size_t)len * 8);
+    double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)mm * nblk * 8);
+    double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)mm * 8);
+    if (!dA || !R || !U || !v1 || !v2 || !dCL || !dX0 || !partial || !coef) return SDPSR_OUT_OF_MEMORY;
+    if (m > 0) HIP_TRY(c, hipMemcpyAsync(dA, A, (size_t)len * m * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(v1, C, (size_t)len * 8, hipMemcpyHostToDevice, s));  // v1 = c
+    if (m > 0) launch_transpose_rows(s, len, m, dA, R);  // R[e + i*len] = A[i + e*m]
+    std::vector<std::vector<double>> coeffs(m, std::vector<double>(mm, 0.0));
+    std::vector<int64_t> piv;
+    std::vector<char> used(m, 0);
+    std::vector<double> hd(mm);
+    double maxnorm = 0;
+    int64_t r = 0;
+    for (int64_t step = 0; step < m; ++step) {
+        launch_col_norms2(s, len, m, R, partial, nblk, coef);  // |R_i|^2 for every row
+        st = d2h_sync(c, hd.data(), coef, (size_t)m * 8);
+        if (st) return st;
+        if (step == 0)
+            for (int64_t i = 0; i < m; ++i) maxnorm = std::max(maxnorm, std::sqrt(hd[i]));
+        int64_t best = -1;
+        double bestn = -1;
+        for (int64_t i = 0; i < m; ++i)
+            if (!used[i] && hd[i] > bestn) {
+                bestn = hd[i];
+                best = i;
+            }
+        if (best < 0 || std::sqrt(std::max(bestn, 0.0)) <= 1e-12 * maxnorm) break;
+        used[best] = 1;
+        double* v = R + (size_t)best * len;
+        if (r > 0) {  // re-orthogonalise against the basis so far
+            launch_proj_coef(s, len, r, U, nullptr, 0, v, partial, nblk, coef);
+            st = d2h_sync(c, hd.data(), coef, (size_t)r * 8);
+            if (st) return st;
+            for (int64_t j = 0; j < r; ++j) coeffs[best][j] += hd[j];
+            launch_proj_apply(s, len, r, U, nullptr, 0, v, coef, 0, 1, 0, v, nullptr);
+        }
+        launch_col_norms2(s, len, 1, v, partial, nblk, coef);
+        double nn = 0;
+        st = d2h_sync(c, &nn, coef, 8);
+        if (st) return st;
+        nn = std::sqrt(std::max(nn, 0.0));
+        if (nn <= 1e-12 * maxnorm) continue;
+        double* ur = U + (size_t)r * len;
+        launch_scale_copy(s, len, v, 1.0 / nn, ur);
+        coeffs[best][r] = nn;
+        // remaining residual rows: R_i -= (u . R_i) u
+        launch_proj_coef(s, len, m, R, nullptr, 0, ur, partial, nblk, coef);  // dots of every row with u
+        st = d2h_sync(c, hd.data(), coef, (size_t)m * 8);
+        if (st) return st;
+        std::vector<double> dots(m, 0.0);
+        for (int64_t i = 0; i < m; ++i)
+            if (!used[i]) {
+                dots[i] = hd[i];
+                coeffs[i][r] += hd[i];
+            }
+        st = h2d_sync(c, coef, dots.data(), (size_t)m * 8);
+        if (st) return st;
+        launch_rank1_update(s, len, m, R, ur, coef);
+        piv.push_back(best);
+        ++r;
+    }
+    // min-norm solution x0 = U y with R' y = b(piv): forward substitution (Krylov.craig, :137)
+    std::vector<double> y(std::max<int64_t>(r, 1), 0.0);
+    for (int64_t k = 0; k < r; ++k) {
+        double s2 = b[piv[k]];
+        for (int64_t j = 0; j < k; ++j) s2 -= coeffs[piv[k]][j] * y[j];
+        y[k] = s2 / coeffs[piv[k]][k];
+    }
+    const double scale = round_scale(c, atol);
+    // C_L (:129-134): v1 = c;  C_L = symmetrize(round(c - U U'c))
+    launch_proj_coef(s, len, r, U, nullptr, 0, v1, partial, nblk, coef);
+    launch_proj_apply(s, len, r, U, nullptr, 0, v1, coef, atol, scale, 1, dCL, nullptr);
+    launch_symmetrize(s, n, n, dCL);
+    // X0_L (:137-142): x0 = U y -> symmetrize -> U U' x0 -> round
+    if (r > 0) {
+        st = h2d_sync(c, coef, y.data(), (size_t)r * 8);
+        if (st) return st;
+        launch_tall_times_small(s, len, len, U, (int)r, coef, (int)r, 1, 1.0, 0.0, v2, len);
+    } else {
+        HIP_TRY(c, hipMemsetAsync(v2, 0, (size_t)len * 8, s));
+    }
+    launch_symmetrize(s, n, n, v2);
+    launch_proj_coef(s, len, r, U, nullptr, 0, v2, partial, nblk, coef);
+    launch_proj_apply(s, len, r, U, nullptr, 0, v2, coef, 0, 1, 0, v1, nullptr);  // v1 = x0 - U U'x0
+    launch_sub_round(s, len, v2, v1, atol, scale, dX0);                           // X0_L = round(x0 - v1)
+    HIP_TRY(c, hipGetLastError());
+    // the loop, device-resident inputs
+    uint32_t* dP = (mem_out == SDPSR_MEM_DEVICE) ? P_out : (uint32_t*)ctx_buf(c, "adm_labels", (size_t)len * 4);
+    if (!dP) return SDPSR_OUT_OF_MEMORY;
+    st = sdpsr_admissible_subspace(c, n, dCL, dX0, U, r, atol, dP, dim_out, iters_out, phase_ms, SDPSR_MEM_DEVICE);
+    if (st && st != SDPSR_NOT_CONVERGED) return st;
+    const int st_loop = st;
+    st = out_finish(c, P_out, dP, len, mem_out);
+    return st ? st : st_loop;
+}
+
+}  // extern "C"

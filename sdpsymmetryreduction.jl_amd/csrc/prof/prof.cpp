@@ -1,0 +1,272 @@
+// libsdpsr_prof.so -- measurement entry points (include/sdpsr_prof.h), NOT part of the product
+// library: bench.py's roofline leg and the tools/ scripts time single kernels of libsdpsr_hip.so
+// through these.  Links against libsdpsr_hip.so (same ctx, same kernels).
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <functional>
+#include <numeric>
+
+#include "../host_internal.h"
+#include "../../../include/sdpsr_prof.h"
+
+using namespace sdpsr;
+
+namespace sdpsr {
+void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t* sig);
+void launch_clock_sampler(hipStream_t s, long long* buf, int ns, const unsigned* flag, long long max_ticks, int* count);
+void launch_wall_marker(hipStream_t s, long long* out);
+}
+
+extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t aux, int reps,
+                                    double* ms_per_launch) {
+    CHECK_CTX(c);
+    if (!ms_per_launch || n < 1 || reps < 1) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    hipStream_t s = c->stream;
+    const int64_t ld = round_up(n, 128);
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    int st = SDPSR_OK;
+    if (kind >= 0 && kind <= 2) {
+        const size_t es = kind == 0 ? 1 : (kind == 1 ? 4 : 8);
+        const size_t os = kind == 0 ? 4 : es;
+        // aux = batch (channels of one launch, as the product path launches them); operands of
+        // all channels are distinct memory
+        // aux >= 100: the lower-triangle launch of the product path (symmetric labels), batch aux - 100
+        const bool tri = aux >= 100 && kind <= 1;
+        if (tri) aux -= 100;
+        const int bt = (int)std::min<int64_t>(std::max<int64_t>(aux, 1), 8);
+        uint32_t* zflag = (uint32_t*)ctx_buf(c, "prof_zero", 64);
+        if (!zflag) return SDPSR_OUT_OF_MEMORY;
+        HIP_TRY(c, hipMemsetAsync(zflag, 0, 64, s));
+        void* X = ctx_buf(c, "prof_x", (size_t)ld * ld * es * bt);
+        void* Cc = ctx_buf(c, "prof_c", (size_t)ld * ld * os * bt);
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)ld * ld * 4);
+        if (!X || !Cc || !Lb) return SDPSR_OUT_OF_MEMORY;
+        // random symmetric operand with full-range values (not zeros: clocks differ on zeros)
+        HIP_TRY(c, hipMemsetAsync(Lb, 0, (size_t)ld * ld * 4, s));
+        launch_fill_test_sig(s, ld * ld / 2, 1 << 20, (uint64_t*)Lb);  // pseudo-random labels
+        for (int b = 0; b < bt; ++b) {
+            if (kind == 0) launch_gather_i8(s, ld, ld, 1, Lb, 12345 + b, (int8_t*)X + (size_t)b * ld * ld);
+            else if (kind == 1) launch_gather_f32(s, ld, ld, 1, 45, Lb, 12345 + b, (float*)X + (size_t)b * ld * ld);
+            else launch_gather_f64_padded(s, ld, ld, Lb, 12345 + b, (double*)X + (size_t)b * ld * ld);
+        }
+        const int64_t sb = ld * ld;
+        auto run = [&]() {
+            if (tri && kind == 0) launch_gemm_tn_i8_sym(s, ld, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, bt, sb, sb, zflag);
+            else if (tri && kind == 1) launch_gemm_tn_f32_sym(s, ld, ld, (float*)X, ld, (float*)Cc, ld, bt, sb, sb, zflag);
+            else if (kind == 0) launch_gemm_tn_i8(s, ld, ld, ld, (int8_t*)X, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, bt, sb, sb, sb);
+            else if (kind == 1) launch_gemm_tn_f32(s, ld, ld, ld, (float*)X, ld, (float*)X, ld, (float*)Cc, ld, bt, sb, sb, sb);
+            else launch_gemm_tn_f64(s, ld, ld, ld, (double*)X, ld, (double*)X, ld, (double*)Cc, ld, bt, sb, sb, sb);
+        };
+        run();
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) run();
+        HIP_TRY(c, hipEventRecord(e1, s));
+    } else if (kind == 3) {
+        const int64_t len = n * n;
+        uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)len * 4);
+        if (!sig || !Lb) return SDPSR_OUT_OF_MEMORY;
+        launch_fill_test_sig(s, len, std::max<int64_t>(aux, 1), sig);
+        int64_t np = 0;
+        st = refine_signatures(c, len, sig, Lb, &np);  // warm-up + table sizing
+        if (st) return st;
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) {
+            st = refine_signatures(c, len, sig, Lb, &np);
+            if (st) return st;
+        }
+        HIP_TRY(c, hipEventRecord(e1, s));
+    } else if (kind == 4) {
+        const int64_t len = n * n, r = std::max<int64_t>(aux, 0);
+        uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)len * 4);
+        double* U = (double*)ctx_buf(c, "prof_u", (size_t)len * std::max<int64_t>(r, 1) * 8);
+        double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)std::max<int64_t>(r, 1) * 2048 * 8);
+        double* coef = (double*)ctx_buf(c, "proj_coef", (size_t)std::max<int64_t>(r, 1) * 8);
+        if (!sig || !Lb || !U || !partial || !coef) return SDPSR_OUT_OF_MEMORY;
+        HIP_TRY(c, hipMemsetAsync(Lb, 0, (size_t)len * 4, s));
+        launch_fill_test_sig(s, len / 2, 1000, (uint64_t*)Lb);
+        HIP_TRY(c, hipMemsetAsync(U, 0, (size_t)len * std::max<int64_t>(r, 1) * 8, s));
+        auto run = [&]() {
+            launch_proj_coef(s, len, r, U, Lb, 777, nullptr, partial, 2048, coef);
+            launch_proj_apply(s, len, r, U, Lb, 777, nullptr, coef, 1.5e-8, 1e7, 1, nullptr, sig);
+        };
+        run();
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) run();
+        HIP_TRY(c, hipEventRecord(e1, s));
+    } else if (kind == 5 || kind == 6) {
+        // 5: the symv kernel of the tridiagonalisation alone, one launch per column j = 0..n-2
+        //    (ms_per_launch = total / (n-1));  6: the whole tridiagonalisation (ms per sytrd)
+        double* A = (double*)ctx_buf(c, "prof_x", (size_t)ld * ld * 8);
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)ld * ld * 4);
+        double* ws = (double*)ctx_buf(c, "eig_sytrd_ws", sytrd_workspace_doubles(n, ld) * 8);
+        double* dd = (double*)ctx_buf(c, "prof_d", (size_t)3 * n * 8);
+        if (!A || !Lb || !ws || !dd) return SDPSR_OUT_OF_MEMORY;
+        // symmetric pseudo-random matrix: labels symmetric in (i,j)
+        std::vector<uint32_t> hl((size_t)n * n);
+        for (int64_t j2 = 0; j2 < n; ++j2)
+            for (int64_t i2 = 0; i2 < n; ++i2) {
+                const int64_t lo = std::min(i2, j2), hi = std::max(i2, j2);
+                hl[(size_t)i2 + j2 * n] = (uint32_t)(sdpsr_fmix64((uint64_t)(lo * 1315423911ll + hi)) | 1u);
+            }
+        HIP_TRY(c, hipMemcpyAsync(Lb, hl.data(), (size_t)n * n * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const int runs = (kind == 5) ? 1 : reps;
+        launch_gather_f64_padded(s, n, ld, Lb, 999, A);
+        if (kind == 6) launch_sytrd(c, n, A, ld, dd, dd + n, dd + 2 * n, ws);  // warm-up
+        launch_gather_f64_padded(s, n, ld, Lb, 999, A);
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < runs; ++i) {
+            if (kind == 5) launch_sytrd_symv_sweep(s, n, A, ld, dd, dd + n, dd + 2 * n, ws);
+            else launch_sytrd(c, n, A, ld, dd, dd + n, dd + 2 * n, ws);
+        }
+        HIP_TRY(c, hipEventRecord(e1, s));
+        HIP_TRY(c, hipEventSynchronize(e1));
+        float ms5 = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms5, e0, e1));
+        ms_per_launch[0] = (kind == 5) ? (double)ms5 / (double)std::max<int64_t>(n - 1, 1) : (double)ms5 / runs;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        HIP_TRY(c, hipGetLastError());
+        return SDPSR_OK;
+    } else if (kind == 8) {
+        // one-workgroup Jacobi eigensolver (n <= 128) on a device-resident random symmetric matrix
+        if (n > 128) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "kind 8: n <= 128");
+        double* A = (double*)ctx_buf(c, "prof_x", (size_t)(reps + 1) * n * n * 8);
+        double* wv = (double*)ctx_buf(c, "prof_d", (size_t)n * 8 + 64);
+        double* Vt = (double*)ctx_buf(c, "prof_c", (size_t)n * n * 8);
+        int* info = (int*)ctx_buf(c, "eig_info", 64);
+        if (!A || !wv || !Vt || !info) return SDPSR_OUT_OF_MEMORY;
+        std::vector<double> h((size_t)(reps + 1) * n * n);
+        for (int rp = 0; rp <= reps; ++rp)
+            for (int64_t j2 = 0; j2 < n; ++j2)
+                for (int64_t i2 = 0; i2 <= j2; ++i2) {
+                    const double v = (double)(sdpsr_fmix64((uint64_t)(rp * 7919 + i2 * 131 + j2 * 1000003)) >> 11) * (1.0 / 9007199254740992.0);
+                    h[(size_t)rp * n * n + i2 + j2 * n] = h[(size_t)rp * n * n + j2 + i2 * n] = v;
+                }
+        HIP_TRY(c, hipMemcpyAsync(A, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        launch_small_syev(s, n, A + (size_t)reps * n * n, n, wv, Vt, info);  // warm-up
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) launch_small_syev(s, n, A + (size_t)i * n * n, n, wv, Vt, info);
+        HIP_TRY(c, hipEventRecord(e1, s));
+    } else if (kind == 9) {
+        // label product Y = A(v) W of the module-compression driver: aux = w | G << 8 | d << 12 (| 1 << 30:
+        // report the largest deviation from a host evaluation of sampled rows instead of the time)
+        const int w = (int)(aux & 0xff), G = ((aux >> 8) & 0xf) ? (int)((aux >> 8) & 0xf) : 1;
+        const int64_t d = ((aux >> 12) & 0xffff) ? ((aux >> 12) & 0xffff) : 34;
+        const bool verify = (aux >> 30) & 1;
+        if (w < 1 || G * w > 64) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "kind 9: 1 <= G w <= 64");
+        uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)n * n * 4);
+        double* W = (double*)ctx_buf(c, "prof_x", (size_t)n * w * 8);
+        double* Y = (double*)ctx_buf(c, "prof_c", (size_t)n * G * w * 8);
+        double* part = (double*)ctx_buf(c, "cm_part", label_spmm_partial_doubles(n, 64) * 8);
+        if (!Lb || !W || !Y || !part) return SDPSR_OUT_OF_MEMORY;
+        std::vector<uint32_t> hl((size_t)n * n);
+        std::vector<double> hw((size_t)n * w);
+        for (size_t e = 0; e < hl.size(); ++e) hl[e] = (uint32_t)(sdpsr_fmix64(e * 2654435761ull + 17) % (uint64_t)(d + 1));
+        for (size_t e = 0; e < hw.size(); ++e) hw[e] = 2.0 * ((double)(sdpsr_fmix64(e + 99991) >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+        const uint64_t keys[4] = {0x1234567ull, 0x89abcdefull, 0x13579bdfull, 0x2468aceull};
+        HIP_TRY(c, hipMemcpyAsync(Lb, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(W, hw.data(), hw.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (!launch_label_spmm_multi(s, n, Lb, keys, G, d, W, n, w, part, Y, n))
+            return ctx_fail(c, SDPSR_BAD_ARGUMENT, "kind 9: shape not supported by the label product");
+        HIP_TRY(c, hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) launch_label_spmm_multi(s, n, Lb, keys, G, d, W, n, w, part, Y, n);
+        HIP_TRY(c, hipEventRecord(e1, s));
+        if (verify) {
+            std::vector<double> hy((size_t)n * G * w);
+            HIP_TRY(c, hipMemcpyAsync(hy.data(), Y, hy.size() * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            double worst = 0;
+            const int64_t rows[12] = {0, 1, 15, 16, 17, 63, 64, n / 3, n / 2, n - 17, n - 2, n - 1};
+            for (int64_t r : rows) {
+                if (r < 0 || r >= n) continue;
+                for (int g = 0; g < G; ++g)
+                    for (int j = 0; j < w; ++j) {
+                        long double acc = 0;
+                        for (int64_t cc = 0; cc < n; ++cc) {
+                            const uint32_t lab = hl[(size_t)r + (size_t)cc * n];
+                            if (lab) acc += (long double)sdpsr_class_uniform(keys[g], lab) * hw[(size_t)cc + (size_t)j * n];
+                        }
+                        worst = std::max(worst, std::fabs((double)acc - hy[(size_t)r + (size_t)(g * w + j) * n]));
+                    }
+            }
+            ms_per_launch[0] = worst;
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+            return SDPSR_OK;
+        }
+    } else {
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "unknown kernel kind");
+    }
+    HIP_TRY(c, hipEventSynchronize(e1));
+    HIP_TRY(c, hipGetLastError());
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    ms_per_launch[0] = (double)ms / reps;
+    if (kind == 8 && aux == 1) {  // diagnostic: sweeps of the last run instead of the time
+        int h[2] = {0, 0};
+        HIP_TRY(c, hipMemcpy(h, ctx_buf(c, "eig_info", 64), 8, hipMemcpyDeviceToHost));
+        ms_per_launch[0] = (double)h[1];
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return SDPSR_OK;
+}
+
+// Diagnostic: sdpsr_profile_kernel(kind, n, aux, reps) with the shader clock sampled meanwhile.
+// out[0] = ms per launch, out[1] = median shader clock (MHz) over the ~20 us intervals of the run,
+// out[2] = number of intervals used.
+extern "C" int sdpsr_profile_clock(sdpsr_ctx* c, int kind, int64_t n, int64_t aux, int reps, double* out) {
+    CHECK_CTX(c);
+    if (!out) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    double ms = 0;
+    int st = sdpsr_profile_kernel(c, kind, n, aux, 1, &ms);  // buffers, tables, clocks: warm
+    if (st) return st;
+    const int NS = 8192;
+    long long* buf = (long long*)ctx_buf(c, "clk_buf", (size_t)(2 * NS + 8) * 8);
+    unsigned* flag = (unsigned*)ctx_buf(c, "clk_flag", 64);
+    if (!buf || !flag) return SDPSR_OUT_OF_MEMORY;
+    long long* marks = buf + 2 * NS;
+    int* count = (int*)(flag + 8);
+    hipStream_t side = nullptr;
+    HIP_TRY(c, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    HIP_TRY(c, hipMemsetAsync(flag, 0, 64, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    launch_clock_sampler(side, buf, NS, flag, 200000000ll /* 2 s */, count);
+    launch_wall_marker(c->stream, marks);
+    st = sdpsr_profile_kernel(c, kind, n, aux, reps, &ms);
+    launch_wall_marker(c->stream, marks + 1);
+    hipMemsetAsync(flag, 1, 4, c->stream);  // releases the sampler whatever happened above
+    hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(side);
+    hipStreamDestroy(side);
+    if (st) return st;
+    std::vector<long long> h((size_t)2 * NS + 8);
+    int hc = 0;
+    HIP_TRY(c, hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&hc, count, 4, hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    // the timed launches are the tail of the marked window (set-up and warm-up come first): use its second half
+    const long long t0 = h[2 * NS] + (h[2 * NS + 1] - h[2 * NS]) / 2, t1 = h[2 * NS + 1];
+    for (int i = 1; i < hc; ++i) {
+        const long long w0 = h[2 * (i - 1) + 1], w1 = h[2 * i + 1];
+        if (w0 >= t0 && w1 <= t1 && w1 > w0) mhz.push_back((double)(h[2 * i] - h[2 * (i - 1)]) / (double)(w1 - w0) * 100.0);
+    }
+    std::sort(mhz.begin(), mhz.end());
+    out[0] = ms;
+    out[1] = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+    out[2] = (double)mhz.size();
+    return SDPSR_OK;
+}
+

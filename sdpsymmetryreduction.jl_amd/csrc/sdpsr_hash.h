@@ -52,19 +52,26 @@ SDPSR_HD uint64_t sdpsr_sig_start(uint32_t label) {
     return 0x51ED270B0F3A4C27ULL + (uint64_t)label * 0xC2B2AE3D27D4EB4FULL;
 }
 
-// round-to-nearest restatement of _clamp_round!/unsafe_round (src/utils.jl:34-53):
-// |a| < atol -> +0.0; else mantissa in [0.5,1) kept to `scale` = 10^sigdigits steps.
+// _clamp_round! / unsafe_round (src/utils.jl:34-53): |a| < atol -> +0.0; else the mantissa in
+// [0.5,1) is kept to |scale| = 10^sigdigits steps.  The sign of `scale` carries the rounding rule
+// (one wave-uniform select, no extra kernel argument anywhere): scale > 0 rounds the scaled mantissa
+// to nearest (the library's default, see sdpsr.h at sdpsr_clamp_round), scale < 0 truncates it like
+// the reference's unsafe_trunc(Int, scale * x) / scale (sdpsr_opts.round_mode = SDPSR_ROUND_TRUNC).
 SDPSR_HD double sdpsr_clamp_round(double a, double atol, double scale) {
     double aa = a < 0 ? -a : a;
     if (aa < atol) return 0.0;
+    const bool trunc_mode = scale < 0;
+    const double sc = trunc_mode ? -scale : scale;
     int e;
 #if defined(__HIP_DEVICE_COMPILE__)
     double x = frexp(a, &e);
-    double y = rint(scale * x) / scale;
+    const double t = sc * x;
+    double y = (trunc_mode ? trunc(t) : rint(t)) / sc;
     return ldexp(y, e);
 #else
     double x = __builtin_frexp(a, &e);
-    double y = __builtin_rint(scale * x) / scale;
+    const double t = sc * x;
+    double y = (trunc_mode ? __builtin_trunc(t) : __builtin_rint(t)) / sc;
     return __builtin_ldexp(y, e);
 #endif
 }

@@ -35,6 +35,7 @@ struct sdpsr_ctx {
     hipStream_t main_shadow = nullptr;  // the main stream while `stream` temporarily points at side_stream
     bool own_stream = false;
     std::string err;
+    double dbg_last_ms = 0;  // SDPSR_DEBUG traces: time of the previous mark
     std::map<std::string, DevBuf> bufs;
     void* pinned = nullptr;  // small pinned host scratch for scalar read-backs
     size_t pinned_bytes = 0;
@@ -56,6 +57,7 @@ struct sdpsr_ctx {
     const uint32_t* bd_sym_labels = nullptr;
     uint32_t epoch_counter = 0;
     int hint_symmetric_basis = 0;         // sdpsr_hint_symmetric_basis: applies to the next admissible_subspace call
+    std::vector<int64_t> adm_dims;        // dimension trajectory of the last admissible_subspace call (sdpsr_dimension_trajectory)
     bool bd_q_valid = false;  // "bd_qhat" holds Q_hat of the last diagonalize (even when check_block_sizes failed)
     bool bd_labels_owned = false;
     // hash table capacity hint (log2) for the next refine
@@ -125,6 +127,7 @@ void launch_sig_f64_rounded(hipStream_t s, int64_t n, int64_t ld, const uint32_t
                             const double* v, double atol, double scale, uint64_t* sig);
 void launch_sig_u32(hipStream_t s, int64_t len, const uint32_t* L, const uint32_t* k,
                     uint64_t* sig);
+void launch_sig_u64(hipStream_t s, int64_t len, const uint64_t* k, uint64_t* sig);
 // T channels of int32 / f32 squares, padded ld, C[t] at C + t*ld*ld
 void launch_sig_i32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t* L,
                     const int32_t* C, uint64_t* sig, const uint32_t* nonsym_flag = nullptr, int packed = 0, int lab_packed = 0);
@@ -178,6 +181,7 @@ size_t refine_sorted_workspace_bytes(int64_t len);
 bool launch_refine_sorted(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
                           uint32_t* counters);
 
+void launch_max_pair_code(hipStream_t s, int64_t len, const uint32_t* p1, const uint32_t* p2, uint64_t d1, uint64_t* out);
 void launch_transpose_labels(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* Lt);
 void launch_labels_checksum(hipStream_t s, int64_t len, const uint32_t* L, uint64_t* partial, uint64_t* out);
 int64_t reduce_columns_chunk(int64_t len, int64_t m, int64_t d);
@@ -240,8 +244,6 @@ void launch_copy_check_symmetric(hipStream_t s, int64_t n, const uint32_t* src, 
 // Operands must be padded: k multiple of KT, m and n multiples of 128, pointers 16-B
 // aligned, lda/ldb multiples of 16 bytes.
 // ---------------------------------------------------------------------------
-void launch_clock_sampler(hipStream_t s, long long* buf, int ns, const unsigned* flag, long long max_ticks, int* count);
-void launch_wall_marker(hipStream_t s, long long* out);
 void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc,
                            int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag);
 void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X, int64_t ldx, float* C, int64_t ldc,

@@ -43,6 +43,8 @@ def checksums_agree(words, group=None, device=None):
     """All-gather two 64-bit words per rank; True iff every rank holds the same pair."""
     import torch
     import torch.distributed as dist
+    if device is not None and torch.device(device).type != "cpu" and dist.get_backend(group) == "gloo":
+        device = None  # gloo has no all_gather for device tensors (the CPU-backend test hook of bench.py): 16 bytes via the host
     mine = torch.tensor([_signed(words[0]), _signed(words[1])], dtype=torch.int64, device=device)
     world = dist.get_world_size(group)
     got = [torch.empty_like(mine) for _ in range(world)]

@@ -12,8 +12,35 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 25
     for s in names:
         assert hasattr(lib, s), s
-    assert lib.sdpsr_version() == 2
+    assert lib.sdpsr_version() == 3
     assert lib.sdpsr_status_string(3) == b"DIMENSION_MISMATCH"
+    # the product library exports the reference-facing ABI only: the measurement entry points live in
+    # libsdpsr_prof.so (include/sdpsr_prof.h)
+    assert not any(n.startswith("sdpsr_profile") for n in names)
+    assert not hasattr(lib, "sdpsr_profile_kernel") and not hasattr(lib, "sdpsr_profile_clock")
+
+
+def test_prof_library_is_separate_and_loads(pkg):
+    prof = pkg._lib.load_prof_library()
+    for s in pkg._lib.declared_symbols(pkg._lib.PROF_HEADER_PATH):
+        assert hasattr(prof, s), s
+    assert hasattr(prof, "sdpsr_profile_kernel") and hasattr(prof, "sdpsr_profile_clock")
+
+
+def test_opts_struct_layout(pkg):
+    """sdpsr_opts kept its size when ABI 0.3 named five of the reserved words (a 0.2 caller's zeroed
+    reserved[] selects the defaults)."""
+    L = pkg._lib
+    assert C.sizeof(L.Opts) == 64
+    assert L.Opts.flags.offset == 24 and L.Opts.round_mode.offset == 28 and L.Opts.label_bits.offset == 40
+    hdr = open(L.HEADER_PATH).read()
+    for name, val in (("SEPARATE_REFINEMENTS", L.FLAG_SEPARATE_REFINEMENTS), ("FRESH_IRREDUCIBLE_ELEMENT", L.FLAG_FRESH_IRREDUCIBLE_ELEMENT),
+                      ("ALWAYS_REORTHOGONALIZE", L.FLAG_ALWAYS_REORTHOGONALIZE), ("REFINE_NO_FUSE", L.FLAG_REFINE_NO_FUSE),
+                      ("UNPACK_EVERY_STEP", L.FLAG_UNPACK_EVERY_STEP), ("SPMM_ONE_BY_ONE", L.FLAG_SPMM_ONE_BY_ONE),
+                      ("SINGLE_COUPLING_ELEMENT", L.FLAG_SINGLE_COUPLING_ELEMENT), ("SMALL_EIGEN_ON_DEVICE", L.FLAG_SMALL_EIGEN_ON_DEVICE),
+                      ("NO_GRAPH", L.FLAG_NO_GRAPH)):
+        m = re.search(r"SDPSR_FLAG_%s = 1u << (\d+)" % name, hdr)
+        assert m and (1 << int(m.group(1))) == val, name
 
 
 def test_header_cites_reference_lines(pkg):
@@ -44,7 +71,9 @@ def test_hash_header_compiles_for_host_and_matches_python():
     #include "sdpsr_hash.h"
     int main(){ unsigned long long k = sdpsr_stream_key(42, 3);
       printf("%llu %llu %.17g %d %.17g\n", k, sdpsr_class_bits(k, 7), sdpsr_class_uniform(k, 7),
-             sdpsr_class_i8(sdpsr_class_bits(k, 7), 2), sdpsr_clamp_round(0.0625*(1-2e-16), 1.4901161193847656e-8, 1e7)); return 0; }
+             sdpsr_class_i8(sdpsr_class_bits(k, 7), 2), sdpsr_clamp_round(0.0625*(1-2e-16), 1.4901161193847656e-8, 1e7));
+      printf("%.17g %.17g %.17g\n", sdpsr_clamp_round(0.0625*(1-2e-16), 1.4901161193847656e-8, -1e7),
+             sdpsr_clamp_round(0.7654321987, 1.4901161193847656e-8, 1e7), sdpsr_clamp_round(0.7654321987, 1.4901161193847656e-8, -1e7)); return 0; }
     '''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.cpp"), "w").write(src)
@@ -65,6 +94,17 @@ def test_hash_header_compiles_for_host_and_matches_python():
     b2 = (bits >> 16) & 0xFF
     assert int(out[3]) == (b2 - 256 if b2 >= 128 else b2)
     assert float(out[4]) == 0.0625
+    # negative scale = the reference's truncation (unsafe_round, src/utils.jl:49-53), same helper on host and device
+    import math
+
+    def ref_round(f, trunc):
+        x, e = math.frexp(f)
+        y = (math.trunc(1e7 * x) if trunc else round(1e7 * x)) / 1e7
+        return math.ldexp(y, e)
+
+    assert float(out[5]) == ref_round(0.0625 * (1 - 2e-16), True) < 0.0625
+    assert float(out[6]) == ref_round(0.7654321987, False) and float(out[7]) == ref_round(0.7654321987, True)
+    assert float(out[6]) != float(out[7])
 
 
 def test_product_path_never_touches_the_oracle():
@@ -118,9 +158,14 @@ def test_no_process_global_state_in_the_library():
         if not f.endswith((".hip", ".cpp", ".h")):
             continue
         txt = open(os.path.join(src, f)).read()
-        for pat in (r"static\s+bool\s+\w*attr", r"\bstd::mutex\b", r"^\s*static\s+\w[\w:<>]*\s+g_\w+", r"\bg_sytrd_"):
+        for pat in (r"static\s+bool\s+\w*attr", r"\bstd::mutex\b", r"^\s*static\s+\w[\w:<>]*\s+g_\w+", r"\bg_sytrd_",
+                    r"static[^;\n]*getenv"):  # no cached environment reads: behaviour comes from sdpsr_opts
             if re.search(pat, txt, flags=re.M):
                 bad.append((f, pat))
+        # the only environment variable the library may read is SDPSR_DEBUG (stderr traces)
+        for m in re.finditer(r'getenv\("(\w+)"\)', txt):
+            if m.group(1) != "SDPSR_DEBUG":
+                bad.append((f, m.group(0)))
         # every hipFuncSetAttribute sits in a *_set_device_attributes function
         for m in re.finditer(r"hipFuncSetAttribute", txt):
             head = txt[:m.start()]

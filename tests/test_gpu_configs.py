@@ -205,3 +205,141 @@ def test_bench_instances_n4096(pkg, problems, oracle, golden, name):
     full, blk = oracle.spectrum_invariant(oracle.Partition(d, L), bd.blks, x)
     assert len(full) == len(blk), (name, len(full), len(blk))
     assert np.allclose(full, blk, rtol=1e-6, atol=1e-8 * np.abs(full).max())
+
+
+def _device_resident_block_diagonalize(pkg, ctx, L, d, epsilon, nsample=6, seed=3):
+    """blockDiagonalize with labels, images and Q_hat left on the device (the 12 GB of images of configs[2] never
+    cross PCIe); checks that need no oracle run: check_block_sizes, orthonormal Q_hat, blks == Q_k' 1[P==i] Q_k on
+    sampled classes with host products, and the spectrum invariant of SURVEY 8c with the block side summed on the
+    device and the full n x n spectrum from an independent solver (LAPACK, or torch's on the GPU for n >= 4096)."""
+    import ctypes as C
+    import torch
+    Lm = pkg._lib
+    n = L.shape[0]
+    dev = torch.device("cuda:0")
+    tP = torch.from_numpy(np.ascontiguousarray(L.ravel(order="F")).astype(np.int32)).to(dev)
+    nb, ssq, ss = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+    lib = ctx._lib
+    for attempt in range(4):  # the reference's answer to its randomized failures is "try again"
+        st = lib.sdpsr_block_diagonalize(ctx._h, n, C.c_void_p(tP.data_ptr()), d, float(epsilon), C.byref(nb), C.byref(ssq),
+                                         C.byref(ss), None, Lm.MEM_DEVICE)
+        if st not in (2, 3):
+            break
+    ctx.check(st)
+    sizes = np.zeros(nb.value, dtype=np.int32)
+    ctx.check(lib.sdpsr_block_sizes(ctx._h, sizes.ctypes.data_as(C.c_void_p)))
+    S, S1 = int(ssq.value), int(ss.value)
+    assert sum(int(s) * (int(s) + 1) // 2 for s in sizes) == d and sum(int(s) ** 2 for s in sizes) == S
+    buf = torch.empty(d * S, dtype=torch.float64, device=dev)
+    qh = torch.empty(n * S1, dtype=torch.float64, device=dev)
+    ctx.check(lib.sdpsr_block_images(ctx._h, C.c_void_p(buf.data_ptr()), C.c_void_p(qh.data_ptr()), None, Lm.MEM_DEVICE))
+    Q = qh.cpu().numpy().reshape(n, S1, order="F")
+    cols = np.concatenate([[0], np.cumsum(sizes)])
+    offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64) ** 2)])
+    for k in range(len(sizes)):
+        q = Q[:, cols[k]:cols[k + 1]]
+        assert np.abs(q.T @ q - np.eye(q.shape[1])).max() < 1e-7, k
+    blks = buf.view(d, S)
+    for i in sorted(set(np.linspace(1, d, nsample).astype(int))):
+        R, Cc = np.nonzero(L == i)
+        row = blks[i - 1].cpu().numpy()
+        for k in range(len(sizes)):
+            q = Q[:, cols[k]:cols[k + 1]]
+            ref = q[R].T @ q[Cc]  # Q_k' 1[P==i] Q_k = sum over the entries (r, c) of class i of Q_k[r,:]' Q_k[c,:]
+            ref[np.abs(ref) < 1e-12 * n] = 0.0
+            got = row[offs[k]:offs[k + 1]].reshape(sizes[k], sizes[k], order="F")
+            assert np.allclose(got, ref, atol=1e-9), (i, k, np.abs(got - ref).max())
+    x = np.random.default_rng(seed).random(d)
+    xb = (torch.from_numpy(x).to(dev) @ blks).cpu().numpy()  # sum_i x_i blks[i][:] on the device
+    blk_vals = []
+    for k in range(len(sizes)):
+        B = xb[offs[k]:offs[k + 1]].reshape(sizes[k], sizes[k], order="F")
+        blk_vals.append(np.linalg.eigvalsh((B + B.T) / 2))
+    blk_vals = np.sort(np.concatenate(blk_vals))
+    tA = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), torch.from_numpy(x).to(dev)])[tP.to(torch.int64)].view(n, n)
+    if n >= 4096:
+        full = torch.linalg.eigvalsh((tA + tA.T) / 2).cpu().numpy()
+    else:
+        A = tA.cpu().numpy()
+        full = np.linalg.eigvalsh((A + A.T) / 2)
+
+    def distinct(v, tol=1e-7):
+        v = np.sort(v)
+        scale = max(1.0, np.abs(v).max())
+        keep = [v[0]]
+        for t in v[1:]:
+            if abs(t - keep[-1]) > tol * scale:
+                keep.append(t)
+        return np.array(keep)
+
+    fd, bdv = distinct(full), distinct(blk_vals)
+    assert len(fd) == len(bdv), (len(fd), len(bdv))
+    assert np.allclose(fd, bdv, rtol=1e-6, atol=1e-8 * np.abs(fd).max())
+    return [int(s) for s in sizes]
+
+
+def test_config2_qap_grid30_block_diagonalize_full_size(pkg, problems):
+    """configs[2] at full size THROUGH blockDiagonalize: the N = 900 QAP-type partition (dim 27 828, blocks 36 ... 81,
+    12 GB of block images written by basis_image_outer_mfma_kernel) -- block sizes consistent with dim(P), orthonormal
+    Q_hat, blks == Q_k' 1[P==i] Q_k on sampled classes, spectrum invariant.  Dense driver (dim(P) >> n)."""
+    flow, dist = problems.grid_qap_instance(5, 6, seed=4)
+    Cv, A, b = problems.qap_problem(flow, dist)
+    setup = pkg.admissible_setup(Cv, A, b)
+    with pkg.Context(seed=1) as ctx:
+        P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)
+        L = np.asarray(P.matrix).astype(np.int64)
+        assert P.nparts > 20000 and L.shape == (900, 900) and np.array_equal(L, L.T)
+        sizes = _device_resident_block_diagonalize(pkg, ctx, L, P.nparts, 1e-8, nsample=8)
+    assert max(sizes) >= 36 and sum(sizes) <= 900
+
+
+def test_config4_n8192_block_diagonalize_full_size(pkg, problems):
+    """configs[4] through blockDiagonalize at N = 8192: all blocks of size 1 (commutative scheme), blks against host
+    products on sampled classes, spectrum invariant with the full 8192 x 8192 spectrum from torch's solver."""
+    n = 8192
+    L, d = problems.synthetic_jordan_partition(n, seed=8)
+    with pkg.Context(seed=78) as ctx:
+        sizes = _device_resident_block_diagonalize(pkg, ctx, L, d, pkg.api.RTOL_DEFAULT, nsample=6)
+    assert sizes == [1] * d
+
+
+# ------------------------------------------------ bench.py --gpus N: the launcher and the agreement step on device tensors
+def _run_bench(extra_env, *flags):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    # one GPU on the box: both ranks on cuda:0, gloo instead of RCCL (which refuses two ranks on one device)
+    env.update({"SDPSR_BENCH_SAME_DEVICE": "1", "SDPSR_BENCH_BACKEND": "gloo"})
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+                          "--skip-roofline", "--n", "1024", *flags], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` (the shape of the driver's command, no launcher, no WORLD_SIZE) must start two ranks
+    itself and report n_gpus = 2 -- not one rank with n_gpus = 1."""
+    js = _run_bench({})
+    assert js["n_gpus"] == 2 and js["value"] > 0 and js["scaling"] == "weak"
+    assert js["config"]["restarts_per_step"] == 2
+    assert js["partition_meets"] == {"warmup": 0, "timed": 0, "note": js["partition_meets"]["note"]}
+
+
+@pytest.mark.gpu
+def test_bench_forced_disagreement_reaches_the_hash_meet():
+    """Rank 1 reports a coarser partition in the warm-up steps: checksums differ, MIN/MAX all-reduce on the device
+    label tensors, SUM all-reduce of the hashed labels, canonical relabel on the device (sdpsr_partition_from_u64);
+    bench.py asserts after every warm-up step that the agreed partition is the generator's closure again."""
+    js = _run_bench({"SDPSR_BENCH_FORCE_DISAGREE": "1"}, "--workload", "theta_c32xk128")
+    assert js["n_gpus"] == 2 and js["value"] > 0
+    assert js["partition_meets"]["warmup"] == 2 and js["partition_meets"]["timed"] == 0

@@ -502,15 +502,14 @@ def test_partition_checksum_matches_restatement(pkg, gpu_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["two_stage", "outer", "chunk"])
 @pytest.mark.parametrize("name", ["er7", "esc16j", "numerical_issues"])
-def test_basis_image_kernel_variants(pkg, oracle, golden, name, variant, monkeypatch):
+def test_basis_image_kernel_variants(pkg, oracle, golden, name, variant):
     """The three basis_image kernels (class sums + contraction; outer products per class for many
     small classes; sorted chunks with partial sums) against Q_k' 1[P==i] Q_k (src/diagonalize.jl:64-89).
     The automatic choice only reaches the last two for shapes far beyond these sizes."""
-    monkeypatch.setenv("SDPSR_BASIS_IMAGE", variant)
     L = golden[f"{name}_P"]
     P = pkg.Partition(int(L.max()), L.copy())
     kw = {"epsilon": 1e-7} if name == "numerical_issues" else {}
-    with pkg.Context(seed=4) as ctx:
+    with pkg.Context(seed=4, basis_image_kernel=variant) as ctx:  # sdpsr_opts.basis_image_kernel
         bd = pkg.blockDiagonalize(P, ctx=ctx, **kw)
     assert sorted(bd.blkSizes) == list(golden[f"{name}_blk"])
     Po = oracle.Partition(P.nparts, L.astype(np.int64))
@@ -690,7 +689,7 @@ def test_device_inputs_from_an_async_torch_kernel(pkg, problems, golden):
             del junk
 
 
-def test_sort_based_refine_matches_oracle(pkg, oracle, monkeypatch):
+def test_sort_based_refine_matches_oracle(pkg, oracle):
     """Radix-sort relabel (many-classes regime, kernels_refine_sort.hip) against the oracle's
     canonical labels: forced on inputs with few, many and all-distinct classes, a zero class,
     and through refine! (pairs of labels)."""
@@ -704,11 +703,7 @@ def test_sort_based_refine_matches_oracle(pkg, oracle, monkeypatch):
     }
     cases["many"][rng.random((n, n)) < 0.1] = 0.0
     for forced in (True, False):
-        if forced:
-            monkeypatch.setenv("SDPSR_REFINE_FORCE_SORT", "1")
-        else:
-            monkeypatch.delenv("SDPSR_REFINE_FORCE_SORT", raising=False)
-        with pkg.Context(seed=2) as ctx:
+        with pkg.Context(seed=2, refine_path="sort" if forced else "auto") as ctx:  # sdpsr_opts.refine_path
             for name, M in cases.items():
                 P = pkg.Partition.from_matrix(M, ctx=ctx)
                 R = oracle.partition_from_values(M)
@@ -866,5 +861,230 @@ def test_label_product_on_the_matrix_cores(pkg, gpu_ctx, n, w, G, d):
     import ctypes as C
     v = C.c_double(0)
     aux = w | (G << 8) | (d << 12) | (1 << 30)
-    gpu_ctx.check(gpu_ctx._lib.sdpsr_profile_kernel(gpu_ctx._h, 9, n, aux, 1, C.byref(v)))
+    prof = pkg._lib.load_prof_library()  # measurement entry points live in libsdpsr_prof.so
+    gpu_ctx.check(prof.sdpsr_profile_kernel(gpu_ctx._h, 9, n, aux, 1, C.byref(v)))
     assert v.value < 1e-11 * n, v.value   # |A| <= 1, |W| <= 1: sums of n products
+
+
+# ------------------------------------------------ ABI 0.3: sdpsr_opts switches (round mode, label width, flags), trajectory
+def test_clamp_round_trunc_mode_is_the_reference_rule(pkg, oracle):
+    """sdpsr_opts.round_mode = SDPSR_ROUND_TRUNC: unsafe_round as written (unsafe_trunc(Int, scale * x) / scale,
+    src/utils.jl:49-53), bit for bit against the oracle's literal restatement; the default stays round-to-nearest."""
+    lib = pkg.load_library()
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.integers(-12, 6, 20000), [0.0625, 0.0625 * (1 - 2e-16), 1e-10, -1e-9, 0.0, -0.0]])
+    with pkg.Context(seed=1, round_mode="trunc") as ctx:
+        got = a.copy()
+        ctx.check(lib.sdpsr_clamp_round(ctx._h, got.size, C.c_void_p(got.ctypes.data), 1.4901161193847656e-8, 0))
+    ref = oracle.clamp_round(a, round_mode="trunc")
+    assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref))
+    near = oracle.clamp_round(a, round_mode="nearest")
+    assert 0.3 < np.mean(got != near) < 0.7  # the two rules differ in the 7th digit of about every second input
+    with pytest.raises(pkg.SdpsrError):
+        pkg.Context(round_mode=7)
+
+
+@pytest.mark.parametrize("name,q", [("er3", 3), ("er5", 5), ("er7", 7)])
+def test_reference_literal_loop_with_truncation(pkg, problems, oracle, golden, name, q):
+    """The whole loop in the reference's own arithmetic: fp64 square, two refinements per iteration, TRUNCATED 7-digit
+    mantissas in the setup stage (device), the projection step and the square (src/partitions.jl:117-185,
+    src/utils.jl:34-53).  Golden partition, and the dimension after every iteration equal to the oracle's trace in
+    the same mode."""
+    Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(q))
+    trace = []
+    ref = oracle.admissible_subspace(Cv, A, b, rng=np.random.default_rng(0), round_mode="trunc", trace=trace)
+    assert np.array_equal(ref.matrix, golden[f"{name}_P"])
+    for seed in (1, 2, 3):
+        with pkg.Context(seed=seed, square_mode=pkg.SQUARE_F64, round_mode="trunc", flags=pkg._lib.FLAG_SEPARATE_REFINEMENTS) as ctx:
+            P = pkg.admissible_subspace(Cv, A, b, ctx=ctx)  # device setup: rounds with the ctx's rule
+            assert P.nparts == ref.nparts and np.array_equal(P.matrix, golden[f"{name}_P"]), (name, seed)
+            assert P.dims[1:] == trace and P.iterations == ref.iterations, (P.dims, trace)
+            assert ctx.dimension_trajectory() == P.dims
+
+
+@pytest.mark.parametrize("name", ["petersen", "er3", "er5", "er7", "esc16j"])
+def test_dimension_trajectory_default_mode(pkg, problems, oracle, golden, name):
+    """sdpsr_dimension_trajectory (src/partitions.jl:150,156,187-188 under verbose): the default loop (int8 squares,
+    2 channels + confirm round, one joint refinement per iteration) walks through the same dimensions as the oracle."""
+    Cv, A, b = _problem(problems, name)
+    setup = pkg.admissible_setup(Cv, A, b)
+    n, CL, X0L, U = setup
+    trace = []
+    ref = oracle.admissible_subspace(Cv, A, b, rng=np.random.default_rng(0), trace=trace,
+                                     setup=(n, U, CL.reshape(n, n, order="F"), X0L.reshape(n, n, order="F")))
+    with pkg.Context(seed=11) as ctx:
+        P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)
+        dims = ctx.dimension_trajectory()
+    assert np.array_equal(P.matrix, golden[f"{name}_P"])
+    assert len(dims) == P.iterations + 1 and dims[-1] == P.nparts
+    assert all(x <= y for x, y in zip(dims, dims[1:]))
+    assert dims[1:] == trace, (name, dims, trace)
+    cnt = C.c_int32(0)  # capacity smaller than the trajectory: count still reported, no overrun
+    two = np.full(3, -1, dtype=np.int64)
+    ctx2 = pkg.Context(seed=12)
+    pkg.admissible_subspace(Cv, A, b, ctx=ctx2, setup=setup)
+    ctx2.check(ctx2._lib.sdpsr_dimension_trajectory(ctx2._h, two.ctypes.data_as(C.c_void_p), 2, C.byref(cnt)))
+    assert cnt.value == len(dims) and list(two[:2]) == dims[:2] and two[2] == -1
+    ctx2.close()
+
+
+@pytest.mark.parametrize("channels,confirm", [(0, 0), (2, 1), (4, 0), (1, 3), (8, 0)])
+def test_channel_counts_and_confirm_rounds(pkg, problems, golden, channels, confirm):
+    """channels = 0 is the default pair (2 channels + 1 confirm round); every explicit choice must end on the same
+    canonical matrix with the same iteration count (a confirm round is not an iteration)."""
+    for name, iters in (("er5", 4), ("esc16j", 3)):
+        Cv, A, b = _problem(problems, name)
+        setup = pkg.admissible_setup(Cv, A, b)
+        for seed in (5, 6):
+            with pkg.Context(seed=seed, channels=channels, confirm_rounds=confirm) as ctx:
+                P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)
+            assert np.array_equal(P.matrix, golden[f"{name}_P"]), (name, channels, confirm, seed)
+            assert P.iterations == iters
+
+
+def test_label_overflow_like_the_reference(pkg, oracle, problems):
+    """sdpsr_opts.label_bits: InexactError of Partition{T} (src/partitions.jl:29,63) as SDPSR_LABEL_OVERFLOW.  refine!
+    decides on the largest pair code l1 + l2 (dim(P1) + 1), exactly like the reference (and the oracle's label_bits)."""
+    rng = np.random.default_rng(4)
+    n = 40
+    A = rng.integers(0, 400, size=(n, n))
+    B = rng.integers(0, 300, size=(n, n))  # pair codes up to ~300 * 401: beyond UInt16, within UInt32
+    for bits, expect in ((8, True), (16, True), (32, False), (0, False)):
+        with pkg.Context(seed=1, label_bits=bits) as ctx:
+            if bits == 8:  # <= 199 classes fit UInt8, ~299 do not: the ctor itself throws (T(l + 1), :29)
+                pkg.Partition.from_matrix(rng.integers(0, 200, size=(n, n)), ctx=ctx)
+                with pytest.raises(pkg.LabelOverflow):
+                    pkg.Partition.from_matrix(B, ctx=ctx)
+                with pytest.raises(pkg.LabelOverflow):
+                    pkg.Partition.from_matrix(B.astype(np.float64), ctx=ctx)
+                continue
+            Pa = pkg.Partition.from_matrix(A, ctx=ctx)
+            Pb = pkg.Partition.from_matrix(B, ctx=ctx)
+            if expect:
+                with pytest.raises(pkg.LabelOverflow):
+                    pkg.refine(Pa, Pb, ctx=ctx)
+                with pytest.raises(oracle.LabelOverflow):
+                    oracle.refine(oracle.partition_from_labels(A), oracle.partition_from_labels(B), bits)
+            else:
+                got = pkg.refine(Pa, Pb, ctx=ctx)
+                ref = oracle.refine(oracle.partition_from_labels(A), oracle.partition_from_labels(B), bits or None)
+                assert got.nparts == ref.nparts and np.array_equal(got.matrix, ref.matrix)
+    # the edge, exactly: max pair code 255 fits UInt8, 256 does not
+    P1 = np.array([[1, 2], [3, 4]])  # dim 4
+    P2ok = np.array([[1, 2], [3, 50]])  # canonical labels 1..4: max code = 4 + 4 * 5 = 24
+    with pkg.Context(seed=1, label_bits=8) as ctx:
+        assert pkg.refine(pkg.Partition.from_matrix(P1, ctx=ctx), pkg.Partition.from_matrix(P2ok, ctx=ctx), ctx=ctx).nparts == 4
+        big1 = np.arange(1, 51).reshape(5, 10)  # dim 50
+        big2 = np.arange(1, 51).reshape(5, 10)  # last entry: 50 + 50 * 51 = 2600 > 255
+        with pytest.raises(pkg.LabelOverflow):
+            pkg.refine(pkg.Partition.from_matrix(big1, ctx=ctx), pkg.Partition.from_matrix(big2, ctx=ctx), ctx=ctx)
+        lab15 = np.arange(1, 16).reshape(3, 5)  # dim 15: max code 15 + 15 * 16 = 255 = typemax(UInt8): still fits
+        assert pkg.refine(pkg.Partition.from_matrix(lab15, ctx=ctx), pkg.Partition.from_matrix(lab15, ctx=ctx), ctx=ctx).nparts == 15
+    # the loop: G(n, 1/2) theta' ends at dim (n^2 + n) / 2 -- beyond UInt16 for n = 400, as in the reference's default
+    # admissible_subspace(Partition{UInt16}, ...) (src/partitions.jl:84)
+    Cv, Am, b = problems.theta_prime_problem(problems.gnp_adjacency(400, 0.5, seed=2))
+    with pkg.Context(seed=3, label_bits=16) as ctx:
+        with pytest.raises(pkg.LabelOverflow):
+            pkg.admissible_subspace(Cv, Am, b, ctx=ctx)
+    with pkg.Context(seed=3, label_bits=32) as ctx:
+        assert pkg.admissible_subspace(Cv, Am, b, ctx=ctx).nparts == (400 * 400 + 400) // 2
+    with pytest.raises(pkg.SdpsrError):
+        pkg.Context(label_bits=12)
+
+
+def test_int64_keys_ctor(pkg, oracle, gpu_ctx):
+    """sdpsr_partition_from_u64: integer entries beyond 2^32 (and the relabel of hash-combined labels in the multi-GPU
+    agreement) -- canonical first-occurrence numbering, 0 preserved."""
+    import torch
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 40, size=(70, 70)).astype(np.int64)
+    M = base * (2 ** 40 + 12345)
+    P = pkg.Partition.from_matrix(M, ctx=gpu_ctx)
+    R = oracle.partition_from_labels(base)
+    assert P.nparts == R.nparts and np.array_equal(P.matrix, R.matrix)
+    keys = torch.from_numpy(M.ravel(order="F").copy()).cuda() * -7  # negative int64 = large uint64: keys, not values
+    lab, d = pkg.relabel_keys(keys, ctx=gpu_ctx)
+    assert d == R.nparts and np.array_equal(lab.cpu().numpy().reshape(70, 70, order="F"), R.matrix)
+
+
+def test_symmetry_verdict_is_not_reused_for_other_labels(pkg, gpu_ctx, golden):
+    """a device-resident symmetric blockDiagonalize caches its symmetry verdict in the ctx; a later
+    eigen_decomposition of a NON-symmetric host partition on the same ctx must still raise
+    InvalidDecompositionField (and the other order must not raise spuriously)."""
+    import torch
+    L = golden["er5_P"]
+    n = L.shape[0]
+    tP = torch.from_numpy(np.ascontiguousarray(L.ravel(order="F")).astype(np.int32)).cuda()
+    Pd = pkg.Partition(int(L.max()), tP.view(n, n).t())
+    bd = pkg.blockDiagonalize(Pd, ctx=gpu_ctx)
+    assert sorted(bd.blkSizes) == [2, 2, 2, 3]
+    c3 = np.zeros((n, n), dtype=np.uint32)  # directed cycle: not symmetric
+    for i in range(n):
+        c3[i, (i + 1) % n] = 1
+        c3[i, i] = 2
+    with pytest.raises(pkg.InvalidDecompositionField):
+        pkg.eigen_decomposition(pkg.Partition(2, c3), ctx=gpu_ctx)
+    ne, nc = pkg.eigen_decomposition(pkg.Partition(int(L.max()), L.copy()), ctx=gpu_ctx)  # symmetric host labels after it
+    assert ne >= nc >= 1
+    bd = pkg.blockDiagonalize(Pd, ctx=gpu_ctx)
+    assert sorted(bd.blkSizes) == [2, 2, 2, 3]
+
+
+def test_symmetry_hint_does_not_survive_a_failed_call(pkg, problems, golden):
+    """sdpsr_hint_symmetric_basis applies to ONE call, also when that call fails early."""
+    Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(3))
+    setup = pkg.admissible_setup(Cv, A, b)
+    n, CL, X0L, U = setup
+    rng = np.random.default_rng(1)
+    with pkg.Context(seed=2) as ctx:
+        lib = ctx._lib
+        lib.sdpsr_hint_symmetric_basis(ctx._h, 3)
+        d, it = C.c_int64(0), C.c_int32(0)
+        P = np.zeros(n * n, dtype=np.uint32)
+        st = lib.sdpsr_admissible_subspace(ctx._h, n, C.c_void_p(CL.ctypes.data), C.c_void_p(X0L.ctypes.data), None, 2, 1e-8,
+                                           C.c_void_p(P.ctypes.data), C.byref(d), C.byref(it), None, 0)  # r > 0 without U
+        assert st == 5
+        # a NON-symmetric problem next: with a stale hint (bit 1) its initial partition would be the mirrored lower triangle
+        M1 = rng.integers(0, 4, size=(n, n)).astype(np.float64)
+        M2 = rng.integers(0, 3, size=(n, n)).astype(np.float64)
+        f1, f2 = np.ascontiguousarray(M1.ravel(order="F")), np.ascontiguousarray(M2.ravel(order="F"))
+        ctx.check(lib.sdpsr_admissible_subspace(ctx._h, n, C.c_void_p(f1.ctypes.data), C.c_void_p(f2.ctypes.data), None, 0, 1e-8,
+                                                C.c_void_p(P.ctypes.data), C.byref(d), C.byref(it), None, 0))
+        got = P.reshape(n, n, order="F")
+        assert not np.array_equal(got, got.T)  # the labels refine the (non-symmetric) pair partition
+
+
+@pytest.mark.parametrize("name", ["circ1024", "er7xK16", "er5xK20"])
+def test_small_compressed_problem_host_and_device_paths(pkg, problems, oracle, golden, name):
+    """Module-compression driver, compressed order w <= 64: Murota's steps on the host (default: host tridiagonal-QL
+    eigensolver inside the read-back the driver makes anyway) against the one-workgroup device kernels
+    (SDPSR_FLAG_SMALL_EIGEN_ON_DEVICE) -- same block sizes, orthonormal Q_hat, blks == Q_k' 1[P==i] Q_k and the
+    spectrum invariant on both; also with the reference-literal switches of the irreducible / coupling steps."""
+    if name == "circ1024":
+        L, d = problems.synthetic_jordan_partition(1024, seed=4)
+        expect = [1] * d
+    elif name == "er7xK16":
+        L, d = problems.kron_with_complete(golden["er7_P"].astype(np.int64), 16, seed=5)
+        expect = sorted([2, 2, 2, 2, 3] * 2)
+    else:
+        L, d = problems.kron_with_complete(golden["er5_P"].astype(np.int64), 20, seed=6)
+        expect = sorted([2, 2, 2, 3] * 2)
+    P = pkg.Partition(d, L.astype(np.uint32))
+    Po = oracle.Partition(d, L)
+    x = np.random.default_rng(8).random(d)
+    F = pkg._lib
+    for flags in (0, F.FLAG_SMALL_EIGEN_ON_DEVICE, F.FLAG_FRESH_IRREDUCIBLE_ELEMENT, F.FLAG_SINGLE_COUPLING_ELEMENT | F.FLAG_ALWAYS_REORTHOGONALIZE,
+                  F.FLAG_SPMM_ONE_BY_ONE):
+        for seed in (3, 4, 5):
+            with pkg.Context(seed=seed, eig_driver=6, flags=flags) as ctx:
+                bd = pkg.blockDiagonalize(P, ctx=ctx, retries=3)
+            assert sorted(bd.blkSizes) == expect, (name, flags, seed)
+            full, blk = oracle.spectrum_invariant(Po, bd.blks, x)
+            assert len(full) == len(blk) and np.allclose(full, blk, rtol=1e-6, atol=1e-8), (name, flags, seed)
+            for q in bd.Q_hat:
+                q = np.asarray(q)
+                assert np.abs(q.T @ q - np.eye(q.shape[1])).max() < 1e-7
+            ref = oracle.basis_image_fast([np.asarray(q) for q in bd.Q_hat], Po)
+            for i in range(0, d, max(1, d // 5)):
+                for k in range(len(bd.blkSizes)):
+                    assert np.allclose(bd.blks[i][k], ref[i][k], atol=1e-9)

@@ -10,5 +10,5 @@ cases = [("int8 N=4096 4ch lower (product launch)", 0, 4096, 104, 40, 4 * 2 * 40
 with pkg.Context(seed=1) as ctx:
     for name, kind, n, aux, reps, ops in cases:
         out = (C.c_double * 3)()
-        ctx.check(ctx._lib.sdpsr_profile_clock(ctx._h, kind, n, aux, reps, out))
+        ctx.check(pkg._lib.load_prof_library().sdpsr_profile_clock(ctx._h, kind, n, aux, reps, out))
         print(f"{name:42s} {out[0]:8.4f} ms  {ops / out[0] / 1e9:9.1f} Tops/s  shader clock {out[1]:6.0f} MHz ({int(out[2])} intervals)")

@@ -6,5 +6,5 @@ pkg = load_package()
 n, aux, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 with pkg.Context(seed=1) as ctx:
     v = C.c_double(0)
-    ctx.check(ctx._lib.sdpsr_profile_kernel(ctx._h, 0, n, aux, reps, C.byref(v)))
+    ctx.check(pkg._lib.load_prof_library().sdpsr_profile_kernel(ctx._h, 0, n, aux, reps, C.byref(v)))
     print(n, aux, "ms %.4f" % v.value)

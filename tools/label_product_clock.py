@@ -9,5 +9,5 @@ for name, kind, n, aux, reps in [("label product w=34", 9, 4096, 34 | (1 << 8) |
                                  ("label product w=16", 9, 4096, 16 | (1 << 8) | (34 << 12), 200),
                                  ("label product w=64", 9, 4096, 64 | (1 << 8) | (34 << 12), 200),
                                  ("fp64 gemm", 2, 4096, 0, 10)]:
-    ctx.check(ctx._lib.sdpsr_profile_clock(ctx._h, kind, n, aux, reps, out))
+    ctx.check(pkg._lib.load_prof_library().sdpsr_profile_clock(ctx._h, kind, n, aux, reps, out))
     print(f"{name}: {out[0]*1e3:.1f} us per launch, shader clock {out[1]:.0f} MHz ({int(out[2])} intervals)")

@@ -7,5 +7,5 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 with pkg.Context(seed=1) as ctx:
     v = C.c_double(0)
-    ctx.check(ctx._lib.sdpsr_profile_kernel(ctx._h, 6, n, 0, reps, C.byref(v)))
+    ctx.check(pkg._lib.load_prof_library().sdpsr_profile_kernel(ctx._h, 6, n, 0, reps, C.byref(v)))
     print("sytrd n=%d: %.3f ms" % (n, v.value))

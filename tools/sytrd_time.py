@@ -8,7 +8,7 @@ ns = [int(x) for x in sys.argv[1:]] or [4096]
 with pkg.Context(seed=1) as ctx:
     lib = ctx._lib
     def prof(kind, n, aux=0, reps=3):
-        v = C.c_double(0); ctx.check(lib.sdpsr_profile_kernel(ctx._h, kind, n, aux, reps, C.byref(v))); return v.value
+        v = C.c_double(0); ctx.check(pkg._lib.load_prof_library().sdpsr_profile_kernel(ctx._h, kind, n, aux, reps, C.byref(v))); return v.value
     for n in ns:
         t6 = prof(6, n, reps=3)
         t5 = prof(5, n, reps=2)
