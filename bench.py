@@ -75,9 +75,9 @@ def cpu_baseline(pr, n_sample, seed):
 
 def rocprof_average_us(pattern):
     """Average duration (us) of a kernel in this round's committed rocprofv3 --kernel-trace --stats
-    summary of the default bench command (profiles/r02_bench_n4096_kernel_stats.csv), or None."""
+    summary of the default bench command (profiles/r03_bench_n4096_kernel_stats.csv), or None."""
     try:
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_n4096_kernel_stats*.csv")))[-1]
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_n4096_kernel_stats*.csv")))[-1]
         for row in csv.DictReader(open(path)):
             if pattern in row["Name"]:
                 return round(float(row["AverageNs"]) / 1e3, 2)
@@ -90,8 +90,8 @@ def pmc_traffic(key):
     """HBM bytes per launch from this round's separate rocprofv3 --pmc passes (FETCH_SIZE x 2 +
     WRITE_SIZE, MI355X_MICROARCH.md HBM section), or None when the pass is not in profiles/."""
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-        return round(pj[key]["traffic_bytes_per_launch"]), "profiles/r02_pmc.json:" + key
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+        return round(pj[key]["traffic_bytes_per_launch"]), "profiles/r03_pmc.json:" + key
     except Exception:
         return None, None
 
@@ -114,7 +114,7 @@ class Workload:
         self.tU = torch.from_numpy(np.ascontiguousarray(U.T)).to(dev) if self.r else None  # (r, n^2): rows = columns of U
         self.tP = torch.empty(n * n, dtype=torch.int32, device=dev)
         self.golden = torch.from_numpy(np.ascontiguousarray(labels.ravel(order="F")).astype(np.int32)).to(dev)
-        self.blk_buf = {}
+        self.blk = None  # device buffer of the block images (sized by the first step)
         self.dev = dev
 
 
@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--mode", default="i8", choices=["i8", "f32", "f64"])
     ap.add_argument("--cpu-n", type=int, default=-1, help="order of the CPU-baseline reduction (-1 = the headline order, 0 = skip)")
     ap.add_argument("--eig-driver", type=int, default=0, help="0 auto (module compression when dim(P) << n), 4 dense eigensolver forced")
+    ap.add_argument("--no-graph", action="store_true", help="dense driver: launch the tridiagonalisation's kernels one by one (per-kernel rocprofv3 statistics)")
+    ap.add_argument("--flags", type=int, default=0, help="sdpsr_opts.flags (include/sdpsr.h: SDPSR_FLAG_*) for A/B runs")
+    ap.add_argument("--channels", type=int, default=0, help="sdpsr_opts.channels (0 = default: 2 + one confirm round)")
     ap.add_argument("--timers-in-timed-region", action="store_true",
                     help="record the per-phase HIP events inside the timed steps (default: in a separate instrumented pass)")
     ap.add_argument("--skip-roofline", action="store_true", help="only the timed steps (clean rocprofv3 kernel statistics)")
@@ -203,7 +206,8 @@ def main():
         return Workload(pkg, dev, name, "theta' SDP of ER(7) [] K_72, N = 4104, non-commutative", Cv, A, b, Ls, d, [2, 2, 2, 2, 3] * 2)
 
     mode = {"i8": L.SQUARE_I8, "f32": L.SQUARE_F32, "f64": L.SQUARE_F64}[args.mode]
-    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode, eig_driver=args.eig_driver)
+    opt_flags = args.flags | (L.FLAG_NO_GRAPH if args.no_graph else 0)
+    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode, eig_driver=args.eig_driver, flags=opt_flags, channels=args.channels)
 
     def vp(t):
         return C.c_void_p(t.data_ptr()) if t is not None else None
@@ -223,16 +227,37 @@ def main():
         lib = cx._lib
         dd = C.c_int64(0)
         it = C.c_int32(0)
+        nb = C.c_int32(0)
+        ssq = C.c_int64(0)
+        ss = C.c_int64(0)
         ms = (C.c_double * L.T_COUNT)()
         tp = (lambda a: C.cast(a, C.c_void_p)) if timers else (lambda a: None)  # NULL: no phase events in the stream
         if w.hint:
             lib.sdpsr_hint_symmetric_basis(cx._h, w.hint)
-        cx.check(lib.sdpsr_admissible_subspace(cx._h, w.n, vp(w.tCL), vp(w.tX0), vp(w.tU), w.r, ATOL, vp(w.tP), C.byref(dd),
-                                               C.byref(it), tp(ms), L.MEM_DEVICE))
-        acc.iters += it.value
-        for i in range(L.T_COUNT):
-            acc.phase[i] += ms[i]
-        if world > 1 and collective:
+        if not (world > 1 and collective):
+            # one rank: the whole reduction in ONE call (sdpsr_jordan_reduce: the partition stays on the device, no host
+            # synchronisation between admissible_subspace, blockDiagonalize and basis_image); the image buffer of the
+            # previous step is offered, a first step (or a changed size) fetches the images with sdpsr_block_images
+            cap = w.blk.numel() if w.blk is not None else 0
+            cx.check(lib.sdpsr_jordan_reduce(cx._h, w.n, vp(w.tCL), vp(w.tX0), vp(w.tU), w.r, ATOL, ATOL, vp(w.tP), C.byref(dd), C.byref(it),
+                                             C.byref(nb), C.byref(ssq), C.byref(ss), vp(w.blk), cap, None, 0, tp(ms), L.MEM_DEVICE))
+            if dd.value * ssq.value > cap:
+                w.blk = torch.empty(max(1, dd.value * ssq.value), dtype=torch.float64, device=dev)
+                ms2 = (C.c_double * L.T_COUNT)()
+                cx.check(lib.sdpsr_block_images(cx._h, vp(w.blk), None, tp(ms2), L.MEM_DEVICE))
+                for i in range(1, L.T_COUNT):
+                    ms[i] += ms2[i]
+            acc.iters += it.value
+            for i in range(L.T_COUNT):
+                acc.phase[i] += ms[i]
+            if check:
+                assert dd.value == w.d and bool((w.tP == w.golden).all()), "partition differs from the generator's closure"
+        else:
+            cx.check(lib.sdpsr_admissible_subspace(cx._h, w.n, vp(w.tCL), vp(w.tX0), vp(w.tU), w.r, ATOL, vp(w.tP), C.byref(dd),
+                                                   C.byref(it), tp(ms), L.MEM_DEVICE))
+            acc.iters += it.value
+            for i in range(L.T_COUNT):
+                acc.phase[i] += ms[i]
             # agree the partition across the restarts (canonical labels: equal w.p. 1): 128-bit
             # checksums computed on the device are all-gathered; the 64 MiB label matrix itself
             # only travels if they differ: MIN/MAX all-reduce, and -- a rank's draws missed a split --
@@ -249,21 +274,17 @@ def main():
                 acc.meets += 1
                 w.tP.copy_(lab)
                 dd.value = int(lab.max().item())
-        if check:
-            assert dd.value == w.d and bool((w.tP == w.golden).all()), "partition differs from the generator's closure"
-        nb = C.c_int32(0)
-        ssq = C.c_int64(0)
-        ss = C.c_int64(0)
-        ms1 = (C.c_double * L.T_COUNT)()
-        cx.check(lib.sdpsr_block_diagonalize(cx._h, w.n, vp(w.tP), dd.value, ATOL, C.byref(nb), C.byref(ssq), C.byref(ss),
-                                             tp(ms1), L.MEM_DEVICE))
-        key = (dd.value, ssq.value)
-        if key not in w.blk_buf:
-            w.blk_buf[key] = torch.empty(max(1, dd.value * ssq.value), dtype=torch.float64, device=dev)
-        ms2 = (C.c_double * L.T_COUNT)()
-        cx.check(lib.sdpsr_block_images(cx._h, vp(w.blk_buf[key]), None, tp(ms2), L.MEM_DEVICE))
-        for i in range(1, L.T_COUNT):
-            acc.phase[i] += ms1[i] + ms2[i]
+            if check:
+                assert dd.value == w.d and bool((w.tP == w.golden).all()), "partition differs from the generator's closure"
+            ms1 = (C.c_double * L.T_COUNT)()
+            cx.check(lib.sdpsr_block_diagonalize(cx._h, w.n, vp(w.tP), dd.value, ATOL, C.byref(nb), C.byref(ssq), C.byref(ss),
+                                                 tp(ms1), L.MEM_DEVICE))
+            if w.blk is None or w.blk.numel() < dd.value * ssq.value:
+                w.blk = torch.empty(max(1, dd.value * ssq.value), dtype=torch.float64, device=dev)
+            ms2 = (C.c_double * L.T_COUNT)()
+            cx.check(lib.sdpsr_block_images(cx._h, vp(w.blk), None, tp(ms2), L.MEM_DEVICE))
+            for i in range(1, L.T_COUNT):
+                acc.phase[i] += ms1[i] + ms2[i]
         if check:
             sizes = np.zeros(nb.value, dtype=np.int32)
             cx.check(lib.sdpsr_block_sizes(cx._h, sizes.ctypes.data_as(C.c_void_p)))
@@ -384,9 +405,10 @@ def main():
     if rank == 0 and not args.skip_roofline:
         d, r = w0.d, w0.r
         flops = 2.0 * n ** 3
-        # the int8 square is launched exactly as the product path launches it: all 4 channels in
+        # the int8 square is launched exactly as the product path launches it: all its channels in
         # one launch (so that the HIP-event duration agrees with rocprofv3's average for the kernel)
-        for name, kind, peak, unit, batch in (("square_i8", 0, I8_MFMA_PEAK_TOPS, "TOP/s", 4), ("square_f32", 1, FP32_MFMA_PEAK_TF, "TFLOP/s", 1),
+        TP = args.channels if args.channels > 0 else 2  # channels of one product launch (sdpsr_opts.channels default)
+        for name, kind, peak, unit, batch in (("square_i8", 0, I8_MFMA_PEAK_TOPS, "TOP/s", TP), ("square_f32", 1, FP32_MFMA_PEAK_TF, "TFLOP/s", 1),
                                               ("gemm_f64", 2, FP64_MFMA_PEAK_TF, "TFLOP/s", 1)):
             ms = prof(kind, n, aux=batch)
             ach = batch * flops / (ms * 1e-3) / 1e12
@@ -454,26 +476,26 @@ def main():
         ms6 = prof(6, n, reps=2)
         kernels["sytrd_total"] = {"ms": round(ms6, 3), "note": "whole tridiagonalisation (graph replay): symv + form + MFMA syr2k launches"}
         # `roofline`: the kernel that carries the O(N^3) work of the default path and its only
-        # MFMA-bound one, launched as the product path launches it: 4 channels, lower-triangle tiles
+        # MFMA-bound one, launched as the product path launches it: TP channels, lower-triangle tiles
         # of the symmetric product.  frac = EXECUTED ops / peak (hardware efficiency); the figure
         # judged against the algorithmic 2*N^3 per square is reported beside it.
-        ms_tri = prof(0, n, aux=104)
+        ms_tri = prof(0, n, aux=100 + TP)
         Tt = (n + 127) // 128
         exec_frac = (Tt + 1) / (2.0 * Tt)
-        alg_rate = 4 * flops / (ms_tri * 1e-3) / 1e12
-        tr, src = pmc_traffic("i8x4_lower")
+        alg_rate = TP * flops / (ms_tri * 1e-3) / 1e12
+        tr, src = pmc_traffic(f"i8x{TP}_lower")
         ki8 = kernels["square_i8"]
-        roof = {"kernel": "gemm_tn_dma_kernel<i8> (random squares: 4 channels per launch, lower-triangle tiles of the symmetric product)",
+        roof = {"kernel": f"gemm_tn_dma_kernel<i8> (random squares: {TP} channels per launch, lower-triangle tiles of the symmetric product)",
                 "bound": "mfma", "achieved": round(alg_rate * exec_frac, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(alg_rate * exec_frac / I8_MFMA_PEAK_TOPS, 4), "traffic": tr, "traffic_source": src,
-                "ms_per_launch": round(ms_tri, 4), "executed_ops_per_launch": 4 * flops * exec_frac,
-                "algorithmic_ops_per_launch": 4 * flops, "algorithmic_rate_2N3": round(alg_rate, 2),
+                "ms_per_launch": round(ms_tri, 4), "channels_per_launch": TP, "executed_ops_per_launch": TP * flops * exec_frac,
+                "algorithmic_ops_per_launch": TP * flops, "algorithmic_rate_2N3": round(alg_rate, 2),
                 "algorithmic_frac_2N3": round(alg_rate / I8_MFMA_PEAK_TOPS, 4),
-                "algorithmic_bytes_per_launch": 4 * (n * n + 4 * n * n),
+                "algorithmic_bytes_per_launch": TP * (n * n + 4 * n * n),
                 "rocprof_avg_us": rocprof_average_us("gemm_tn_dma_kernel<0,"),
                 "full_square_kernel": {"ms_per_launch": ki8["ms_per_launch"], "achieved": ki8["achieved"], "frac": ki8["frac"]},
-                "algorithmic": "2*N^3 int8 multiply-adds (as ops) per channel and square (SURVEY 8d); one launch = 4 channels (the "
-                               "reference does ONE square per iteration: 4 channels are this build's redundancy for 8-bit draws); "
+                "algorithmic": f"2*N^3 int8 multiply-adds (as ops) per channel and square (SURVEY 8d); one launch = {TP} channels (the "
+                               f"reference does ONE square per iteration: {TP} channels + one confirm round are this build's redundancy for 8-bit draws); "
                                "executed = (T+1)/(2T) of that (lower-triangle tiles); algorithmic bytes per launch = channels x "
                                "(N^2 int8 read + N^2 int32 written)"}
         # shader clock while this launch runs (sdpsr_profile_clock: a one-wave sampler on a side
@@ -483,7 +505,7 @@ def main():
         # beside the fraction of the nominal (2.4 GHz) peak
         try:
             co = (C.c_double * 3)()
-            ctx.check(L.load_prof_library().sdpsr_profile_clock(ctx._h, 0, n, 104, 40, co))
+            ctx.check(L.load_prof_library().sdpsr_profile_clock(ctx._h, 0, n, 100 + TP, 40, co))
             if co[1] > 0:
                 roof["shader_clock_mhz"] = round(co[1], 0)
                 roof["nominal_clock_mhz"] = 2400
@@ -509,7 +531,7 @@ def main():
             "dtype": {"i8": "int8 square (int32 acc) + f64 eigen", "f32": "f32 square + f64 eigen", "f64": "f64"}[args.mode],
             "data": "synthetic",
             "config": {"workload": f"configs[3]: synthetic Jordan algebra N={w0.n}, {w0.d} basis matrices, instance '{args.workload}' ({w0.note}), "
-                                   f"square_mode={args.mode}, 4 channels", "N": w0.n, "dim": w0.d, "restarts_per_step": world,
+                                   f"square_mode={args.mode}, {args.channels or 2} channels" + ("" if args.channels else " + 1 confirm round"), "N": w0.n, "dim": w0.d, "restarts_per_step": world,
                        "iterations_per_reduction": acc_timed.iters / max(1, args.steps)},
             "phase_ms_per_step": phases(acc_timed, args.steps),
             "phase_ms_source": "HIP events inside the timed steps" if args.timers_in_timed_region else

@@ -112,7 +112,11 @@ enum {
     SDPSR_FLAG_SMALL_EIGEN_ON_DEVICE = 1u << 7,
     /* dense driver: launch the kernels of the tridiagonalisation one by one instead of replaying
        their hipGraph (per-kernel profiles) */
-    SDPSR_FLAG_NO_GRAPH = 1u << 8
+    SDPSR_FLAG_NO_GRAPH = 1u << 8,
+    /* admissible_subspace: every round runs the full refinement (insert / rank / label passes); by
+       default a round that is expected not to refine -- a confirm round, the first iteration -- first
+       compares every entry with the representative of its class and skips the relabel when none differs */
+    SDPSR_FLAG_NO_VERIFY_SHORTCUT = 1u << 9
 };
 
 typedef struct sdpsr_opts {
@@ -302,6 +306,23 @@ int sdpsr_q_hat(sdpsr_ctx* ctx, double* Q_hat, int mem);
    blks: d * sum_sq doubles, class-major, then block, each block column-major s_k x s_k.
    Q_hat (optional, may be NULL): n x sum_s column-major, blocks side by side. */
 int sdpsr_block_images(sdpsr_ctx* ctx, double* blks, double* Q_hat, double* phase_ms, int mem);
+/* ---- one reduction in one call ---------------------------------------------------------------------
+   sdpsr_admissible_subspace followed by sdpsr_block_diagonalize on its result and -- when the images fit the
+   caller's buffer -- sdpsr_block_images, with the partition staying on the device and no host synchronisation
+   between the stages (the separate entry points each return with their outputs complete).  Same arguments and
+   meaning as those three; `mem` names the memory space of CL / X0L / U / P_out / blks / Q_hat.
+     P_out           n x n labels, may be NULL (the partition is then only kept inside ctx for sdpsr_block_images);
+     blks            d * sum_sq doubles if that is <= blks_capacity (in doubles), else untouched: the caller reads
+                     *dim_out * *sum_sq, allocates and calls sdpsr_block_images; blks_capacity = 0: sizes only;
+     Q_hat           n * sum_s doubles under the same rule with qhat_capacity; may be NULL.
+   Status: that of the first stage that fails.  After SDPSR_NUMERICAL_INCONSISTENCY / SDPSR_DIMENSION_MISMATCH
+   (the randomized failures of blockDiagonalize, "try again" in the reference) the partition outputs are valid and
+   the caller retries with sdpsr_block_diagonalize on them; SDPSR_NOT_CONVERGED is reported after the other stages ran. */
+int sdpsr_jordan_reduce(sdpsr_ctx* ctx, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r,
+                        double atol, double epsilon, uint32_t* P_out, int64_t* dim_out, int32_t* iters_out,
+                        int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks, int64_t blks_capacity,
+                        double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem);
+
 /* ---- blockDiagonalize(P; complex = true), src/compat.jl:26-32,46-68 with T = ComplexF64 ---------
    diagonalize(ComplexF64, P) = desymmetrize (src/diagonalize.jl:26-28) + Murota's decomposition
    over C + check_block_sizes with sum s_k^2 == dim(P) (:13-23); the partition handed to

@@ -27,6 +27,7 @@ FLAG_SPMM_ONE_BY_ONE = 1 << 5
 FLAG_SINGLE_COUPLING_ELEMENT = 1 << 6
 FLAG_SMALL_EIGEN_ON_DEVICE = 1 << 7
 FLAG_NO_GRAPH = 1 << 8
+FLAG_NO_VERIFY_SHORTCUT = 1 << 9
 BASIS_IMAGE_KERNELS = {"auto": 0, "two_stage": 1, "outer": 2, "chunk": 3}
 REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2}
 
@@ -101,6 +102,7 @@ def load_library():
         "sdpsr_gemm_tn_f64": (C.c_int, [vp, i64, i64, i64, vp, i64, vp, i64, vp, i64, C.c_int]),
         "sdpsr_admissible_subspace": (C.c_int, [vp, i64, vp, vp, vp, i64, dbl, vp, pi64, pi32, vp, C.c_int]),
         "sdpsr_admissible_subspace_dense": (C.c_int, [vp, i64, i64, vp, vp, vp, dbl, vp, pi64, pi32, vp, C.c_int]),
+        "sdpsr_jordan_reduce": (C.c_int, [vp, i64, vp, vp, vp, i64, dbl, dbl, vp, pi64, pi32, pi32, pi64, pi64, vp, i64, vp, i64, vp, C.c_int]),
         "sdpsr_reduce_constraints": (C.c_int, [vp, i64, vp, i64, i64, vp, vp, C.c_int]),
         "sdpsr_desymmetrize": (C.c_int, [vp, i64, vp, pi64, pi32, C.c_int]),
         "sdpsr_block_diagonalize": (C.c_int, [vp, i64, vp, i64, dbl, pi32, pi64, pi64, vp, C.c_int]),

@@ -14,11 +14,9 @@
 
 using namespace sdpsr;
 
-extern "C" {
-
-int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon,
-                            int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* phase_ms,
-                            int mem) {
+namespace sdpsr {
+int block_diagonalize_impl(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon, int32_t* nblocks, int64_t* sum_sq,
+                           int64_t* sum_s, double* phase_ms, int mem, bool trusted_symmetric, bool final_sync) {
     CHECK_CTX(c);
     if (!P || n < 1 || d < 0 || !(epsilon > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
     const int64_t len = n * n;
@@ -34,6 +32,7 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
     if (!L) return SDPSR_OUT_OF_MEMORY;
     c->bd_sym_labels = nullptr;
     c->bd_sym_epoch = 0;
+    c->bd_trusted_symmetric = (trusted_symmetric && mem == SDPSR_MEM_DEVICE && P == L) ? L : nullptr;
     if (mem == SDPSR_MEM_DEVICE) {
         if (P != L) {
             // copy and symmetry check of the same tiles in one pass; the verdict ("bd_symflag"[0] ==
@@ -61,7 +60,7 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
         return ctx_fail(c, SDPSR_SOLVER_ERROR, "requested driver not applicable to this partition (" + c->err + ")");
     if (st != SDPSR_OK && st != DRIVER_FALLBACK) return st;
     if (st == DRIVER_FALLBACK) {
-        st = dense_diagonalize(c, n, L, nullptr, atol, info, sizes, S1, S, tm);
+        st = dense_diagonalize(c, n, L, nullptr, atol, info, sizes, S1, S, tm, d);  // d: extra coupling elements on demand
         if (st) return st;
     }
 
@@ -83,7 +82,7 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
         tm.collect();
         for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = tm.acc[i];
         phase_ms[SDPSR_T_TOTAL] = ms;
-    } else {
+    } else if (final_sync) {
         HIP_TRY(c, hipStreamSynchronize(s));
     }
     if (final_dim != d) {
@@ -95,6 +94,15 @@ int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t 
     }
     c->bd_valid = true;
     return SDPSR_OK;
+}
+}  // namespace sdpsr
+
+extern "C" {
+
+int sdpsr_block_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon,
+                            int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* phase_ms,
+                            int mem) {
+    return block_diagonalize_impl(c, n, P, d, epsilon, nblocks, sum_sq, sum_s, phase_ms, mem, false, true);
 }
 
 }  // extern "C"

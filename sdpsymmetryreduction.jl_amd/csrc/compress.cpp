@@ -50,11 +50,14 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     // memory-safe for any labels, their results are simply discarded)
     if (!c->pinned_small) return SDPSR_OUT_OF_MEMORY;
     const bool sym_pre = c->bd_sym_epoch != 0 && c->bd_sym_labels == L;  // checked by the copy pass of blockDiagonalize
-    if (!sym_pre) launch_check_symmetric(s, n, L, flag);
+    const bool sym_trusted = c->bd_trusted_symmetric == L;               // labels of the library's own symmetric loop
     c->pinned_small[0] = 0;
-    HIP_TRY(c, hipMemcpyAsync(c->pinned_small, sym_pre ? (const uint32_t*)ctx_buf(c, "bd_symflag", 64) : flag, 4,
-                              hipMemcpyDeviceToHost, s));
-    bool sym_checked = false;
+    if (!sym_trusted) {
+        if (!sym_pre) launch_check_symmetric(s, n, L, flag);
+        HIP_TRY(c, hipMemcpyAsync(c->pinned_small, sym_pre ? (const uint32_t*)ctx_buf(c, "bd_symflag", 64) : flag, 4,
+                                  hipMemcpyDeviceToHost, s));
+    }
+    bool sym_checked = sym_trusted;
     // Y <- A W for a fresh generic element A: fused label product when the shape allows it,
     // gather + split-K MFMA GEMM otherwise.  Columns >= wcols of dst keep their old content.
     auto apply_generic = [&](int wcols, double* dst) -> int {
@@ -379,9 +382,8 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         launch_tall_times_small(s, n, ld, W, w, qs, w, (int)S1, 1.0, 0.0, Qhat, n);
         launch_clamptol(s, n * S1, Qhat, atol);  // src/diagonalize.jl:39
         tm.end();
-        HIP_TRY(c, hipStreamSynchronize(s));
-        HIP_TRY(c, hipGetLastError());
-        dbg_mark(c, "compressed: small problem solved on the host, lifted");
+        HIP_TRY(c, hipGetLastError());  // no host wait here: the caller synchronises (or keeps enqueueing: sdpsr_jordan_reduce)
+        dbg_mark(c, "compressed: small problem solved on the host, lift enqueued");
         return SDPSR_OK;
     }
     // columns >= w must be zero for the padded products below

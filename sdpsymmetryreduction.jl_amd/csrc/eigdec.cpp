@@ -159,7 +159,7 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     if (!flag || !Q || !Ap || !Tp || !w) return SDPSR_OUT_OF_MEMORY;
     // a non-symmetric partition has a non-symmetric generic element: eigen() leaves the reals
     // (src/eigen_decomposition.jl:247-253)
-    if (!gen) {
+    if (!gen && c->bd_trusted_symmetric != L) {
         const bool pre = c->bd_sym_epoch != 0 && c->bd_sym_labels == L;  // checked by the copy pass of blockDiagonalize
         const uint32_t* fsrc = flag;
         if (pre) fsrc = (const uint32_t*)ctx_buf(c, "bd_symflag", 64);
@@ -273,15 +273,17 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
         norms.resize((size_t)neig * neig);
     }
     auto dimof = [&](int b) { return info.ptrs[b + 1] - info.ptrs[b]; };
-    // Compressed problems (module-compression driver): every eigenspace is 1- or 2-dimensional, so
-    // the coupling of an isomorphic pair under ONE generic element is a single random number (not the
-    // maximum over an m_i x m_j block as in the full-size algorithm) and falls below the Otsu
-    // threshold in ~0.5 % of the draws (measured: 6 DimensionMismatch in 1000 reductions of
-    // ER(7) (x) K_72 against 0 in 1000 for the reference-literal oracle).  When the classes found
-    // do not add up to dim(P) -- the check the reference makes right afterwards,
+    // The coupling of an isomorphic pair of eigenspaces under ONE generic element is the maximum over
+    // an m_i x m_j block of random numbers -- a single one when the eigenspaces are 1-dimensional
+    // (always so in compressed problems, often in QAP- and theta'-type partitions) -- and falls below
+    // the Otsu threshold in ~0.1-0.5 % of the draws (measured round 2: 6 DimensionMismatch in 1000
+    // compressed reductions of ER(7) (x) K_72, 4 in 2000 dense ones at N = 456, against 0 in 1000 for
+    // the reference-literal oracle).  When the caller knows dim(P) (blockDiagonalize does) and the
+    // classes found do not add up to it -- the check the reference makes right afterwards,
     // src/diagonalize.jl:1-11 -- or are inconsistent, the coupling matrix is raised by another
     // independent generic element (block_norms accumulates maxima: a coupling can only grow) and
-    // the classes are formed again, up to twice.  The common case pays nothing.
+    // the classes are formed again, up to twice.  The common case pays nothing;
+    // SDPSR_FLAG_SINGLE_COUPLING_ELEMENT keeps the reference's single element (:259-262).
     for (int extra = 0;; ++extra) {
         if (!(have_norms && extra == 0)) {
             st = d2h_sync(c, norms.data(), dnorms, (size_t)neig * neig * 8);
@@ -295,8 +297,10 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
                 double v = (dimof(i) != dimof(j)) ? 0.0 : norms[(size_t)i * neig + j];  // block rows Ei, cols Ej
                 norms[(size_t)i * neig + j] = norms[(size_t)j * neig + i] = v;
             }
+        dbg_mark(c, "eigen_decomposition: block norms on the host");
         st = isomorphism_classes(c, norms, neig, atol, info.kpart);
-        if (!gen || expect_dim < 0 || extra >= 2) return st;
+        dbg_mark(c, "eigen_decomposition: Otsu + union-find done");
+        if (expect_dim < 0 || extra >= 2 || (c->opts.flags & SDPSR_FLAG_SINGLE_COUPLING_ELEMENT)) return st;
         if (st != SDPSR_OK && st != SDPSR_NUMERICAL_INCONSISTENCY) return st;
         if (st == SDPSR_OK) {
             std::vector<int> cnt(neig, 0);
@@ -503,6 +507,7 @@ int sdpsr_eigen_decomposition(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_
     if (st) return st;
     c->bd_sym_epoch = 0;  // the verdict cached by sdpsr_block_diagonalize belongs to the labels it copied, not to these
     c->bd_sym_labels = nullptr;
+    c->bd_trusted_symmetric = nullptr;
     const uint32_t* L = in_dev(c, "bd_labels", P, (size_t)n * n, mem, &st);
     if (st) return st;
     c->bd_valid = false;
@@ -529,6 +534,7 @@ int sdpsr_eigen_decomposition_batched(sdpsr_ctx* c, int64_t n, const uint32_t* P
     if (st) return st;
     c->bd_sym_epoch = 0;  // the verdict cached by sdpsr_block_diagonalize belongs to the labels it copied, not to these
     c->bd_sym_labels = nullptr;
+    c->bd_trusted_symmetric = nullptr;
     const uint32_t* L = in_dev(c, "bd_labels", P, (size_t)n * n, mem, &st);
     if (st) return st;
     c->bd_valid = false;

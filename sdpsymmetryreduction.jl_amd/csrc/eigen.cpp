@@ -134,6 +134,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             double* ws = (double*)ctx_buf(c, "eig_sytrd_ws", sytrd_workspace_doubles(n, lda) * sizeof(double));
             if (!ws) return SDPSR_OUT_OF_MEMORY;
             launch_sytrd(c, n, A, lda, w, E, tau, ws);
+            if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: tridiagonalisation done"); }
             if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "sytrd launch failed");
             if (hipMemsetAsync(Z, 0, (size_t)ldz * ldz * sizeof(double), c->stream) != hipSuccess)
                 return ctx_fail(c, SDPSR_HIP_ERROR, "memset of the eigenvector buffer failed");
@@ -144,6 +145,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)ldz, info);
         if (rs != rocblas_status_success)
             return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver tridiagonal solver status " + std::to_string(rs));
+        if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: tridiagonalisation + tridiagonal solver done"); }
         if (own) {
             const int bst = backtransform_device(c, n, A, lda, tau, Z);
             if (bst) return bst;
@@ -158,6 +160,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
                              hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             return ctx_fail(c, SDPSR_HIP_ERROR, "copy of eigenvectors failed");
     }
+    if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: back-transformation done"); }
     if (after_launch) (*after_launch)();  // everything of the eigensolver is enqueued; the caller overlaps its own launches here
     if (defer_readback) return SDPSR_OK;  // the caller reads "eig_info" (status, sweeps) and w with its own next read-back
     // read-back through the pinned scratch of the ctx (a pageable 4-byte copy costs tens of us)

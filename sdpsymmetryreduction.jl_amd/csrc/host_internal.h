@@ -174,6 +174,15 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
 int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* labels, int64_t* nparts, int64_t sym_n = 0,
                       uint32_t* symflag_dev = nullptr, int* sym_out = nullptr);
 
+// loop.cpp / blockdiag.cpp: the bodies of the entry points, chainable without host synchronisation in between
+// (reduce.cpp: sdpsr_jordan_reduce)
+int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r, double atol,
+                             uint32_t* P_out, int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem, int mem_out,
+                             bool final_sync, int* labels_sym_out);
+// labels_in_place: P is ctx buffer "bd_labels" itself; trusted_symmetric: the caller made the labels and knows
+int block_diagonalize_impl(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon, int32_t* nblocks, int64_t* sum_sq,
+                           int64_t* sum_s, double* phase_ms, int mem, bool trusted_symmetric, bool final_sync);
+
 // ---- blockDiagonalize: host pieces and drivers (eigdec.cpp, compress.cpp) ----
 struct EigInfo {
     std::vector<double> vals;

@@ -411,10 +411,11 @@ __global__ void proj_apply_kernel(int64_t len, int r, const double* __restrict__
         double p = 0;
         for (int k = 0; k < r; ++k) p = fma(U[(int64_t)k * len + e], coef[k], p);
         double y = x - p;
-        if (do_round) y = sdpsr_clamp_round(y, atol, scale);
-        if (yout) yout[e] = y;
+        // signature: the injective code of the rounded value (sdpsr_hash.h) -- no division / ldexp; raw bits when not rounding
+        const uint64_t kcode = do_round ? sdpsr_round_key(y, atol, scale) : (uint64_t)__double_as_longlong(y);
+        if (yout) yout[e] = do_round ? sdpsr_clamp_round(y, atol, scale) : y;
         if (sig) {
-            uint64_t kb = (uint64_t)__double_as_longlong(y);
+            uint64_t kb = kcode;
             uint64_t h = 0;
             if (l != 0 || kb != 0) {
                 h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
@@ -535,8 +536,7 @@ __global__ void proj_apply_lower_kernel(int n, int r, const double* __restrict__
             const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
             double p = 0;
             for (int k = 0; k < r; ++k) p = fma(U[(int64_t)k * len + e], coef[k], p);
-            const double y = sdpsr_clamp_round(x - p, atol, scale);
-            const uint64_t kb = (uint64_t)__double_as_longlong(y);
+            const uint64_t kb = sdpsr_round_key(x - p, atol, scale);
             uint64_t h = 0;
             if (l != 0 || kb != 0) {
                 h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
@@ -613,8 +613,7 @@ __global__ void sig_f64_rounded_kernel(int64_t n, int64_t ld, const uint32_t* __
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
         const int64_t j = e / n, i = e - j * n;
         uint32_t l = L[e];
-        double y = sdpsr_clamp_round(v[i + j * ld], atol, scale);
-        uint64_t kb = (uint64_t)__double_as_longlong(y);
+        const uint64_t kb = sdpsr_round_key(v[i + j * ld], atol, scale);
         sig[e] = finish_sig(l, kb == 0, sdpsr_sig_mix(sdpsr_sig_start(l), kb));
     }
 }
@@ -793,8 +792,7 @@ struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig onl
         double p = 0;
 #pragma unroll
         for (int k = 0; k < R; ++k) p = fma(u[k], coef[k], p);
-        const double y = sdpsr_clamp_round(x - p, atol, scale);
-        const uint64_t kb = (uint64_t)__double_as_longlong(y);
+        const uint64_t kb = sdpsr_round_key(x - p, atol, scale);
         uint64_t h = 0;
         if (l != 0 || kb != 0) {
             h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
@@ -884,8 +882,7 @@ struct SrcJoint {
         double p = 0;
 #pragma unroll
         for (int k = 0; k < R; ++k) p = fma(u[k], coef[k], p);
-        const double y = sdpsr_clamp_round(x - p, atol, scale);
-        const uint64_t kb = (uint64_t)__double_as_longlong(y);
+        const uint64_t kb = sdpsr_round_key(x - p, atol, scale);
         uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
         bool allz = kb == 0;
 #pragma unroll
@@ -925,6 +922,9 @@ constexpr int MAX_PROBES = 512;
 // ranks those slots by first index and the three entry-level ranking passes exit at once.
 constexpr uint32_t SMALL_K = 1024;
 constexpr int LIST_OFF = 16;
+// classes whose first-occurrence index the ranking passes also write to RefineWs::first_idx
+constexpr uint32_t REFINE_FIRST_CAP = 65536;
+uint32_t refine_first_cap() { return REFINE_FIRST_CAP; }
 
 size_t refine_block_entries() { return REFINE_BLOCK; }
 uint32_t refine_small_k() { return SMALL_K; }
@@ -1189,7 +1189,7 @@ refine_scan_kernel(int64_t nblk, uint32_t* __restrict__ blk_cnt, uint32_t* count
 __global__ void __launch_bounds__(REFINE_THREADS)
 refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
                    const uint32_t* __restrict__ tab_min, const uint32_t* __restrict__ blk_off,
-                   uint32_t* __restrict__ tab_lab, const uint32_t* __restrict__ counters) {
+                   uint32_t* __restrict__ tab_lab, const uint32_t* __restrict__ counters, uint32_t* __restrict__ first_idx) {
     __shared__ int wsum[REFINE_THREADS / 64];
     if (counters[0] <= SMALL_K) return;
     const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
@@ -1212,7 +1212,11 @@ refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
         uint32_t lab = blk_off[blk] + (uint32_t)excl;
 #pragma unroll
         for (int q = 0; q < REFINE_PER_THREAD; ++q)
-            if (flags[q]) tab_lab[slots[q]] = ++lab;
+            if (flags[q]) {
+                tab_lab[slots[q]] = ++lab;
+                // first occurrence of class `lab` (its class representative for verify_* below)
+                if (first_idx && lab <= REFINE_FIRST_CAP) first_idx[lab - 1] = (uint32_t)(blk * REFINE_BLOCK + (int64_t)threadIdx.x * REFINE_PER_THREAD + q);
+            }
         __syncthreads();
     }
 }
@@ -1220,7 +1224,7 @@ refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
 // <= SMALL_K classes: label of a class = 1 + number of classes with a smaller first index
 __global__ void __launch_bounds__(1024)
 refine_small_rank_kernel(const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ tab_lab,
-                         uint32_t* __restrict__ counters) {
+                         uint32_t* __restrict__ counters, uint32_t* __restrict__ first_idx) {
     __shared__ uint32_t s_min[SMALL_K];
     const uint32_t K = counters[0];
     if (K > SMALL_K) return;
@@ -1236,6 +1240,7 @@ refine_small_rank_kernel(const uint32_t* __restrict__ tab_min, uint32_t* __restr
         uint32_t rank = 0;
         for (uint32_t j = 0; j < K; ++j) rank += (s_min[j] < mine);
         tab_lab[slot] = rank + 1;
+        if (first_idx) first_idx[rank] = mine;  // K <= SMALL_K <= REFINE_FIRST_CAP
     }
     if (i == 0) counters[2] = K;
 }
@@ -1400,8 +1405,7 @@ __global__ void sig_joint_lower_kernel(int n, int64_t ld, int r, int T, const do
             const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
             double p = 0;
             for (int k = 0; k < r; ++k) p = fma(U[(int64_t)k * len + e], coef[k], p);
-            const double y = sdpsr_clamp_round(x - p, atol, scale);
-            const uint64_t kb = (uint64_t)__double_as_longlong(y);
+            const uint64_t kb = sdpsr_round_key(x - p, atol, scale);
             const int32_t* Cij = C + (int64_t)j * ld + i;
             uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
             bool allz = kb == 0;
@@ -1413,6 +1417,127 @@ __global__ void sig_joint_lower_kernel(int n, int64_t ld, int r, int T, const do
             sig[poff + i] = finish_sig(l, allz, h);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// "Does this step split any class?" without a relabel.  A refinement that ends with the dimension it
+// started with (every confirm round; the first iteration on an already closed partition) leaves the
+// labels as they are, so the insert / rank / label passes only establish that nothing changed.  That
+// question needs no hash table: with the first-occurrence index of every class at hand (first_idx,
+// written by the ranking pass of the refinement that made the labels) a tiny kernel evaluates the
+// step's values at the class representatives, and one streaming pass compares every entry with the
+// representative of its class -- raw values (rounded projection, channel products), no signature
+// hashing, no atomics; flag[0] = 1 as soon as some entry differs (the caller then runs the full
+// refinement).  Packed lower triangle, int32 channels (the default loop).
+// ---------------------------------------------------------------------------
+struct VerifyRef {  // one per class: the step's values at the class representative
+    double x;        // the class's uniform draw (depends on the label only)
+    uint64_t ybits;  // code of the rounded projected value there (sdpsr_round_key)
+    int32_t c[4];    // channel products there
+};
+template <int R, int T, bool JOINT>
+__global__ void verify_ref_kernel(int n, int64_t ld, int d, const uint32_t* __restrict__ first_idx, const double* __restrict__ U,
+                                  uint64_t key, const double* __restrict__ coef, double atol, double scale,
+                                  const int32_t* __restrict__ C, VerifyRef* __restrict__ ref, uint32_t* __restrict__ flag) {
+    const int cls = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cls == 0) flag[0] = 0u;  // the verdict of the compare pass that follows in stream order
+    if (cls >= d) return;
+    uint32_t i, j;
+    packed_lower_ij(n, (int64_t)first_idx[cls], i, j);
+    const int64_t ef = (int64_t)i + (int64_t)j * n;
+    VerifyRef r;
+    r.x = 0;
+    r.ybits = 0;
+    if (JOINT) {
+        r.x = sdpsr_class_uniform(key, (uint32_t)cls + 1u);
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) p = fma(U[(int64_t)k * n * n + ef], coef[k], p);
+        r.ybits = sdpsr_round_key(r.x - p, atol, scale);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r.c[t] = t < T ? C[(int64_t)t * ld * ld + (int64_t)j * ld + i] : 0;
+    ref[cls] = r;
+}
+template <int R, int T, bool JOINT>
+__global__ void __launch_bounds__(256)
+verify_lower_kernel(int n, int64_t ld, const uint32_t* __restrict__ Lp, const double* __restrict__ U, const double* __restrict__ coef,
+                    double atol, double scale, const int32_t* __restrict__ C, const VerifyRef* __restrict__ ref,
+                    uint32_t* __restrict__ flag) {
+    bool bad = false;
+    double cf[R > 0 ? R : 1];
+#pragma unroll
+    for (int k = 0; k < R; ++k) cf[k] = coef[k];
+    const int64_t nn = (int64_t)n * n;
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        const int64_t poff = (int64_t)j * n - (int64_t)j * (j - 1) / 2 - j;
+        const uint32_t* Lj = Lp + poff;
+        const int32_t* Cj = C + (int64_t)j * ld;
+        const double* Uj = U + (int64_t)j * n;
+#pragma unroll 2
+        for (int i = j + threadIdx.x; i < n; i += 256) {
+            const uint32_t l = __builtin_nontemporal_load(&Lj[i]);
+            int32_t c[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) c[t] = __builtin_nontemporal_load(&Cj[(int64_t)t * ld * ld + i]);
+            double u[R > 0 ? R : 1];
+            if (JOINT) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) u[k] = __builtin_nontemporal_load(&Uj[(int64_t)k * nn + i]);
+            }
+            VerifyRef r;
+            r.x = 0;
+            r.ybits = 0;
+            r.c[0] = r.c[1] = r.c[2] = r.c[3] = 0;
+            if (l) r = ref[l - 1];  // label 0: the zero class stays together only while every value is zero
+            if (JOINT) {
+                double p = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) p = fma(u[k], cf[k], p);
+                const uint64_t yb = sdpsr_round_key(r.x - p, atol, scale);
+                bad = bad || yb != r.ybits;
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) bad = bad || c[t] != r.c[t];
+        }
+    }
+    if (bad) flag[0] = 1u;
+}
+
+template <int R, int T, bool JOINT>
+static void launch_verify_rt(hipStream_t s, const SigSource& q, int64_t d, const uint32_t* first_idx, void* ref, uint32_t* flag) {
+    const int n = (int)q.n;
+    verify_ref_kernel<R, T, JOINT><<<(unsigned)((d + 255) / 256), 256, 0, s>>>(n, q.ld, (int)d, first_idx, q.U, q.key, q.coef, q.atol, q.scale,
+                                                                             (const int32_t*)q.C, (VerifyRef*)ref, flag);
+    const int g = n < 256 * 8 ? n : 256 * 8;
+    verify_lower_kernel<R, T, JOINT><<<g, 256, 0, s>>>(n, q.ld, q.L, q.U, q.coef, q.atol, q.scale, (const int32_t*)q.C,
+                                                      (const VerifyRef*)ref, flag);
+}
+size_t verify_ref_bytes(int64_t d) { return (size_t)(d > 0 ? d : 1) * sizeof(VerifyRef); }
+// q: SIG_JOINT_I32 or SIG_CHAN_I32 on the packed lower triangle with packed labels (q.L = Lp); flag[0] = verdict.
+// Returns false when there is no instance for the shape (the caller runs the refinement).
+bool launch_verify_no_split(hipStream_t s, const SigSource& q, int64_t d, const uint32_t* first_idx, void* ref, uint32_t* flag) {
+    if (!q.packed || !q.lab_packed || d < 1 || d > (int64_t)REFINE_FIRST_CAP || (q.T != 2 && q.T != 4)) return false;
+    if (q.kind == SIG_CHAN_I32) {
+        if (q.T == 2) launch_verify_rt<0, 2, false>(s, q, d, first_idx, ref, flag);
+        else launch_verify_rt<0, 4, false>(s, q, d, first_idx, ref, flag);
+        return true;
+    }
+    if (q.kind != SIG_JOINT_I32 || q.r < 0 || q.r > 4) return false;
+#define SDPSR_VERIFY_CASE(RR)                                                       \
+    case RR:                                                                        \
+        if (q.T == 2) launch_verify_rt<RR, 2, true>(s, q, d, first_idx, ref, flag); \
+        else launch_verify_rt<RR, 4, true>(s, q, d, first_idx, ref, flag);          \
+        break;
+    switch (q.r) {
+        SDPSR_VERIFY_CASE(0)
+        SDPSR_VERIFY_CASE(1)
+        SDPSR_VERIFY_CASE(2)
+        SDPSR_VERIFY_CASE(3)
+        SDPSR_VERIFY_CASE(4)
+    }
+#undef SDPSR_VERIFY_CASE
+    return true;
 }
 
 bool sig_source_fusable(const SigSource& q) {
@@ -1505,12 +1630,12 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
     // launches the one-workgroup ranking only; it checks counters[0] afterwards and repeats the
     // pass with expect_small = 0 on a misprediction (the three general kernels would exit at once
     // anyway, but three empty launches cost ~15 us of a ~150 us refinement)
-    refine_small_rank_kernel<<<1, 1024, 0, s>>>(ws.tab_min, ws.tab_lab, ws.counters);
+    refine_small_rank_kernel<<<1, 1024, 0, s>>>(ws.tab_min, ws.tab_lab, ws.counters, ws.first_idx);
     if (!ws.expect_small) {
         refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt, ws.counters);
         refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
         refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt,
-                                                         ws.tab_lab, ws.counters);
+                                                         ws.tab_lab, ws.counters, ws.first_idx);
     }
     if (sym_n > 0 && sym_n * sym_n == len) {  // labels of an n x n matrix: the symmetry verdict comes with the label pass
         const unsigned t = (unsigned)((sym_n + 63) / 64);

@@ -14,14 +14,16 @@
 
 using namespace sdpsr;
 
-extern "C" {
-
 // ---------------------------------------------------------------------------
 // admissible_subspace loop, src/partitions.jl:145-185
 // ---------------------------------------------------------------------------
-int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L,
-                              const double* U, int64_t r, double atol, uint32_t* P_out,
-                              int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem) {
+namespace sdpsr {
+// mem_in: where CL / X0L / U live; mem_out: where P_out lives.  final_sync = false (sdpsr_jordan_reduce):
+// return with the last launches (the unpack of the packed labels) still in flight on ctx's stream -- the
+// caller keeps enqueueing; *labels_sym_out = 1 if the labels written are symmetric by construction.
+int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r, double atol,
+                             uint32_t* P_out, int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem, int mem_out,
+                             bool final_sync, int* labels_sym_out) {
     CHECK_CTX(c);
     const int hint = c->hint_symmetric_basis;  // one call only, whatever happens below
     c->hint_symmetric_basis = 0;
@@ -38,7 +40,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     const double* dCL = in_dev(c, "adm_cl", CL, len, mem, &st);
     const double* dX0 = in_dev(c, "adm_x0", X0L, len, mem, &st);
     const double* dU = in_dev(c, "adm_u", U, (size_t)len * std::max<int64_t>(r, 1), mem, &st);
-    uint32_t* L = out_dev(c, "adm_labels", P_out, len, mem, &st);
+    uint32_t* L = out_dev(c, "adm_labels", P_out, len, mem_out, &st);
     uint64_t* sig = (uint64_t*)ctx_buf(c, "sig", len * 8);
     const int nblk = 2048;
     double* partial = (double*)ctx_buf(c, "proj_partial", (size_t)2 * std::max<int64_t>(r, 1) * nblk * 8);  // + the symmetry probes
@@ -158,6 +160,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
             launch_proj_coef_lower(s, n, r, dU, jl ? Lp : L, jl ? 1 : 0, key, partial, nblk, coef);
             tm.end();
             int64_t dj = current;
+            bool confirming = false;  // this round repeats the square after a round that did not refine
             for (;;) {
                 tm.begin(SDPSR_T_SQUARE);
                 const uint64_t key2 = next_key(c);
@@ -183,7 +186,30 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
                 qj.packed = 1;
                 qj.L = jl2 ? Lp : L;
                 qj.lab_packed = jl2 ? 1 : 0;
-                st = refine_signatures(c, lenp, qj, Lp, &dj);
+                // Rounds that are expected NOT to refine -- a confirm round, and the first iteration (an
+                // input that is closed already) -- first ask the cheap question "does any entry differ
+                // from the representative of its class?" (one streaming compare pass, kernels_partition.hip
+                // verify_*); only a yes runs the insert / rank / label passes.  A confirm round re-checks
+                // the channels only: its projected element is the one the previous round has cleared.
+                bool unchanged = false;
+                if ((it == 1 || confirming) && jl2 && c->first_idx_labels == Lp && current >= 1 && current <= (int64_t)refine_first_cap() &&
+                    !(c->opts.flags & SDPSR_FLAG_NO_VERIFY_SHORTCUT)) {
+                    SigSource qv = qj;
+                    if (confirming) qv.kind = SIG_CHAN_I32;
+                    uint32_t* vflag = (uint32_t*)ctx_buf(c, "adm_vflag", 64);
+                    void* vref = ctx_buf(c, "adm_vref", verify_ref_bytes(current));
+                    const uint32_t* first = (const uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
+                    uint32_t* hv = (uint32_t*)ctx_pinned(c, 64);
+                    if (!vflag || !vref || !first || !hv) return SDPSR_OUT_OF_MEMORY;
+                    if (launch_verify_no_split(s, qv, current, first, vref, vflag)) {
+                        HIP_TRY(c, hipMemcpyAsync(hv, vflag, 4, hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipStreamSynchronize(s));
+                        HIP_TRY(c, hipGetLastError());
+                        unchanged = hv[0] == 0;
+                    }
+                }
+                if (unchanged) dj = current;  // labels, class representatives and table hints stay as they are
+                else st = refine_signatures(c, lenp, qj, Lp, &dj);
                 packed_valid = true;
                 full_valid = false;
                 tm.end();
@@ -191,6 +217,7 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
                 tm.collect();
                 if (dj == current && confirm_left > 0) {  // extra independent draws before stopping
                     --confirm_left;
+                    confirming = true;
                     continue;  // (same projected element, a fresh square: the projection did not refine either)
                 }
                 break;
@@ -375,8 +402,11 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     HIP_TRY(c, hipGetLastError());
     *dim_out = current;
     if (iters_out) *iters_out = it;
-    st = out_finish(c, P_out, L, len, mem);
-    if (st) return st;
+    if (labels_sym_out) *labels_sym_out = labels_sym;
+    if (final_sync || mem_out != SDPSR_MEM_DEVICE) {
+        st = out_finish(c, P_out, L, len, mem_out);
+        if (st) return st;
+    }
     if (phase_ms) {
         const float ms = ev_total.stop(s);
         tm.collect();
@@ -385,6 +415,15 @@ int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const d
     }
     if (!converged) return ctx_fail(c, SDPSR_NOT_CONVERGED, "max_iters reached");
     return SDPSR_OK;
+}
+}  // namespace sdpsr
+
+extern "C" {
+
+int sdpsr_admissible_subspace(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L,
+                              const double* U, int64_t r, double atol, uint32_t* P_out,
+                              int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem) {
+    return admissible_subspace_impl(c, n, CL, X0L, U, r, atol, P_out, dim_out, iters_out, phase_ms, mem, mem, true, nullptr);
 }
 
 // desymmetrize, src/partitions.jl:197-223

@@ -46,6 +46,7 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
     const int64_t nblk = (len + rb - 1) / rb;
     int attempts = 0;
     bool mispredicted = false;
+    c->first_idx_labels = nullptr;  // whatever happens below, the old representatives no longer describe `labels`
     // many-classes regime (problems without symmetry: ~len/2 distinct signatures): a hash table
     // that large means one global atomic per entry into memory no cache holds; the radix-sort
     // relabel (kernels_refine_sort.hip) moves ~15x the algorithmic bytes but streams.  Taken when
@@ -81,7 +82,8 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         ws.tab_lab = (uint32_t*)ctx_buf(c, "ref_tab_lab", cap * 4);
         ws.blk_cnt = (uint32_t*)ctx_buf(c, "ref_blk_cnt", (nblk + 1) * 4);
         ws.counters = (uint32_t*)ctx_buf(c, "ref_counters", refine_counters_bytes());
-        if (!ws.tab_sig || !ws.tab_min || !ws.tab_lab || !ws.blk_cnt || !ws.counters)
+        ws.first_idx = (uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
+        if (!ws.tab_sig || !ws.tab_min || !ws.tab_lab || !ws.blk_cnt || !ws.counters || !ws.first_idx)
             return SDPSR_OUT_OF_MEMORY;
         ws.log2cap = log2cap;
         ws.nblk = (int)nblk;
@@ -117,6 +119,7 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         }
         *nparts = h[2];
         c->table_log2_hint = std::min(full, std::max(12, ceil_log2((uint64_t)h[2] * 8 + 1)));
+        if (h[2] <= refine_first_cap()) c->first_idx_labels = labels;  // "ref_first" describes these labels
         return SDPSR_OK;
     }
 }

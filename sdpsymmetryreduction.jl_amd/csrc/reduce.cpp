@@ -1,0 +1,56 @@
+// One reduction in one call: admissible_subspace (src/partitions.jl:109-190) followed by
+// blockDiagonalize (src/compat.jl:46-68) on its result, the partition never leaving the device and
+// the host never waiting between the stages (the three separate entry points each return with their
+// outputs complete, include/sdpsr.h: two host synchronisations and one label copy + symmetry pass per
+// reduction that a caller who wants both results does not need).
+#include <algorithm>
+#include <cstring>
+
+#include "host_internal.h"
+
+using namespace sdpsr;
+
+extern "C" int sdpsr_jordan_reduce(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r,
+                                   double atol, double epsilon, uint32_t* P_out, int64_t* dim_out, int32_t* iters_out,
+                                   int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks, int64_t blks_capacity,
+                                   double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem) {
+    CHECK_CTX(c);
+    if (!dim_out || n < 1 || !(epsilon > 0) || blks_capacity < 0 || qhat_capacity < 0 || (blks_capacity > 0 && !blks) ||
+        (qhat_capacity > 0 && !Q_hat))
+        return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    // the partition is formed in the buffer blockDiagonalize keeps its labels in
+    uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", (size_t)len * 4);
+    if (!L) return SDPSR_OUT_OF_MEMORY;
+    c->bd_valid = false;
+    c->bd_q_valid = false;
+    double pm_a[SDPSR_T_COUNT] = {}, pm_b[SDPSR_T_COUNT] = {}, pm_i[SDPSR_T_COUNT] = {};
+    int labels_sym = 0;
+    st = admissible_subspace_impl(c, n, CL, X0L, U, r, atol, L, dim_out, iters_out, phase_ms ? pm_a : nullptr, mem, SDPSR_MEM_DEVICE,
+                                  /*final_sync=*/false, &labels_sym);
+    const int st_loop = st;
+    if (st && st != SDPSR_NOT_CONVERGED) return st;
+    if (P_out)  // stream-ordered; complete when the call returns (it ends with a synchronisation on every path)
+        HIP_TRY(c, hipMemcpyAsync(P_out, L, (size_t)len * 4, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    const int64_t d = *dim_out;
+    int32_t nb = 0;
+    int64_t S = 0, S1 = 0;
+    st = block_diagonalize_impl(c, n, L, d, epsilon, &nb, &S, &S1, phase_ms ? pm_b : nullptr, SDPSR_MEM_DEVICE, labels_sym != 0,
+                                /*final_sync=*/false);
+    if (nblocks) *nblocks = nb;
+    if (sum_sq) *sum_sq = S;
+    if (sum_s) *sum_s = S1;
+    if (st == SDPSR_OK && blks && d * S <= blks_capacity && (!Q_hat || n * S1 <= qhat_capacity)) {
+        st = sdpsr_block_images(c, blks, (Q_hat && n * S1 <= qhat_capacity) ? Q_hat : nullptr, phase_ms ? pm_i : nullptr, mem);  // ends synchronised
+    } else {
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess && st == SDPSR_OK) st = ctx_fail(c, SDPSR_HIP_ERROR, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+    if (phase_ms) {
+        for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = pm_a[i] + pm_b[i] + pm_i[i];
+    }
+    return st ? st : st_loop;
+}

@@ -75,3 +75,34 @@ SDPSR_HD double sdpsr_clamp_round(double a, double atol, double scale) {
     return __builtin_ldexp(y, e);
 #endif
 }
+
+// The same rule as an injective 64-bit CODE of the rounded value, for signatures: 0 for |a| < atol,
+// else (k, e) with k = the rounded / truncated scaled mantissa (|k| in [|scale| / 2, |scale|)) and e the
+// binary exponent, packed as a 52-bit and a 12-bit two's complement field.
+// Two inputs get the same code exactly when sdpsr_clamp_round gives them the same double (k / scale
+// is strictly monotone in k; a mantissa that rounds up to 1.0 is folded onto 0.5 * 2^(e+1), the same
+// double) -- so classes formed from the codes are the classes of the rounded values, without the
+// fp64 division and the ldexp per entry that the value itself costs.
+SDPSR_HD uint64_t sdpsr_round_key(double a, double atol, double scale) {
+    double aa = a < 0 ? -a : a;
+    if (aa < atol) return 0ull;
+    const bool trunc_mode = scale < 0;
+    const double sc = trunc_mode ? -scale : scale;
+    int e;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double x = frexp(a, &e);
+    const double t = sc * x;
+    double kd = trunc_mode ? trunc(t) : rint(t);
+#else
+    const double x = __builtin_frexp(a, &e);
+    const double t = sc * x;
+    double kd = trunc_mode ? __builtin_trunc(t) : __builtin_rint(t);
+#endif
+    if (kd == sc || kd == -sc) {  // mantissa rounded up to 1.0: the same double as 0.5 * 2^(e+1)
+        kd *= 0.5;
+        e += 1;
+    }
+    // |k| <= 1e15 < 2^51 for every sigdigits <= 15; e in [-1074, 1025]: 52 + 12 bits, two's complement fields
+    return ((uint64_t)(int64_t)kd & ((1ull << 52) - 1)) | ((uint64_t)((uint32_t)e & 0xFFFu) << 52);
+}
+

@@ -55,7 +55,11 @@ struct sdpsr_ctx {
     bool bdc_valid = false;
     uint32_t bd_sym_epoch = 0;            // != 0: "bd_symflag"[0] == epoch <=> bd_sym_labels are NOT symmetric (copy + check pass of blockDiagonalize)
     const uint32_t* bd_sym_labels = nullptr;
+    const uint32_t* bd_trusted_symmetric = nullptr;  // labels the library made itself and knows to be symmetric (sdpsr_jordan_reduce)
     uint32_t epoch_counter = 0;
+    // "ref_first"[l - 1] = first-occurrence index of class l in the label array `first_idx_labels` (written by the
+    // ranking pass of the refinement that made those labels); nullptr = not available (sort path, other arrays)
+    const uint32_t* first_idx_labels = nullptr;
     int hint_symmetric_basis = 0;         // sdpsr_hint_symmetric_basis: applies to the next admissible_subspace call
     std::vector<int64_t> adm_dims;        // dimension trajectory of the last admissible_subspace call (sdpsr_dimension_trajectory)
     bool bd_q_valid = false;  // "bd_qhat" holds Q_hat of the last diagonalize (even when check_block_sizes failed)
@@ -142,6 +146,7 @@ struct RefineWs {
     uint32_t* tab_lab;   // cap
     uint32_t* blk_cnt;   // nblk + 1
     int expect_small = 0;  // host prediction: <= refine_small_k() classes (see launch_refine)
+    uint32_t* first_idx = nullptr;  // optional: first-occurrence index of class l at [l - 1], l <= refine_first_cap()
     uint32_t* counters;  // [0] = inserted, [1] = overflow flag, [2] = nparts, [16..] slot list (refine_counters_bytes())
     int log2cap;
     int nblk;
@@ -170,6 +175,9 @@ struct SigSource {
     const uint32_t* zero_flag = nullptr;                          // device constant 0 when packed (the kernels' "lower" flag)
 };
 bool sig_source_fusable(const SigSource& q);
+uint32_t refine_first_cap();
+size_t verify_ref_bytes(int64_t d);
+bool launch_verify_no_split(hipStream_t s, const SigSource& q, int64_t d, const uint32_t* first_idx, void* ref, uint32_t* flag);
 void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint64_t* sig);
 // slot: len entries of scratch; labels_out may alias q.L (it is written only by a pass that succeeded)
 // sym_n > 0 (and len == sym_n^2): the label pass also checks the new labels for symmetry, counters[3] = 1 if NOT symmetric

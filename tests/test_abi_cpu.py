@@ -38,7 +38,7 @@ def test_opts_struct_layout(pkg):
                       ("ALWAYS_REORTHOGONALIZE", L.FLAG_ALWAYS_REORTHOGONALIZE), ("REFINE_NO_FUSE", L.FLAG_REFINE_NO_FUSE),
                       ("UNPACK_EVERY_STEP", L.FLAG_UNPACK_EVERY_STEP), ("SPMM_ONE_BY_ONE", L.FLAG_SPMM_ONE_BY_ONE),
                       ("SINGLE_COUPLING_ELEMENT", L.FLAG_SINGLE_COUPLING_ELEMENT), ("SMALL_EIGEN_ON_DEVICE", L.FLAG_SMALL_EIGEN_ON_DEVICE),
-                      ("NO_GRAPH", L.FLAG_NO_GRAPH)):
+                      ("NO_GRAPH", L.FLAG_NO_GRAPH), ("NO_VERIFY_SHORTCUT", L.FLAG_NO_VERIFY_SHORTCUT)):
         m = re.search(r"SDPSR_FLAG_%s = 1u << (\d+)" % name, hdr)
         assert m and (1 << int(m.group(1))) == val, name
 
@@ -105,6 +105,54 @@ def test_hash_header_compiles_for_host_and_matches_python():
     assert float(out[5]) == ref_round(0.0625 * (1 - 2e-16), True) < 0.0625
     assert float(out[6]) == ref_round(0.7654321987, False) and float(out[7]) == ref_round(0.7654321987, True)
     assert float(out[6]) != float(out[7])
+
+
+def test_round_key_is_injective_on_rounded_values():
+    """sdpsr_round_key (signatures of rounded values without the division / ldexp): two inputs get the same code
+    exactly when sdpsr_clamp_round gives them the same double -- both rounding rules, mantissas that round up to
+    1.0, sign, the atol cut, several atol."""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = r'''
+    #include <stdio.h>
+    #include <string.h>
+    #include <stdlib.h>
+    #include <map>
+    #include <math.h>
+    #include "sdpsr_hash.h"
+    int main(){
+      const double atols[3] = {1.4901161193847656e-8, 1e-12, 1e-3};
+      unsigned long long z = 12345; long bad = 0, n = 0;
+      for (int ai = 0; ai < 3; ++ai) for (int mode = 0; mode < 2; ++mode) {
+        const double atol = atols[ai];
+        double sc = 1; for (int i = 0; i < (ai == 0 ? 7 : (ai == 1 ? 12 : 3)); ++i) sc *= 10;
+        if (mode) sc = -sc;
+        std::map<unsigned long long, unsigned long long> k2v, v2k;
+        for (int t = 0; t < 400000; ++t) {
+          z = sdpsr_fmix64(z + 0x9E3779B97F4A7C15ULL);
+          double m = 0.5 + (double)(z >> 11) * (1.0 / 9007199254740992.0) * 0.5;   // [0.5, 1)
+          if (t % 7 == 0) m = 1.0 - (double)(z & 1023) * 1e-9;                     // hugging 1.0 from below
+          if (t % 11 == 0) m = 0.5 + (double)(z & 1023) * 1e-10;                   // hugging 0.5
+          int e = (int)((z >> 3) % 60) - 40;
+          double a = ldexp(m, e); if (z & 4) a = -a;
+          double v = sdpsr_clamp_round(a, atol, sc); unsigned long long vb; memcpy(&vb, &v, 8);
+          unsigned long long k = sdpsr_round_key(a, atol, sc);
+          if ((k == 0) != (vb == 0)) ++bad;
+          auto it = k2v.find(k); if (it == k2v.end()) k2v[k] = vb; else if (it->second != vb) ++bad;
+          auto jt = v2k.find(vb); if (jt == v2k.end()) v2k[vb] = k; else if (jt->second != k) ++bad;
+          ++n;
+        }
+      }
+      printf("%ld %ld\n", n, bad); return 0; }
+    '''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-O2", "-I", os.path.join(root, "sdpsymmetryreduction.jl_amd", "csrc"),
+                               os.path.join(d, "t.cpp"), "-o", os.path.join(d, "t")])
+        n, bad = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    assert int(n) == 2400000 and int(bad) == 0
 
 
 def test_product_path_never_touches_the_oracle():

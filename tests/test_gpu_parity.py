@@ -1088,3 +1088,103 @@ def test_small_compressed_problem_host_and_device_paths(pkg, problems, oracle, g
             for i in range(0, d, max(1, d // 5)):
                 for k in range(len(bd.blkSizes)):
                     assert np.allclose(bd.blks[i][k], ref[i][k], atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["petersen", "er5", "er7", "esc16j", "circ256"])
+def test_verify_shortcut_agrees_with_full_refinement(pkg, problems, golden, name):
+    """Rounds expected not to refine (confirm rounds, the first iteration) compare every entry with its class
+    representative before running a refinement; with SDPSR_FLAG_NO_VERIFY_SHORTCUT every round refines.  Same
+    canonical matrix, same iteration count, same dimension trajectory -- on inputs whose first iteration splits
+    (theta' problems: the shortcut says "differs" and the refinement runs) and on an already closed one (circ256:
+    neither the first iteration nor the confirm round relabels anything)."""
+    if name == "circ256":
+        Lg = golden["circ256_P"].astype(np.int64)
+        Cv, A, b = problems.partition_as_sdp(Lg, seed=1)
+    else:
+        Lg = golden[f"{name}_P"]
+        Cv, A, b = _problem(problems, name)
+    setup = pkg.admissible_setup(Cv, A, b)
+    outs = []
+    for flags in (0, pkg._lib.FLAG_NO_VERIFY_SHORTCUT):
+        for seed in (1, 2, 3):
+            with pkg.Context(seed=seed, flags=flags) as ctx:
+                P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)
+                outs.append((P.iterations, tuple(P.dims)))
+                assert np.array_equal(P.matrix, Lg), (name, flags, seed)
+    assert len(set(outs)) == 1, outs
+
+
+@pytest.mark.parametrize("name", ["er7", "esc16j", "circ256"])
+def test_jordan_reduce_equals_the_three_calls(pkg, problems, oracle, golden, name):
+    """sdpsr_jordan_reduce = admissible_subspace + blockDiagonalize + basis_image in one stream-ordered call:
+    same canonical partition, pinned block sizes, blks == Q_k' 1[P==i] Q_k for the Q_hat it returns; the capacity
+    protocol (sizes only -> sdpsr_block_images afterwards) and host / device memory spaces."""
+    import torch
+    if name == "circ256":
+        Lg = golden["circ256_P"].astype(np.int64)
+        Cv, A, b = problems.partition_as_sdp(Lg, seed=1)
+    else:
+        Lg = golden[f"{name}_P"].astype(np.int64)
+        Cv, A, b = _problem(problems, name)
+    expect = list(golden[f"{name}_blk"])
+    setup = pkg.admissible_setup(Cv, A, b)
+    n, CL, X0L, U = setup
+    Uf = np.asfortranarray(U)
+    r = U.shape[1]
+    d = int(Lg.max())
+    Po = oracle.Partition(d, Lg)
+    L = pkg._lib
+    for mem in (L.MEM_HOST, L.MEM_DEVICE):
+        with pkg.Context(seed=5) as ctx:
+            lib = ctx._lib
+            if mem == L.MEM_DEVICE:
+                tCL, tX0 = torch.from_numpy(CL).cuda(), torch.from_numpy(X0L).cuda()
+                tU = torch.from_numpy(np.ascontiguousarray(U.T)).cuda()
+                tP = torch.empty(n * n, dtype=torch.int32, device="cuda")
+                args = [C.c_void_p(t.data_ptr()) for t in (tCL, tX0, tU)]
+                pP = C.c_void_p(tP.data_ptr())
+            else:
+                P = np.zeros(n * n, dtype=np.uint32)
+                args = [C.c_void_p(a.ctypes.data) for a in (CL, X0L, Uf)]
+                pP = C.c_void_p(P.ctypes.data)
+            dd, it, nb, ssq, ss = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int64(0)
+            ms = (C.c_double * L.T_COUNT)()
+            if setup.hint:
+                lib.sdpsr_hint_symmetric_basis(ctx._h, setup.hint)
+            # sizes only
+            ctx.check(lib.sdpsr_jordan_reduce(ctx._h, n, *args, r, pkg.api.RTOL_DEFAULT, pkg.api.RTOL_DEFAULT, pP, C.byref(dd), C.byref(it), C.byref(nb),
+                                              C.byref(ssq), C.byref(ss), None, 0, None, 0, C.cast(ms, C.c_void_p), mem))
+            assert dd.value == d and ms[L.T_TOTAL] > 0
+            sizes = np.zeros(nb.value, dtype=np.int32)
+            ctx.check(lib.sdpsr_block_sizes(ctx._h, sizes.ctypes.data_as(C.c_void_p)))
+            assert sorted(int(x) for x in sizes) == expect
+            S, S1 = ssq.value, ss.value
+            got = (tP.cpu().numpy().view(np.uint32) if mem == L.MEM_DEVICE else P).reshape(n, n, order="F")
+            assert np.array_equal(got, Lg)
+            # images in the same call (capacity given), again with fresh generic elements
+            if mem == L.MEM_DEVICE:
+                tb = torch.empty(d * S, dtype=torch.float64, device="cuda")
+                tq = torch.empty(n * S1, dtype=torch.float64, device="cuda")
+                pb, pq = C.c_void_p(tb.data_ptr()), C.c_void_p(tq.data_ptr())
+            else:
+                hb, hq = np.zeros(d * S), np.zeros(n * S1)
+                pb, pq = C.c_void_p(hb.ctypes.data), C.c_void_p(hq.ctypes.data)
+            if setup.hint:
+                lib.sdpsr_hint_symmetric_basis(ctx._h, setup.hint)
+            for attempt in range(4):
+                st = lib.sdpsr_jordan_reduce(ctx._h, n, *args, r, pkg.api.RTOL_DEFAULT, pkg.api.RTOL_DEFAULT, None, C.byref(dd), C.byref(it), C.byref(nb),
+                                             C.byref(ssq), C.byref(ss), pb, d * S, pq, n * S1, None, mem)
+                if st not in (2, 3):
+                    break
+            ctx.check(st)
+            assert (ssq.value, ss.value) == (S, S1)
+            ctx.check(lib.sdpsr_block_sizes(ctx._h, sizes.ctypes.data_as(C.c_void_p)))
+            blks = (tb.cpu().numpy() if mem == L.MEM_DEVICE else hb).reshape(d, S)
+            Q = (tq.cpu().numpy() if mem == L.MEM_DEVICE else hq).reshape(n, S1, order="F")
+            cols = np.concatenate([[0], np.cumsum(sizes)])
+            offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64) ** 2)])
+            Qs = [Q[:, cols[k]:cols[k + 1]] for k in range(len(sizes))]
+            ref = oracle.basis_image_fast(Qs, Po)
+            for i in range(d):
+                for k in range(len(sizes)):
+                    assert np.allclose(blks[i, offs[k]:offs[k + 1]].reshape(sizes[k], sizes[k], order="F"), ref[i][k], atol=1e-9)

@@ -1,6 +1,6 @@
 """Failure rate of the randomized blockDiagonalize on ER(7) (x) K_k (blocks [2,2,2,2,3] twice):
 the CPU oracle (reference-literal restatement) and the device path on the SAME partition.
-usage: bd_failure_compare.py oracle|device [k] [runs]"""
+usage: bd_failure_compare.py oracle|device [k] [runs] [eig_driver] [flags]"""
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,8 +27,9 @@ if who == "oracle":
             fails[type(e).__name__] = fails.get(type(e).__name__, 0) + 1
 else:
     drv = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # sdpsr_opts.flags, e.g. 64 = SDPSR_FLAG_SINGLE_COUPLING_ELEMENT
     P = pkg.Partition(d, L.astype(np.uint32))
-    with pkg.Context(seed=77, eig_driver=drv) as ctx:
+    with pkg.Context(seed=77, eig_driver=drv, flags=flags) as ctx:
         for s in range(runs):
             try:
                 bd = pkg.blockDiagonalize(P, ctx=ctx)
@@ -37,4 +38,4 @@ else:
                     print("run", s, "sizes", sorted(bd.blkSizes), flush=True)
             except pkg.SdpsrError as e:
                 fails[type(e).__name__] = fails.get(type(e).__name__, 0) + 1
-print(who, "N", L.shape[0], "dim", d, "runs", runs, "failures", fails, "%.1f s" % (time.time() - t0))
+print(who, " ".join(sys.argv[2:]), "N", L.shape[0], "dim", d, "runs", runs, "failures", fails, "%.1f s" % (time.time() - t0))

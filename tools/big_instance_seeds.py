@@ -12,6 +12,8 @@ Lm = import_module(pkg.__name__ + "._lib")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 use_hint = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # sdpsr_opts.flags for A/B sweeps
+channels = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = torch.device("cuda:0")
 gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_partitions.npz"))["er7_P"].astype(np.int64)
 for name, prob in (("theta_c32xk128", lambda: pr.theta_prime_product_problem(pr.cycle_adjacency(32), pr.symmetric_circulant_labels(32), 128, seed=1)),
@@ -26,7 +28,7 @@ for name, prob in (("theta_c32xk128", lambda: pr.theta_prime_product_problem(pr.
     golden = torch.from_numpy(np.ascontiguousarray(Ls.ravel(order="F")).astype(np.int32)).to(dev)
     bad, iters = 0, collections.Counter()
     for seed in range(nseeds):
-        with pkg.Context(seed=7000 + seed) as ctx:
+        with pkg.Context(seed=7000 + seed, flags=flags, channels=channels) as ctx:
             dd, it = C.c_int64(0), C.c_int32(0)
             if use_hint and setup.hint:
                 ctx._lib.sdpsr_hint_symmetric_basis(ctx._h, setup.hint)
@@ -36,4 +38,4 @@ for name, prob in (("theta_c32xk128", lambda: pr.theta_prime_product_problem(pr.
             iters[it.value] += 1
             if dd.value != d or not bool((tP == golden).all()):
                 bad += 1
-    print(f"{name}: N={n} dim {d}: mismatches {bad} of {nseeds} seeds (hint {use_hint and setup.hint}); iterations {dict(iters)}", flush=True)
+    print(f"[flags {flags} channels {channels}] {name}: N={n} dim {d}: mismatches {bad} of {nseeds} seeds (hint {use_hint and setup.hint}); iterations {dict(iters)}", flush=True)

@@ -17,6 +17,9 @@ with pkg.Context(seed=1) as ctx:
     print("config1 G(1024,.5): admissible %.1f ms (host arrays), dim %d, iters %d, phases %s" % (ms, P.nparts, P.iterations, ["%.2f" % x for x in P.phase_ms[:4]]))
     ms, r = timeit(lambda: pkg.eigen_decomposition(P, atol=1.5e-8, ctx=ctx), reps=2)
     print("         eigen_decomposition (dense, 1024 eigenspaces): %.1f ms -> %s" % (ms, r))
+    os.environ["SDPSR_DEBUG"] = "1"  # phase marks of one more run on stderr
+    pkg.eigen_decomposition(P, atol=1.5e-8, ctx=ctx)
+    del os.environ["SDPSR_DEBUG"]
     # config 2: QAP grid 30
     flow, dist = pr.grid_qap_instance(5, 6, seed=4)
     Cv, A, b = pr.qap_problem(flow, dist)
