@@ -116,7 +116,11 @@ enum {
     /* admissible_subspace: every round runs the full refinement (insert / rank / label passes); by
        default a round that is expected not to refine -- a confirm round, the first iteration -- first
        compares every entry with the representative of its class and skips the relabel when none differs */
-    SDPSR_FLAG_NO_VERIFY_SHORTCUT = 1u << 9
+    SDPSR_FLAG_NO_VERIFY_SHORTCUT = 1u << 9,
+    /* basis_image: always the projection formula Q_k' 1[P==i] Q_k (src/diagonalize.jl:64-89); by default, when every
+       block is 1 x 1, the images are read off as eigenvalues, blks[i][k] = q_k'(1[P==i] x) with x = sum_k q_k, under
+       a randomized self-check that falls back to the projection formula (see sdpsr_block_images) */
+    SDPSR_FLAG_FULL_BASIS_IMAGE = 1u << 10
 };
 
 typedef struct sdpsr_opts {
@@ -303,6 +307,11 @@ int sdpsr_block_sizes(sdpsr_ctx* ctx, int32_t* blk_sizes);
    SDPSR_DIMENSION_MISMATCH (diagonalize does not run check_block_sizes, src/compat.jl:60 does). */
 int sdpsr_q_hat(sdpsr_ctx* ctx, double* Q_hat, int mem);
 /* Phase 2 = basis_image(Q_hat, P) (src/diagonalize.jl:64-89).
+   BEHAVIOURAL NOTE (commutative algebras, every block 1 x 1): Q_hat from Murota's decomposition spans invariant
+   subspaces, 1[P==i] q_k = blks[i][k] q_k, so the images are obtained from the class sums of ONE vector x = sum_k q_k
+   (n^2 label reads) instead of all sum_k s_k columns; a second vector with random signs goes through the same pass and
+   the two answers must agree to 2e-10, else -- and always with SDPSR_FLAG_FULL_BASIS_IMAGE -- the projection formula
+   Q_k' 1[P==i] Q_k is evaluated as the reference does.  Both give Q_k' 1[P==i] Q_k up to rounding (tests: 1e-9).
    blks: d * sum_sq doubles, class-major, then block, each block column-major s_k x s_k.
    Q_hat (optional, may be NULL): n x sum_s column-major, blocks side by side. */
 int sdpsr_block_images(sdpsr_ctx* ctx, double* blks, double* Q_hat, double* phase_ms, int mem);

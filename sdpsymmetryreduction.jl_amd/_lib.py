@@ -28,6 +28,7 @@ FLAG_SINGLE_COUPLING_ELEMENT = 1 << 6
 FLAG_SMALL_EIGEN_ON_DEVICE = 1 << 7
 FLAG_NO_GRAPH = 1 << 8
 FLAG_NO_VERIFY_SHORTCUT = 1 << 9
+FLAG_FULL_BASIS_IMAGE = 1 << 10
 BASIS_IMAGE_KERNELS = {"auto": 0, "two_stage": 1, "outer": 2, "chunk": 3}
 REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2}
 

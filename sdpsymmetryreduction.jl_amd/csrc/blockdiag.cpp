@@ -148,7 +148,26 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     // automatic choice reaches `outer` / `chunk` only for shapes far beyond the test sizes)
     const int force = c->opts.basis_image_kernel;
     const bool f_two = force == 1, f_outer = force == 2, f_chunk = force == 3;
-    if (basis_image_two_stage_fits(n, d, S1) && !f_outer && !f_chunk) {
+    // commutative case (every block 1 x 1): the images are eigenvalues, lambda_ik = q_k'(1[P==i] x) for x = sum_k q_k
+    // -- one vector's class sums -- with a randomized self-check; the projection formula below runs if the check
+    // fails (kernels_blockdiag.hip, launch_basis_image_commutative) and always under SDPSR_FLAG_FULL_BASIS_IMAGE
+    bool done = false;
+    if (S == S1 && force == 0 && !(c->opts.flags & SDPSR_FLAG_FULL_BASIS_IMAGE) && d >= 1 && n >= 64) {
+        double* ws = (double*)ctx_buf(c, "bi_comm_ws", basis_image_commutative_workspace_doubles(n, d) * 8);
+        uint32_t* bflag = (uint32_t*)ctx_buf(c, "bi_comm_flag", 64);
+        uint32_t* hv = (uint32_t*)ctx_pinned(c, 64);
+        if (!ws || !bflag || !hv) return SDPSR_OUT_OF_MEMORY;
+        if (launch_basis_image_commutative(s, n, d, S1, L, Qrm, next_key(c), atol, 2e-10, ws, out, bflag)) {
+            HIP_TRY(c, hipMemcpyAsync(hv, bflag, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, hipGetLastError());
+            done = hv[0] == 0;
+            if (!done && dbg_on()) fprintf(stderr, "[sdpsr] basis_image: invariance check failed, projection formula instead\n");
+        }
+    }
+    if (done) {
+        // (out is complete)
+    } else if (basis_image_two_stage_fits(n, d, S1) && !f_outer && !f_chunk) {
         // two-stage form (class sums per row, then the s_k x s_k dots): descriptor = the two
         // columns of Q_hat every output multiplies, blocks side by side, column-major inside
         std::vector<int32_t> hdesc(2 * (size_t)S);

@@ -867,8 +867,173 @@ class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// basis_image through the block structure (commutative case: every block 1 x 1).
+//
+// Q_hat from Murota's decomposition spans invariant subspaces: A_i q_k = lambda_ik q_k for every class
+// matrix A_i = 1[P==i] and every column q_k, and the columns are orthonormal.  Hence for
+// x = sum_k q_k:   q_k'(A_i x) = lambda_ik = q_k' A_i q_k = blks[i][k]  -- ONE vector's class sums
+// (n^2 label reads, no gathers of Q_hat rows) instead of the class sums of all S1 columns
+// (n^2 S1 / 2 gathered 8-byte words, the L2-bound 190 us of basis_image_rows_kernel at N = 4096).
+// The identity is only as good as the invariance, so it is CHECKED, not assumed: a second vector
+// x' = sum_k sigma_k q_k with random signs goes through the same pass (double2 lanes), and
+// q_k'(A_i x) must agree with sigma_k q_k'(A_i x') -- the cross terms q_k' A_i q_k', k' != k, enter the
+// two with different signs.  Any disagreement raises a flag and the caller computes the projection
+// formula Q_k' 1[P==i] Q_k itself (two-stage kernels above), which is also what
+// sdpsr_opts.flags & SDPSR_FLAG_FULL_BASIS_IMAGE always does.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double bi_sign(uint64_t key, int k) { return (sdpsr_fmix64(key + 0x9E3779B97F4A7C15ULL * (uint64_t)(k + 1)) >> 63) ? -1.0 : 1.0; }
+
+// X[r] = (sum_k Q[r,k], sum_k sigma_k Q[r,k]);  Qrm row-major n x S1
+__global__ void bi_signed_sums_kernel(int n, int S1, const double* __restrict__ Qrm, uint64_t key, double2* __restrict__ X, uint32_t* flag) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) flag[0] = 0u;
+    if (r >= n) return;
+    double a = 0, b = 0;
+    for (int k = 0; k < S1; ++k) {
+        const double q = Qrm[(int64_t)r * S1 + k];
+        a += q;
+        b = fma(bi_sign(key, k), q, b);
+    }
+    X[r] = make_double2(a, b);
+}
+
+// Class sums of a PAIR of vectors: out[(i-1) n + r] = sum over c with L[c,r] == i of X[c]  (both halves).
+// Same scheme as class_sums_small_d_kernel (private per-lane tables in LDS, fixed summation order), the
+// tables hold double2 (one 16-byte read-modify-write per entry); X comes from global memory (64 KiB at
+// N = 4096, L2-resident, coalesced along c) and is prefetched with the labels.  W waves per workgroup:
+// W * 64 * tstride * 16 bytes of LDS.
+template <int W>
+__global__ void __launch_bounds__(64 * W)
+class_sums2_kernel(int n, int d, int tstride, const uint32_t* __restrict__ L, const double2* __restrict__ X,
+                   double2* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double2 cs2_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double2* acc = cs2_smem + (size_t)wave * 64 * tstride;  // [64][tstride], tstride odd >= d + 1
+    double2* mine = acc + (size_t)lane * tstride;
+    const int rows_per_round = gridDim.x * W;
+    const int bpr = (n + 511) / 512;  // batches of 8 x 64 columns per row
+    const int my_rows = (n - (int)blockIdx.x * W + rows_per_round - 1) / rows_per_round;
+    const int total = my_rows * bpr;
+    auto fetch = [&](int bq, uint32_t (&lab)[8], double2 (&xv)[8]) {
+        const int rr = bq / bpr, bb = bq - rr * bpr;
+        const int r = blockIdx.x * W + rr * rows_per_round + wave;
+        const uint32_t* col = L + (int64_t)((bq < total && r < n) ? r : 0) * n;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = bb * 512 + u * 64 + lane;
+            const int cc = c < n ? c : n - 1;
+            lab[u] = col[cc];
+            xv[u] = X[cc];
+        }
+    };
+    auto process = [&](int bq, const uint32_t (&lab)[8], const double2 (&xv)[8]) {
+        if (bq >= total) return;  // uniform over the workgroup
+        const int rr = bq / bpr, bb = bq - rr * bpr;
+        if (bb == 0)
+            for (int i = 0; i <= d; ++i) mine[i] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = bb * 512 + u * 64 + lane;
+            if (c < n) {
+                double2 t = mine[lab[u]];
+                t.x += xv[u].x;
+                t.y += xv[u].y;
+                mine[lab[u]] = t;
+            }
+        }
+        if (bb == bpr - 1) {
+            const int r = blockIdx.x * W + rr * rows_per_round + wave;
+            __syncthreads();
+            if (r < n)
+                for (int i = 1 + lane; i <= d; i += 64) {
+                    double tx = 0, ty = 0;
+                    for (int l2 = 0; l2 < 64; ++l2) {
+                        const double2 v = acc[(size_t)l2 * tstride + i];
+                        tx += v.x;
+                        ty += v.y;
+                    }
+                    out[(int64_t)(i - 1) * n + r] = make_double2(tx, ty);
+                }
+            __syncthreads();
+        }
+    };
+    uint32_t la[8], lb[8], lc[8];
+    double2 xa[8], xb[8], xc[8];
+    fetch(0, la, xa);
+    fetch(1, lb, xb);
+#pragma unroll 1
+    for (int bq = 0; bq < total; bq += 3) {
+        fetch(bq + 2, lc, xc);
+        process(bq, la, xa);
+        fetch(bq + 3, la, xa);
+        process(bq + 1, lb, xb);
+        fetch(bq + 4, lb, xb);
+        process(bq + 2, lc, xc);
+    }
+}
+
+// out[i * S1 + k] = q_k' Y_i (first halves), checked against sigma_k q_k' Y_i (second halves): flag[0] = 1
+// where they differ by more than tol.  grid (d, ceil(S1 / 4)), 256 threads = 4 outputs x 64 row groups.
+__global__ void __launch_bounds__(256)
+bi_contract_check_kernel(int n, int S1, const double* __restrict__ Qrm, const double2* __restrict__ Y, uint64_t key, double atol,
+                         double tol, double* __restrict__ out, uint32_t* __restrict__ flag) {
+    __shared__ double red[2][256];
+    const int i = blockIdx.x;
+    const int k = blockIdx.y * 4 + (threadIdx.x & 3);
+    const int g = threadIdx.x >> 2;
+    const double2* Yi = Y + (int64_t)i * n;
+    double a0 = 0, a1 = 0;
+    if (k < S1)
+        for (int r = g; r < n; r += 64) {
+            const double q = Qrm[(int64_t)r * S1 + k];
+            const double2 y = Yi[r];
+            a0 = fma(q, y.x, a0);
+            a1 = fma(q, y.y, a1);
+        }
+    red[0][threadIdx.x] = a0;
+    red[1][threadIdx.x] = a1;
+    __syncthreads();
+    if (threadIdx.x < 4 && k < S1) {
+        double v0 = 0, v1 = 0;
+        for (int gg = 0; gg < 64; ++gg) {
+            v0 += red[0][gg * 4 + threadIdx.x];
+            v1 += red[1][gg * 4 + threadIdx.x];
+        }
+        if (!(fabs(v0 - bi_sign(key, k) * v1) <= tol)) flag[0] = 1u;
+        out[(int64_t)i * S1 + k] = (fabs(v0) < atol) ? 0.0 : v0;
+    }
+}
+
+size_t basis_image_commutative_workspace_doubles(int64_t n, int64_t d) { return (size_t)2 * n * (d + 1); }
+// All blocks 1 x 1 (S = S1).  ws: 2 n (d + 1) doubles.  Returns false when the shape has no instance (d > 148);
+// flag[0] = 1 after the launches <=> the check failed and `out` must be recomputed by the projection formula.
+bool launch_basis_image_commutative(hipStream_t s, int64_t n, int64_t d, int64_t S1, const uint32_t* L, const double* Qrm, uint64_t key,
+                                    double atol, double tol, double* ws, double* out, uint32_t* flag) {
+    const int tstride = (int)((d + 1) | 1);
+    const size_t per_wave = (size_t)64 * tstride * sizeof(double2);
+    int W = 4;
+    while (W > 1 && per_wave * W > 150 * 1024) W >>= 1;
+    if (per_wave * W > 150 * 1024 || n < 1 || n > 0x7FFFFFFF / 2) return false;
+    double2* X = reinterpret_cast<double2*>(ws);
+    double2* Y = X + n;
+    bi_signed_sums_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((int)n, (int)S1, Qrm, key, X, flag);
+    int g = (int)((n + W - 1) / W);
+    if (g > 256) g = 256;  // one resident workgroup per CU, rows in rounds
+    const size_t lds = per_wave * W;
+    if (W == 4) class_sums2_kernel<4><<<g, 256, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+    else if (W == 2) class_sums2_kernel<2><<<g, 128, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+    else class_sums2_kernel<1><<<g, 64, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+    dim3 gc((unsigned)d, (unsigned)((S1 + 3) / 4));
+    bi_contract_check_kernel<<<gc, 256, 0, s>>>((int)n, (int)S1, Qrm, Y, key, atol, tol, out, flag);
+    return true;
+}
+
 // per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes)
 void blockdiag_set_device_attributes() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&small_qtaq_block_norms_kernel),

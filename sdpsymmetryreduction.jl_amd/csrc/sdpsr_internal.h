@@ -320,6 +320,9 @@ void launch_class_sums(hipStream_t s, int64_t n, int64_t d, const uint32_t* L, c
 void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S,
                                   const uint32_t* L, const double* Qrm, double* T, const int32_t* colA,
                                   const int32_t* colB, double atol, double* out);
+size_t basis_image_commutative_workspace_doubles(int64_t n, int64_t d);
+bool launch_basis_image_commutative(hipStream_t s, int64_t n, int64_t d, int64_t S1, const uint32_t* L, const double* Qrm, uint64_t key,
+                                    double atol, double tol, double* ws, double* out, uint32_t* flag);
 void launch_transpose_to_rowmajor(hipStream_t s, int64_t n, int64_t S1, const double* Qcm,
                                   double* Qrm);
 // stable sort of entries by label (label 0 dropped): ent sorted, hist[d+1]

@@ -20,12 +20,30 @@ struct StatusError <: Exception
     msg::String
 end
 
+# sdpsr_opts (include/sdpsr.h, ABI 0.3): 16 32-bit words; everything zero = the library's defaults
+struct Opts
+    struct_size::UInt32
+    square_mode::Int32
+    channels::Int32
+    max_iters::Int32
+    confirm_rounds::Int32
+    eig_driver::Int32
+    flags::UInt32            # SDPSR_FLAG_*
+    round_mode::Int32        # 0 nearest (default), 1 trunc = unsafe_round as written (utils.jl:49-53)
+    basis_image_kernel::Int32
+    refine_path::Int32
+    label_bits::Int32        # 8 * sizeof(T) of Partition{T}: InexactError where the reference throws it; 0 = never
+    reserved::NTuple{5,Int32}
+end
+Opts(; flags=0, round_mode=0, label_bits=0, square_mode=0, channels=0) =
+    Opts(UInt32(64), square_mode, channels, 0, 0, 0, UInt32(flags), round_mode, 0, 0, label_bits, (Int32(0), Int32(0), Int32(0), Int32(0), Int32(0)))
+
 mutable struct Context
     handle::Ptr{Cvoid}
-    function Context(; device::Integer=0, seed::Integer=rand(UInt64))
+    function Context(; device::Integer=0, seed::Integer=rand(UInt64), opts::Opts=Opts())
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        st = ccall((:sdpsr_create, libsdpsr), Cint, (Cint, UInt64, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
-                   device, seed % UInt64, C_NULL, h)
+        st = ccall((:sdpsr_create, libsdpsr), Cint, (Cint, UInt64, Ref{Opts}, Ref{Ptr{Cvoid}}),
+                   device, seed % UInt64, Ref(opts), h)
         st == 0 || throw(StatusError(st, "sdpsr_create"))
         ctx = new(h[])
         finalizer(c -> ccall((:sdpsr_destroy, libsdpsr), Cvoid, (Ptr{Cvoid},), c.handle), ctx)
@@ -118,8 +136,40 @@ function SR.admissible_subspace(::Type{HIPPartition}, C::AbstractVector{T}, A::A
                     (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Float64,
                      Ptr{UInt32}, Ref{Int64}, Ref{Int32}, Ptr{Float64}, Cint),
                     cx.handle, n, c, x0, U, size(U, 2), atol, P, d, it, C_NULL, MEM_HOST))
-    verbose && @info "Minimal admissible subspace converged in $(it[]) iterations at dimension:" final = d[]
+    if verbose  # the reference's log lines (partitions.jl:150,156,187-188) from the dimension trajectory
+        cnt = Ref{Int32}(0)
+        ccall((:sdpsr_dimension_trajectory, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int32, Ref{Int32}), cx.handle, C_NULL, 0, cnt)
+        dims = Vector{Int64}(undef, cnt[])
+        ccall((:sdpsr_dimension_trajectory, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int32, Ref{Int32}), cx.handle, dims, cnt[], cnt)
+        @info "Starting the reduction. Dimensions:" maximal = (n^2 + n) ÷ 2 initial = dims[1]
+        for k in 1:length(dims)-1
+            @debug "Iteration $k, Current dimension: $(dims[k])"
+        end
+        @info "Minimal admissible subspace converged in $(it[]) iterations at dimension:" final = d[]
+    end
     return HIPPartition(d[], P)
+end
+
+# ---- the whole reduction in ONE call (sdpsr_jordan_reduce): admissible_subspace + blockDiagonalize with the
+# partition staying on the device; the images are fetched with sdpsr_block_images once their size is known ----
+function jordan_reduce(C::AbstractVector{Float64}, A::AbstractMatrix{Float64}, b::AbstractVector{Float64};
+                       atol=Base.rtoldefault(Float64), epsilon=Base.rtoldefault(Float64))
+    n = isqrt(length(C)); @assert n^2 == length(C)
+    F = qr(A'); U = Matrix(F.Q)[:, 1:rank(A)]; proj(v) = U * (U' * v)
+    c = Vector(C); c .-= proj(c); SR._clamp_round!(c, atol=atol); SR._symmetrize!(c, n)
+    x0, _ = SR.Krylov.craig(A, b); SR._symmetrize!(x0, n); x0 = proj(x0); SR._clamp_round!(x0, atol=atol)
+    P = Matrix{UInt32}(undef, n, n); d = Ref{Int64}(0); it = Ref{Int32}(0); cx = ctx()
+    nb = Ref{Int32}(0); ssq = Ref{Int64}(0); ss = Ref{Int64}(0)
+    check(cx, ccall((:sdpsr_jordan_reduce, libsdpsr), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Float64, Ptr{UInt32}, Ref{Int64},
+                     Ref{Int32}, Ref{Int32}, Ref{Int64}, Ref{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Cint),
+                    cx.handle, n, c, x0, U, size(U, 2), atol, epsilon, P, d, it, nb, ssq, ss, C_NULL, 0, C_NULL, 0, C_NULL, MEM_HOST))
+    sizes = Vector{Int32}(undef, nb[])
+    check(cx, ccall((:sdpsr_block_sizes, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{Int32}), cx.handle, sizes))
+    flat = Vector{Float64}(undef, d[] * ssq[])
+    check(cx, ccall((:sdpsr_block_images, libsdpsr), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint),
+                    cx.handle, flat, C_NULL, C_NULL, MEM_HOST))
+    return HIPPartition(d[], P), Int.(sizes), reshape(flat, Int(ssq[]), Int(d[]))   # column i = the blocks of class i, concatenated
 end
 
 # ---- blockDiagonalize(Float64, P) (compat.jl:46-68) -------------------------------------

@@ -1188,3 +1188,26 @@ def test_jordan_reduce_equals_the_three_calls(pkg, problems, oracle, golden, nam
             for i in range(d):
                 for k in range(len(sizes)):
                     assert np.allclose(blks[i, offs[k]:offs[k + 1]].reshape(sizes[k], sizes[k], order="F"), ref[i][k], atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["circ64", "circ256", "circ1024"])
+def test_commutative_basis_image_shortcut_equals_projection_formula(pkg, problems, oracle, golden, name):
+    """Every block 1 x 1: blks[i][k] = q_k'(1[P==i] x), x = sum_k q_k (one vector's class sums, randomized self-check)
+    against the projection formula Q_k' 1[P==i] Q_k (SDPSR_FLAG_FULL_BASIS_IMAGE, and the host products of the
+    oracle): same numbers to 1e-9, same clamping of |x| < 1e-12 n."""
+    if name == "circ1024":
+        L, d = problems.synthetic_jordan_partition(1024, seed=4)
+    else:
+        L = golden[f"{name}_P"].astype(np.int64)
+        d = int(L.max())
+    P = pkg.Partition(d, L.astype(np.uint32))
+    Po = oracle.Partition(d, L)
+    for flags in (0, pkg._lib.FLAG_FULL_BASIS_IMAGE):
+        for seed in (1, 2):
+            with pkg.Context(seed=seed, flags=flags) as ctx:
+                bd = pkg.blockDiagonalize(P, ctx=ctx, retries=3)
+            assert bd.blkSizes == [1] * d
+            ref = oracle.basis_image_fast([np.asarray(q) for q in bd.Q_hat], Po)
+            got = np.array([[bd.blks[i][k][0, 0] for k in range(d)] for i in range(d)])
+            want = np.array([[ref[i][k][0, 0] for k in range(d)] for i in range(d)])
+            assert np.allclose(got, want, atol=1e-9), (name, flags, seed, np.abs(got - want).max())
