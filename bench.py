@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--eig-driver", type=int, default=0, help="0 auto (module compression when dim(P) << n), 4 dense eigensolver forced")
     ap.add_argument("--no-graph", action="store_true", help="dense driver: launch the tridiagonalisation's kernels one by one (per-kernel rocprofv3 statistics)")
     ap.add_argument("--flags", type=int, default=0, help="sdpsr_opts.flags (include/sdpsr.h: SDPSR_FLAG_*) for A/B runs")
+    ap.add_argument("--insert-wgs", type=int, default=0, help="sdpsr_opts.insert_wgs_per_cu (measurement knob)")
     ap.add_argument("--channels", type=int, default=0, help="sdpsr_opts.channels (0 = default: 2 + one confirm round)")
     ap.add_argument("--timers-in-timed-region", action="store_true",
                     help="record the per-phase HIP events inside the timed steps (default: in a separate instrumented pass)")
@@ -207,7 +208,7 @@ def main():
 
     mode = {"i8": L.SQUARE_I8, "f32": L.SQUARE_F32, "f64": L.SQUARE_F64}[args.mode]
     opt_flags = args.flags | (L.FLAG_NO_GRAPH if args.no_graph else 0)
-    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode, eig_driver=args.eig_driver, flags=opt_flags, channels=args.channels)
+    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode, eig_driver=args.eig_driver, flags=opt_flags, channels=args.channels, insert_wgs_per_cu=args.insert_wgs)
 
     def vp(t):
         return C.c_void_p(t.data_ptr()) if t is not None else None

@@ -142,7 +142,8 @@ typedef struct sdpsr_opts {
     int32_t label_bits;         /* 0 = no emulation; 8 / 16 / 32: width of the reference's label type T in
                                    Partition{T} (admissible_subspace defaults to UInt16, src/partitions.jl:84):
                                    SDPSR_LABEL_OVERFLOW where the reference throws InexactError (see below) */
-    int32_t reserved[5];
+    int32_t insert_wgs_per_cu;  /* measurement knob: resident workgroups per CU of the refinement's insert pass (0 = default) */
+    int32_t reserved[4];
 } sdpsr_opts;
 
 /* phase_ms slots filled by sdpsr_admissible_subspace / sdpsr_block_diagonalize

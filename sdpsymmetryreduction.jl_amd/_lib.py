@@ -52,7 +52,8 @@ class Opts(C.Structure):
         ("basis_image_kernel", C.c_int32),
         ("refine_path", C.c_int32),
         ("label_bits", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("insert_wgs_per_cu", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

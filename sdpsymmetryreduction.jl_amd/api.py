@@ -67,7 +67,7 @@ class Context:
 
     def __init__(self, device=0, seed=0, square_mode=L.SQUARE_AUTO, channels=0, max_iters=0,
                  confirm_rounds=0, eig_driver=0, flags=0, round_mode="nearest", basis_image_kernel="auto",
-                 refine_path="auto", label_bits=0):
+                 refine_path="auto", label_bits=0, insert_wgs_per_cu=0):
         """``flags``: OR of ``_lib.FLAG_*``; ``round_mode``: "nearest" (default) or "trunc" (the
         reference's ``unsafe_round``, src/utils.jl:49-53); ``label_bits``: 0, or the width of the
         reference's label type ``T`` in ``Partition{T}`` to get ``LabelOverflow`` where it would throw."""
@@ -84,6 +84,7 @@ class Context:
         o.basis_image_kernel = L.BASIS_IMAGE_KERNELS[basis_image_kernel] if isinstance(basis_image_kernel, str) else int(basis_image_kernel)
         o.refine_path = L.REFINE_PATHS[refine_path] if isinstance(refine_path, str) else int(refine_path)
         o.label_bits = int(label_bits)
+        o.insert_wgs_per_cu = int(insert_wgs_per_cu)
         h = C.c_void_p()
         st = self._lib.sdpsr_create(int(device), C.c_uint64(seed & (2 ** 64 - 1)), C.byref(o), C.byref(h))
         if st != 0:

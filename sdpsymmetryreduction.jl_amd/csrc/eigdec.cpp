@@ -47,10 +47,23 @@ struct DisjointSets {
 double otsu_threshold(const std::vector<double>& X, double atol) {
     const int nb = std::max((int)std::ceil(-std::log10(2.220446049250313e-16)), 4);  // 16
     double mn = INFINITY, mx = 0;
-    for (double x : X) {
-        double a = std::fabs(x);
-        mn = std::min(mn, a);
-        mx = std::max(mx, a);
+    {  // eight independent running minima / maxima (one chain is bound by the latency of min / max: 2 x 4 clocks per value)
+        double mns[8], mxs[8];
+        for (int q = 0; q < 8; ++q) mns[q] = INFINITY, mxs[q] = 0;
+        const size_t nx = X.size(), n8 = nx & ~size_t(7);
+        const double* xp = X.data();
+        for (size_t e = 0; e < n8; e += 8)
+            for (int q = 0; q < 8; ++q) {
+                const double a = std::fabs(xp[e + q]);
+                mns[q] = std::min(mns[q], a);  // std::min(a, b) = (b < a) ? b : a: a NaN in b never replaces a, as in the scalar loop
+                mxs[q] = std::max(mxs[q], a);
+            }
+        for (size_t e = n8; e < nx; ++e) {
+            const double a = std::fabs(xp[e]);
+            mns[0] = std::min(mns[0], a);
+            mxs[0] = std::max(mxs[0], a);
+        }
+        for (int q = 0; q < 8; ++q) mn = std::min(mn, mns[q]), mx = std::max(mx, mxs[q]);
     }
     if (mn < atol) mn = atol;
     std::vector<double> edges(nb + 1);
@@ -61,15 +74,26 @@ double otsu_threshold(const std::vector<double>& X, double atol) {
         edges[i] = std::exp(t);
     }
     std::vector<double> counts(nb, 0.0);
-    for (double x : X) {
-        int f = nb + 1;  // something(findfirst(b -> b > x, edges), nb + 1), 1-based
-        for (int i = 0; i <= nb; ++i)
-            if (edges[i] > x) {
-                f = i + 1;
-                break;
+    {
+        // something(findfirst(b -> b > x, edges), nb + 1) (1-based) = 1 + #{edges <= x} for ascending edges:
+        // counted without branches (the loop vectorises; neig^2 values -- a million at neig = 1024 -- go through it)
+        std::vector<int64_t> hist(nb + 2, 0);
+        if (nb == 16) {
+            int64_t cnt[18];
+            host_count_edges17(X.data(), X.size(), edges.data(), cnt);  // cnt[c]: c edges <= x
+            // f = min(c + 1, nb + 1): no edge above x (c = 17: x >= the last edge, or a NaN) is the default nb + 1
+            for (int cidx = 0; cidx <= 17; ++cidx) hist[cidx + 1 < nb + 1 ? cidx + 1 : nb + 1] += cnt[cidx];
+        } else {
+            for (double x : X) {
+                int le = 0;
+                for (int i = 0; i <= nb; ++i) le += !(edges[i] > x);
+                ++hist[le + 1 < nb + 1 ? le + 1 : nb + 1];
             }
-        int bin = std::min(std::max(f - 1, 1), nb);
-        counts[bin - 1] += 1;
+        }
+        for (int f = 1; f <= nb + 1; ++f) {
+            const int bin = std::min(std::max(f - 1, 1), nb);
+            counts[bin - 1] += (double)hist[f];
+        }
     }
     double total = 0;
     for (double v : counts) total += v;

@@ -229,6 +229,7 @@ bool compression_eligible(const sdpsr_ctx* c, int64_t n, int64_t d);
 
 // small_eigen_host.cpp: the compressed problem (order w <= 64) on the host
 int host_syev(int n, const double* A, int lda, double* w, double* Z, int ldz);  // host_syev.cpp
+void host_count_edges17(const double* x, size_t n, const double* ed, int64_t* hist);
 void host_gemm_tn(int m, int n, int k, const double* A, int lda, const double* B, int ldb, double* C, int ldc);
 int murota_small_host(sdpsr_ctx* c, int w, const double* B1, const std::function<int(double*)>& next_element, double atol,
                       int64_t expect_dim, std::vector<int32_t>& sizes, int64_t& S1, int64_t& S, std::vector<double>& Qs);

@@ -180,6 +180,31 @@ int host_syev(int n, const double* A, int lda, double* w, double* Z, int ldz) {
     return 0;
 }
 
+// hist[c] = number of x with exactly c of the 17 ascending edges <= x, c = 0..17 (a NaN counts as 17: it compares
+// false with every "edge > x").  The log-histogram of otsu_threshold (src/eigen_decomposition.jl:83-110) over the
+// neig^2 block norms -- a million values at neig = 1024 -- eight values per step, no branches.
+SDPSR_HOST_CLONES void host_count_edges17(const double* __restrict__ x, size_t n, const double* __restrict__ ed, int64_t* __restrict__ hist) {
+    int64_t h[8][20] = {};
+    size_t e = 0;
+    for (; e + 8 <= n; e += 8) {
+        int64_t le[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 17; ++i) {
+            const double t = ed[i];
+            for (int q = 0; q < 8; ++q) le[q] += (t > x[e + q]) ? 0 : 1;
+        }
+        for (int q = 0; q < 8; ++q) ++h[q][le[q]];
+    }
+    for (; e < n; ++e) {
+        int le = 0;
+        for (int i = 0; i < 17; ++i) le += (ed[i] > x[e]) ? 0 : 1;
+        ++h[0][le];
+    }
+    for (int f = 0; f <= 17; ++f) {
+        hist[f] = 0;
+        for (int q = 0; q < 8; ++q) hist[f] += h[q][f];
+    }
+}
+
 // C (m x n) = A' B with A: k x m (lda), B: k x n (ldb), column-major, small orders
 void host_gemm_tn(int m, int n, int k, const double* A, int lda, const double* B, int ldb, double* C, int ldc) {
     for (int j = 0; j < n; ++j)

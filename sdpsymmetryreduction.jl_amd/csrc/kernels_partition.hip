@@ -758,7 +758,20 @@ struct SrcPair {  // sig_f64_pair_kernel; packed: the lower triangle column by c
         const uint64_t h = sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb);
         return finish_sig(0u, ka == 0 && kb == 0, h);
     }
-    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t) const { return flat((int64_t)i + (int64_t)j * n); }
+    // fetch / sig: the loads of an entry and the signature of what was loaded, separately -- the insert pass
+    // issues the loads of its NEXT chunk before it works on the current one
+    struct Raw {
+        double a, b;
+    };
+    __device__ __forceinline__ Raw fetch(uint32_t i, uint32_t j, int64_t) const {
+        const int64_t e = (int64_t)i + (int64_t)j * n;
+        return Raw{__builtin_nontemporal_load(&a[e]), __builtin_nontemporal_load(&b[e])};
+    }
+    __device__ __forceinline__ uint64_t sig(const Raw& r) const {
+        const uint64_t ka = (uint64_t)__double_as_longlong(r.a), kb = (uint64_t)__double_as_longlong(r.b);
+        return finish_sig(0u, ka == 0 && kb == 0, sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb));
+    }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const { return sig(fetch(i, j, e)); }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         if (packed) {
             uint32_t i, j;
@@ -800,10 +813,32 @@ struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig onl
         }
         return h;
     }
-    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const {
+    struct Raw {
+        uint32_t l;
+        double u[R > 0 ? R : 1];
+    };
+    __device__ __forceinline__ Raw fetch(uint32_t i, uint32_t j, int64_t e) const {
         const int64_t ef = (int64_t)i + (int64_t)j * n;
-        return flat(ef, lab_packed ? e : ef);
+        Raw r;
+        r.l = L[lab_packed ? e : ef];
+#pragma unroll
+        for (int k = 0; k < R; ++k) r.u[k] = __builtin_nontemporal_load(&U[(int64_t)k * len + ef]);
+        return r;
     }
+    __device__ __forceinline__ uint64_t sig(const Raw& r) const {
+        const double x = r.l ? sdpsr_class_uniform(key, r.l) : 0.0;
+        double p = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) p = fma(r.u[k], coef[k], p);
+        const uint64_t kb = sdpsr_round_key(x - p, atol, scale);
+        uint64_t h = 0;
+        if (r.l != 0 || kb != 0) {
+            h = sdpsr_sig_mix(sdpsr_sig_start(r.l), kb);
+            if (h == 0) h = 1;
+        }
+        return h;
+    }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const { return sig(fetch(i, j, e)); }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         if (packed) {
             uint32_t i, j;
@@ -825,22 +860,33 @@ struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by c
     __device__ __forceinline__ bool walks() const { return true; }  // C is ld-strided: (i, j) needed either way
     __device__ __forceinline__ bool lower() const { return packed != 0; }
     __device__ __forceinline__ int order() const { return n; }
-    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const {
-        const uint32_t l = lab_packed ? L[e] : L[(int64_t)j * n + i];
+    struct Raw {
+        uint32_t l;
+        CT c[T];
+    };
+    __device__ __forceinline__ Raw fetch(uint32_t i, uint32_t j, int64_t e) const {
+        Raw r;
+        r.l = lab_packed ? L[e] : L[(int64_t)j * n + i];
         const CT* Cij = C + (int64_t)j * ld + i;
+#pragma unroll
+        for (int t = 0; t < T; ++t) r.c[t] = __builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
+        return r;
+    }
+    __device__ __forceinline__ uint64_t sig(const Raw& r) const {
         int32_t c[T + (T & 1)];
 #pragma unroll
-        for (int t = 0; t < T; ++t) c[t] = (int32_t)__builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
+        for (int t = 0; t < T; ++t) c[t] = (int32_t)r.c[t];  // exact: f32 channels hold integers < 2^24
         if constexpr ((T & 1) != 0) c[T] = 0;
-        uint64_t h = sdpsr_sig_start(l);
+        uint64_t h = sdpsr_sig_start(r.l);
         bool allz = true;
 #pragma unroll
         for (int t = 0; t < T; t += 2) {
             allz = allz && (c[t] == 0) && (c[t + 1] == 0);
             h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[t] | ((uint64_t)(uint32_t)c[t + 1] << 32));
         }
-        return finish_sig(l, allz, h);
+        return finish_sig(r.l, allz, h);
     }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const { return sig(fetch(i, j, e)); }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         uint32_t i, j;
         IjWalk::locate(n, packed != 0, e, i, j);
@@ -867,31 +913,39 @@ struct SrcJoint {
     __device__ __forceinline__ bool walks() const { return true; }
     __device__ __forceinline__ bool lower() const { return true; }
     __device__ __forceinline__ int order() const { return n; }
-    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const {
+    struct Raw {
+        uint32_t l;
+        double u[R > 0 ? R : 1];
+        int32_t c[T];
+    };
+    __device__ __forceinline__ Raw fetch(uint32_t i, uint32_t j, int64_t e) const {
         static_assert(T == 2 || T == 4, "joint signatures: 2 or 4 channels");
         const int64_t ef = (int64_t)i + (int64_t)j * n;
-        const uint32_t l = lab_packed ? L[e] : L[ef];
-        double u[R > 0 ? R : 1];
+        Raw r;
+        r.l = lab_packed ? L[e] : L[ef];
 #pragma unroll
-        for (int k = 0; k < R; ++k) u[k] = __builtin_nontemporal_load(&U[(int64_t)k * n * n + ef]);
+        for (int k = 0; k < R; ++k) r.u[k] = __builtin_nontemporal_load(&U[(int64_t)k * n * n + ef]);
         const int32_t* Cij = C + (int64_t)j * ld + i;
-        int32_t c[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) c[t] = __builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
-        const double x = l ? sdpsr_class_uniform(key, l) : 0.0;
+        for (int t = 0; t < T; ++t) r.c[t] = __builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
+        return r;
+    }
+    __device__ __forceinline__ uint64_t sig(const Raw& r) const {
+        const double x = r.l ? sdpsr_class_uniform(key, r.l) : 0.0;
         double p = 0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) p = fma(u[k], coef[k], p);
+        for (int k = 0; k < R; ++k) p = fma(r.u[k], coef[k], p);
         const uint64_t kb = sdpsr_round_key(x - p, atol, scale);
-        uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(l), kb);
+        uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(r.l), kb);
         bool allz = kb == 0;
 #pragma unroll
         for (int t = 0; t < T; t += 2) {
-            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[t] | ((uint64_t)(uint32_t)c[t + 1] << 32));
-            allz = allz && c[t] == 0 && c[t + 1] == 0;
+            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)r.c[t] | ((uint64_t)(uint32_t)r.c[t + 1] << 32));
+            allz = allz && r.c[t] == 0 && r.c[t + 1] == 0;
         }
-        return finish_sig(l, allz, h);
+        return finish_sig(r.l, allz, h);
     }
+    __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const { return sig(fetch(i, j, e)); }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
         uint32_t i, j;
         packed_lower_ij(n, e, i, j);
@@ -959,6 +1013,15 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned 
 // the global table directly instead.
 constexpr int LDS_MAX_PROBES = 24;
 
+template <class S, bool IJ>
+struct RawOf {
+    struct type {};
+};
+template <class S>
+struct RawOf<S, true> {
+    using type = typename S::Raw;
+};
+
 // SRC: where the signatures come from (see the Src* functors); INSERT_PER_THREAD entries per
 // thread and chunk (16 for the plain array, 8 for the computed sources: their loads and hashes
 // of one chunk are all live before the first probe)
@@ -975,10 +1038,31 @@ refine_insert_kernel(int64_t len, const SRC src,
     __shared__ unsigned long long l_sig[LDS_SLOTS];
     __shared__ uint32_t l_min[LDS_SLOTS];
     __shared__ uint32_t l_gslot[LDS_SLOTS];
-    __shared__ uint32_t l_count, l_overflow;
+    __shared__ uint32_t l_count, l_overflow, l_new;
     constexpr uint32_t PENDING = 0xFFFFFFFEu;
     const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
     bool need_clear = true, bypass = false;
+    // Matrix-walking sources: the loads of a workgroup's NEXT chunk are issued before it hashes and probes the
+    // current one (PMC, round 3: two thirds of the wave cycles of this kernel were s_waitcnt on the chunk's own
+    // loads -- 3.4 TB/s of HBM traffic with the bytes at 1.05x the algorithmic ones: latency, not bandwidth)
+    using RawT = typename RawOf<SRC, SRC::kIJ>::type;
+    RawT pre[INSERT_PER_THREAD];
+    bool pre_valid = false;
+    auto load_chunk = [&](int64_t b, RawT (&dst)[INSERT_PER_THREAD]) {
+        if constexpr (SRC::kIJ) {
+            const int nn = src.order();
+            const bool low = src.lower();
+            const int64_t b0 = b * INSERT_CHUNK;
+            uint32_t wi = 0, wj = 0;
+            if (b0 + threadIdx.x < len) IjWalk::locate(nn, low, b0 + threadIdx.x, wi, wj);
+#pragma unroll
+            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
+                const int64_t e = b0 + q * REFINE_THREADS + threadIdx.x;
+                if (e < len) dst[q] = src.fetch(wi, wj, e);
+                IjWalk::step(nn, low, wi, wj, REFINE_THREADS);
+            }
+        }
+    };
     for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x) {
         if (need_clear) {
             for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
@@ -987,13 +1071,17 @@ refine_insert_kernel(int64_t len, const SRC src,
             }
             if (threadIdx.x == 0) l_count = 0;
         }
-        if (threadIdx.x == 0) l_overflow = __builtin_nontemporal_load(&counters[1]);
+        if (threadIdx.x == 0) {
+            l_overflow = __builtin_nontemporal_load(&counters[1]);
+            l_new = 0;
+        }
         __syncthreads();
         if (l_overflow) return;  // uniform: the host repeats the pass with a larger table
         const int64_t base = blk * INSERT_CHUNK;
         if (bypass) {
             // many classes (the previous chunk half filled the LDS table on its own): the LDS
             // level only costs probes, every entry goes to the global table directly
+            pre_valid = false;
 #pragma unroll 4
             for (int q = 0; q < INSERT_PER_THREAD; ++q) {
                 const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
@@ -1015,15 +1103,16 @@ refine_insert_kernel(int64_t len, const SRC src,
         // atomics, which the compiler will not move global loads across
         uint64_t sgs[INSERT_PER_THREAD];
         if (SRC::kIJ && src.walks()) {  // uniform
-            const int nn = src.order();
-            const bool low = src.lower();
-            uint32_t wi = 0, wj = 0;
-            if (base + threadIdx.x < len) IjWalk::locate(nn, low, base + threadIdx.x, wi, wj);
+            if constexpr (SRC::kIJ) {
+                if (!pre_valid) load_chunk(blk, pre);  // the workgroup's first chunk (or the one after a bypassed chunk)
 #pragma unroll
-            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-                sgs[q] = (e < len) ? src.at(wi, wj, e) : 0ull;
-                IjWalk::step(nn, low, wi, wj, REFINE_THREADS);
+                for (int q = 0; q < INSERT_PER_THREAD; ++q) {
+                    const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+                    sgs[q] = (e < len) ? src.sig(pre[q]) : 0ull;
+                }
+                // the same registers take the next chunk: in flight while this one is probed, published and stored
+                pre_valid = blk + gridDim.x < nchunk;
+                if (pre_valid) load_chunk(blk + gridDim.x, pre);
             }
         } else {
 #pragma unroll
@@ -1065,6 +1154,7 @@ refine_insert_kernel(int64_t len, const SRC src,
                     if (placed == 2) {
                         l_gslot[idx] = PENDING;
                         atomicAdd(&l_count, 1u);
+                        l_new = 1u;
                     }
                     // l_min only decreases: a plain read that is already <= e makes the atomic a
                     // no-op (true for every entry after the first of its class in this thread's
@@ -1081,7 +1171,9 @@ refine_insert_kernel(int64_t len, const SRC src,
             }
         }
         __syncthreads();
-        // publish the signatures this workgroup has not resolved yet
+        // publish the signatures this workgroup has not resolved yet (few classes: nothing new after the first chunks,
+        // the scan of the table and its barrier are skipped; l_new is uniform after the barrier above)
+        if (l_new) {
         for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
             if (l_sig[i] != 0ull && l_gslot[i] == PENDING) {
                 const uint32_t g = global_find_or_insert(l_sig[i], tab_sig, mask, counters);
@@ -1095,6 +1187,7 @@ refine_insert_kernel(int64_t len, const SRC src,
             }
         }
         __syncthreads();
+        }
 #pragma unroll
         for (int q = 0; q < INSERT_PER_THREAD; ++q) {
             const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
@@ -1373,7 +1466,10 @@ template <class SRC, int PER, int SLOTS = 1024>
 static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SRC& src, uint32_t* slot, const RefineWs& ws,
                           size_t cap) {
     const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
-    if (SLOTS == 1024) g_chunks_cap = 256 * 5;  // resident workgroups per CU, measured 2..8: 5 is the minimum of a flat curve
+    // resident workgroups per CU.  Round 2 (no prefetch, 71 VGPRs): 5 was the minimum of a flat curve over 2..8.  With the
+    // next chunk's loads in flight the computed sources hold 126-172 VGPRs (2-4 waves per SIMD) and a workgroup should
+    // own several chunks for the prefetch to matter: ws.insert_wgs_per_cu (sdpsr_opts.insert_wgs_per_cu) or the default
+    if (SLOTS == 1024) g_chunks_cap = 256 * (ws.insert_wgs_per_cu > 0 ? ws.insert_wgs_per_cu : 3);
     const int g = (int)(nchunk < g_chunks_cap ? nchunk : g_chunks_cap);
     refine_insert_kernel<SRC, PER, SLOTS><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                                 (uint32_t)(cap - 1), ws.counters);

@@ -33,10 +33,11 @@ struct Opts
     basis_image_kernel::Int32
     refine_path::Int32
     label_bits::Int32        # 8 * sizeof(T) of Partition{T}: InexactError where the reference throws it; 0 = never
-    reserved::NTuple{5,Int32}
+    insert_wgs_per_cu::Int32 # measurement knob, 0 = default
+    reserved::NTuple{4,Int32}
 end
 Opts(; flags=0, round_mode=0, label_bits=0, square_mode=0, channels=0) =
-    Opts(UInt32(64), square_mode, channels, 0, 0, 0, UInt32(flags), round_mode, 0, 0, label_bits, (Int32(0), Int32(0), Int32(0), Int32(0), Int32(0)))
+    Opts(UInt32(64), square_mode, channels, 0, 0, 0, UInt32(flags), round_mode, 0, 0, label_bits, 0, (Int32(0), Int32(0), Int32(0), Int32(0)))
 
 mutable struct Context
     handle::Ptr{Cvoid}

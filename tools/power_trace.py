@@ -14,9 +14,13 @@ kind, n, aux = sys.argv[1], sys.argv[2], sys.argv[3]
 seconds = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
 
 
-def hwmon_files():
+def hwmon_files(bdf=None):
+    """hwmon files of the GPU with PCI address `bdf` (the one the child process computes on: a box shows all of its
+    GPUs in sysfs, the process sees one), else of the first card that has a power sensor"""
     out = {}
-    for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+    roots = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf.lower()}/hwmon/hwmon*")) if bdf else []
+    roots += [] if roots else sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    for h in roots:
         for key, names in (("power", ("power1_average", "power1_input")), ("sclk", ("freq1_input",)), ("cap", ("power1_cap",))):
             for nm in names:
                 p = os.path.join(h, nm)
@@ -52,10 +56,15 @@ def sample_smi():
         return float("nan"), float("nan"), float("nan")
 
 
-files = hwmon_files()
-use_hwmon = "power" in files
-sample = (lambda: sample_hwmon(files)) if use_hwmon else sample_smi
-print("source:", files if use_hwmon else "rocm-smi --showpower --showclocks --json", flush=True)
+files, use_hwmon, sample = {}, False, sample_smi
+
+
+def choose_source(bdf):
+    global files, use_hwmon, sample
+    files = hwmon_files(bdf)
+    use_hwmon = "power" in files
+    sample = (lambda: sample_hwmon(files)) if use_hwmon else sample_smi
+    print("GPU", bdf, "source:", files if use_hwmon else "rocm-smi --showpower --showclocks --json", flush=True)
 
 
 def collect(duration, proc=None):
@@ -87,16 +96,21 @@ with pkg.Context(seed=1) as ctx:
     v = C.c_double(0)
     ctx.check(prof.sdpsr_profile_kernel(ctx._h, kind, n, aux, 20, C.byref(v)))
     reps = max(20, int(seconds * 1e3 / max(v.value, 1e-3)))
-    print("READY", flush=True)
+    import ctypes as C2
+    hip = C2.CDLL("libamdhip64.so")
+    buf = C2.create_string_buffer(64)
+    hip.hipDeviceGetPCIBusId(buf, 64, 0)
+    print("READY", buf.value.decode(), flush=True)
     time.sleep(1.0)
     t = time.time()
     ctx.check(prof.sdpsr_profile_kernel(ctx._h, kind, n, aux, reps, C.byref(v)))
     print("kernel kind %%d n %%d aux %%d: %%d launches, %%.4f ms per launch, loop %%.2f s" %% (kind, n, aux, reps, v.value, time.time() - t), flush=True)
 ''' % ROOT
-show("idle before", collect(1.0))
 p = subprocess.Popen([sys.executable, "-c", child, kind, n, aux, str(seconds)], stdout=subprocess.PIPE, text=True)
-line = p.stdout.readline()  # READY: library loaded, buffers allocated, kernel warmed
+line = p.stdout.readline()  # "READY <pci bus id>": library loaded, buffers allocated, kernel warmed; the loop starts 1 s later
+choose_source(line.split()[1] if len(line.split()) > 1 else None)
 warm = collect(0.9)
+show("idle (kernel warmed, before the loop)", warm)
 rows = collect(0, proc=p)
 print(p.stdout.read().strip(), flush=True)
 # the loop starts ~1 s after READY: drop the samples of the sleep and the first 0.2 s of the ramp
