@@ -450,9 +450,12 @@ def main():
                                   "rocprof_avg_us": {"basis_image_rows_kernel": rocprof_average_us("basis_image_rows_kernel"),
                                                      "basis_image_blocks_kernel": rocprof_average_us("basis_image_blocks_kernel")}}
         wdim = min(64, int(d))  # the compressed eigenproblem of the module-compression driver: w = dim <S>x <= dim(P)
-        ms = prof(8, wdim, reps=10)
-        kernels["small_syev_jacobi64"] = {"ms": round(ms, 4), "order": wdim, "bound": "latency (one workgroup, LDS-resident)",
-                                          "rocprof_avg_us": rocprof_average_us("small_syev_jacobi64_kernel")}
+        # solved on the host inside the read-back the driver makes anyway (small_eigen_host.cpp), while the device forms
+        # the second generic element; the one-workgroup Jacobi kernel it replaced (SDPSR_FLAG_SMALL_EIGEN_ON_DEVICE) beside it
+        ms_h = prof(10, wdim, reps=20)
+        ms_d = prof(8, wdim, reps=10)
+        kernels["small_eigen_host"] = {"ms": round(ms_h, 4), "order": wdim, "where": "one host core (Householder + implicit QL), overlapped with the "
+                                       "device's second generic element", "device_jacobi_one_workgroup_ms": round(ms_d, 4)}
         # Y = A(v) W straight from the labels on v_mfma_f64_16x16x4_f64 (w = the compressed order): the time is the
         # whole product (transposed copy of W + MFMA kernel + reduction of the partial sums); executed flop =
         # 2 N^2 * 16*ceil(w/16) (whole 16-column tiles), useful = 2 N^2 w

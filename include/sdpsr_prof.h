@@ -25,6 +25,7 @@ extern "C" {
        W n x w, G elements per pass): aux = w | G << 8 | d << 12; with bit 30 of aux set the call
        returns in ms_per_launch[0] the largest absolute deviation of sampled rows of Y from a host
        evaluation in extended precision instead of the time.
+   10 = the HOST eigensolver of the compressed problem (order n <= 512, one host core, no device work);
    ms_per_launch[0] = average milliseconds per launch. */
 int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps,
                          double* ms_per_launch);

@@ -758,8 +758,7 @@ struct SrcPair {  // sig_f64_pair_kernel; packed: the lower triangle column by c
         const uint64_t h = sdpsr_sig_mix(sdpsr_sig_mix(sdpsr_sig_start(0u), ka), kb);
         return finish_sig(0u, ka == 0 && kb == 0, h);
     }
-    // fetch / sig: the loads of an entry and the signature of what was loaded, separately -- the insert pass
-    // issues the loads of its NEXT chunk before it works on the current one
+    // fetch / sig: the loads of an entry and the signature of what was loaded
     struct Raw {
         double a, b;
     };
@@ -1013,15 +1012,6 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned 
 // the global table directly instead.
 constexpr int LDS_MAX_PROBES = 24;
 
-template <class S, bool IJ>
-struct RawOf {
-    struct type {};
-};
-template <class S>
-struct RawOf<S, true> {
-    using type = typename S::Raw;
-};
-
 // SRC: where the signatures come from (see the Src* functors); INSERT_PER_THREAD entries per
 // thread and chunk (16 for the plain array, 8 for the computed sources: their loads and hashes
 // of one chunk are all live before the first probe)
@@ -1042,27 +1032,11 @@ refine_insert_kernel(int64_t len, const SRC src,
     constexpr uint32_t PENDING = 0xFFFFFFFEu;
     const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
     bool need_clear = true, bypass = false;
-    // Matrix-walking sources: the loads of a workgroup's NEXT chunk are issued before it hashes and probes the
-    // current one (PMC, round 3: two thirds of the wave cycles of this kernel were s_waitcnt on the chunk's own
-    // loads -- 3.4 TB/s of HBM traffic with the bytes at 1.05x the algorithmic ones: latency, not bandwidth)
-    using RawT = typename RawOf<SRC, SRC::kIJ>::type;
-    RawT pre[INSERT_PER_THREAD];
-    bool pre_valid = false;
-    auto load_chunk = [&](int64_t b, RawT (&dst)[INSERT_PER_THREAD]) {
-        if constexpr (SRC::kIJ) {
-            const int nn = src.order();
-            const bool low = src.lower();
-            const int64_t b0 = b * INSERT_CHUNK;
-            uint32_t wi = 0, wj = 0;
-            if (b0 + threadIdx.x < len) IjWalk::locate(nn, low, b0 + threadIdx.x, wi, wj);
-#pragma unroll
-            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-                const int64_t e = b0 + q * REFINE_THREADS + threadIdx.x;
-                if (e < len) dst[q] = src.fetch(wi, wj, e);
-                IjWalk::step(nn, low, wi, wj, REFINE_THREADS);
-            }
-        }
-    };
+    // (Round 3 tried issuing the loads of a workgroup's NEXT chunk before hashing and probing the current one -- PMC
+    // showed two thirds of the wave cycles in s_waitcnt on the chunk's own loads.  The prefetched registers took the
+    // joint source from 71 to 172 VGPRs (2 waves per SIMD instead of 7) and the pass got SLOWER at every grid size
+    // tried, 1-6 workgroups per CU: refine phase of theta_c32xk128 0.91-1.17 ms against 0.79.  Latency is hidden by
+    // resident workgroups here, not by software pipelining; removed.)
     for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x) {
         if (need_clear) {
             for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
@@ -1081,7 +1055,6 @@ refine_insert_kernel(int64_t len, const SRC src,
         if (bypass) {
             // many classes (the previous chunk half filled the LDS table on its own): the LDS
             // level only costs probes, every entry goes to the global table directly
-            pre_valid = false;
 #pragma unroll 4
             for (int q = 0; q < INSERT_PER_THREAD; ++q) {
                 const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
@@ -1103,16 +1076,15 @@ refine_insert_kernel(int64_t len, const SRC src,
         // atomics, which the compiler will not move global loads across
         uint64_t sgs[INSERT_PER_THREAD];
         if (SRC::kIJ && src.walks()) {  // uniform
-            if constexpr (SRC::kIJ) {
-                if (!pre_valid) load_chunk(blk, pre);  // the workgroup's first chunk (or the one after a bypassed chunk)
+            const int nn = src.order();
+            const bool low = src.lower();
+            uint32_t wi = 0, wj = 0;
+            if (base + threadIdx.x < len) IjWalk::locate(nn, low, base + threadIdx.x, wi, wj);
 #pragma unroll
-                for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-                    const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-                    sgs[q] = (e < len) ? src.sig(pre[q]) : 0ull;
-                }
-                // the same registers take the next chunk: in flight while this one is probed, published and stored
-                pre_valid = blk + gridDim.x < nchunk;
-                if (pre_valid) load_chunk(blk + gridDim.x, pre);
+            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
+                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+                sgs[q] = (e < len) ? src.at(wi, wj, e) : 0ull;
+                IjWalk::step(nn, low, wi, wj, REFINE_THREADS);
             }
         } else {
 #pragma unroll
@@ -1466,10 +1438,8 @@ template <class SRC, int PER, int SLOTS = 1024>
 static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SRC& src, uint32_t* slot, const RefineWs& ws,
                           size_t cap) {
     const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
-    // resident workgroups per CU.  Round 2 (no prefetch, 71 VGPRs): 5 was the minimum of a flat curve over 2..8.  With the
-    // next chunk's loads in flight the computed sources hold 126-172 VGPRs (2-4 waves per SIMD) and a workgroup should
-    // own several chunks for the prefetch to matter: ws.insert_wgs_per_cu (sdpsr_opts.insert_wgs_per_cu) or the default
-    if (SLOTS == 1024) g_chunks_cap = 256 * (ws.insert_wgs_per_cu > 0 ? ws.insert_wgs_per_cu : 3);
+    // resident workgroups per CU, measured 2..8: 5 is the minimum of a flat curve (sdpsr_opts.insert_wgs_per_cu overrides)
+    if (SLOTS == 1024) g_chunks_cap = 256 * (ws.insert_wgs_per_cu > 0 ? ws.insert_wgs_per_cu : 5);
     const int g = (int)(nchunk < g_chunks_cap ? nchunk : g_chunks_cap);
     refine_insert_kernel<SRC, PER, SLOTS><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                                 (uint32_t)(cap - 1), ws.counters);

@@ -206,6 +206,23 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
             hipEventDestroy(e1);
             return SDPSR_OK;
         }
+    } else if (kind == 10) {
+        // the host eigensolver of the compressed problem (host_syev.cpp: Householder + implicit QL, order n <= 512) on a
+        // random symmetric matrix: wall-clock milliseconds per solve on ONE host core (no device work)
+        if (n > 512) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "kind 10: n <= 512");
+        std::vector<double> h((size_t)n * n), w((size_t)n), z((size_t)n * n);
+        for (int64_t j2 = 0; j2 < n; ++j2)
+            for (int64_t i2 = 0; i2 <= j2; ++i2) {
+                const double v = (double)(sdpsr_fmix64((uint64_t)(i2 * 131 + j2 * 1000003 + 17)) >> 11) * (1.0 / 9007199254740992.0);
+                h[(size_t)i2 + j2 * n] = h[(size_t)j2 + i2 * n] = v;
+            }
+        host_syev((int)n, h.data(), (int)n, w.data(), z.data(), (int)n);  // warm-up
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; ++i) host_syev((int)n, h.data(), (int)n, w.data(), z.data(), (int)n);
+        ms_per_launch[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        return SDPSR_OK;
     } else {
         return ctx_fail(c, SDPSR_BAD_ARGUMENT, "unknown kernel kind");
     }
