@@ -157,8 +157,8 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
         uint32_t* bflag = (uint32_t*)ctx_buf(c, "bi_comm_flag", 64);
         uint32_t* hv = (uint32_t*)ctx_pinned(c, 64);
         if (!ws || !bflag || !hv) return SDPSR_OUT_OF_MEMORY;
-        if (launch_basis_image_commutative(s, n, d, S1, L, Qrm, next_key(c), atol, 2e-10, ws, out, bflag)) {
-            HIP_TRY(c, hipMemcpyAsync(hv, bflag, 4, hipMemcpyDeviceToHost, s));
+        (void)bflag;
+        if (launch_basis_image_commutative(s, n, d, S1, L, Qrm, next_key(c), atol, 2e-10, ws, out, hv)) {  // verdict stored into pinned host memory
             HIP_TRY(c, hipStreamSynchronize(s));
             HIP_TRY(c, hipGetLastError());
             done = hv[0] == 0;

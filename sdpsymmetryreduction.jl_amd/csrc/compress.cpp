@@ -156,11 +156,22 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     // the stacked coefficients S = [-C X; X] ((w+mc) x r) with V_new = [W V] S.  r < 0: error.
     auto ortho_step = [&](int mc, double tol_abs, bool take_ref, std::vector<double>& stacked) -> int {
         const int64_t ap = round_up(w + mc, 128), mp = round_up(mc, 128);
-        abs_err = gram_tn(c, w + mc, mc, ld, W, ld, W + (size_t)w * ld, ld, Cc, ap, mp);
+        // the exact-shape Gram kernel stores the product into pinned host memory as well: no copy launch before the read-back
+        double* hpin = (double*)ctx_pinned(c, (size_t)ap * mp * 8);
+        bool host_filled = false;
+        abs_err = hpin ? gram_tn(c, w + mc, mc, ld, W, ld, W + (size_t)w * ld, ld, Cc, ap, mp, hpin, &host_filled) : SDPSR_OUT_OF_MEMORY;
         if (abs_err) return -1;
         hG.resize((size_t)ap * mp);
-        abs_err = d2h_sync(c, hG.data(), Cc, (size_t)ap * mc * 8);  // the mc columns the host looks at
-        if (abs_err) return -1;
+        if (host_filled) {
+            if (hipStreamSynchronize(s) != hipSuccess) {
+                abs_err = ctx_fail(c, SDPSR_HIP_ERROR, "hipStreamSynchronize (module growth)");
+                return -1;
+            }
+            memcpy(hG.data(), hpin, (size_t)ap * mc * 8);
+        } else {
+            abs_err = d2h_sync(c, hG.data(), Cc, (size_t)ap * mc * 8);  // the mc columns the host looks at
+            if (abs_err) return -1;
+        }
         if (!sym_checked) {  // the stream has been synchronised: the verdict of the symmetric check is in
             sym_checked = true;
             if (sym_pre ? c->pinned_small[0] == c->bd_sym_epoch : c->pinned_small[0] != 0) {
@@ -336,8 +347,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         auto enqueue_element = [&]() -> int {
             const int e2 = apply_generic(w, T);  // T[:, 0:w) = A W (rows < n)
             if (e2) return e2;
-            launch_gram_small(s, n, w, w, W, ld, T, ld, gp, dB, w, w, w);
-            HIP_TRY(c, hipMemcpyAsync(pin, dB, bbytes, hipMemcpyDeviceToHost, s));
+            launch_gram_small(s, n, w, w, W, ld, T, ld, gp, dB, w, w, w, pin);  // product stored into the pinned buffer itself
             return SDPSR_OK;
         };
         auto fetch = [&](double* dst) -> int {  // waits for the enqueued element, symmetrised like _symmetrize!

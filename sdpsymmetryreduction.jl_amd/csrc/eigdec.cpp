@@ -507,12 +507,14 @@ int gemm_tn_splitk(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* 
 // outside ma x nb): the skinny Gram kernel when both operands fit its LDS stage, the padded split-K
 // MFMA product otherwise.
 int gram_tn(sdpsr_ctx* c, int64_t ma, int64_t nb, int64_t k, const double* A, int64_t lda, const double* B, int64_t ldb,
-                   double* C, int64_t mp, int64_t np) {
+            double* C, int64_t mp, int64_t np, double* host_C, bool* host_filled) {
+    if (host_filled) *host_filled = false;
     const int64_t pa = (ma + 15) / 16 * 16 + 1, pb = (nb + 15) / 16 * 16 + 1;
     if (ma >= 1 && nb >= 1 && ma <= 128 && nb <= 128 && 32 * (pa + pb) * 8 <= 64 * 1024) {
         double* P = (double*)ctx_buf(c, "gram_partials", gram_small_partial_doubles(k, (int)ma, (int)nb) * 8);
         if (!P) return SDPSR_OUT_OF_MEMORY;
-        launch_gram_small(c->stream, k, (int)ma, (int)nb, A, lda, B, ldb, P, C, mp, (int)mp, (int)np);
+        launch_gram_small(c->stream, k, (int)ma, (int)nb, A, lda, B, ldb, P, C, mp, (int)mp, (int)np, host_C);
+        if (host_filled) *host_filled = host_C != nullptr;
         return SDPSR_OK;
     }
     return gemm_tn_splitk(c, mp, np, k, A, lda, B, ldb, C, mp);

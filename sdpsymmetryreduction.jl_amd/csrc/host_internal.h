@@ -221,8 +221,10 @@ int dense_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, const ElemGen*
                       std::vector<int32_t>& sizes, int64_t& S1, int64_t& S, PhaseTimer& tm, int64_t expect_dim = -1);
 int gemm_tn_splitk(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B, int64_t ldb,
                    double* C, int64_t ldc);
+// host_C (optional, pinned host memory, mp x np like C): filled by the product itself when the exact-shape kernel
+// runs; *host_filled says whether it did (the padded split-K path does not)
 int gram_tn(sdpsr_ctx* c, int64_t ma, int64_t nb, int64_t k, const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
-            int64_t mp, int64_t np);
+            int64_t mp, int64_t np, double* host_C = nullptr, bool* host_filled = nullptr);
 int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d, double atol, EigInfo& info,
                            std::vector<int32_t>& sizes, int64_t& S1, int64_t& S, PhaseTimer& tm);
 bool compression_eligible(const sdpsr_ctx* c, int64_t n, int64_t d);
@@ -240,7 +242,7 @@ void launch_extract_symmetric(hipStream_t s, int64_t m, int64_t mp, const double
 void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
 size_t gram_small_partial_doubles(int64_t k, int ma, int nb);
 void launch_gram_small(hipStream_t s, int64_t k, int ma, int nb, const double* A, int64_t lda, const double* B, int64_t ldb,
-                       double* partials, double* C, int64_t ldc, int mp, int np);
+                       double* partials, double* C, int64_t ldc, int mp, int np, double* host_C = nullptr);
 size_t label_spmm_partial_doubles(int64_t n, int w);
 bool launch_label_spmm_multi(hipStream_t s, int64_t n, const uint32_t* L, const uint64_t* keys, int G, int64_t d, const double* W,
                              int64_t ldw, int w, double* partials, double* Y, int64_t ldy);

@@ -237,7 +237,8 @@ gram_partial_kernel(int k, int ma, int nb, const double* __restrict__ A, int64_t
 // Workgroup = 16 consecutive outputs x 16 groups of z: thread (o, g) adds P[z] for z = g, g + 16, ...
 // (independent loads, one round trip), the 16 group sums of an output are added in group order.
 __global__ void __launch_bounds__(256)
-gram_reduce_kernel(int ma, int nb, int mp, int np, int Z, const double* __restrict__ P, double* __restrict__ C, int64_t ldc) {
+gram_reduce_kernel(int ma, int nb, int mp, int np, int Z, const double* __restrict__ P, double* __restrict__ C, int64_t ldc,
+                   double* __restrict__ host_C) {
     __shared__ double part[16][17];
     const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + o;  // index in the padded result
@@ -263,18 +264,21 @@ gram_reduce_kernel(int ma, int nb, int mp, int np, int Z, const double* __restri
 #pragma unroll
         for (int q = 0; q < 16; ++q) t += part[q][o];
         C[i + (int64_t)j * ldc] = t;
+        // optional second copy straight into pinned host memory (same layout): the host reads the product after its
+        // next synchronisation without a copy launch in between
+        if (host_C) host_C[i + (int64_t)j * ldc] = t;
     }
 }
 
 size_t gram_small_partial_doubles(int64_t k, int ma, int nb) { return (size_t)((k + GS_ROWS - 1) / GS_ROWS) * ma * nb; }
 // ma, nb <= 128; C gets the mp x np (padded) result, ldc >= mp
 void launch_gram_small(hipStream_t s, int64_t k, int ma, int nb, const double* A, int64_t lda, const double* B, int64_t ldb,
-                       double* partials, double* C, int64_t ldc, int mp, int np) {
+                       double* partials, double* C, int64_t ldc, int mp, int np, double* host_C) {
     const int Z = (int)((k + GS_ROWS - 1) / GS_ROWS);
     const int pa = ((ma + 15) / 16) * 16 + 1, pb = ((nb + 15) / 16) * 16 + 1;
     const size_t lds = (size_t)GS_ROWS * (pa + pb) * sizeof(double);
     gram_partial_kernel<<<Z, 256, lds, s>>>((int)k, ma, nb, A, lda, B, ldb, pa, pb, partials);
-    gram_reduce_kernel<<<(mp * np + 15) / 16, 256, 0, s>>>(ma, nb, mp, np, Z, partials, C, ldc);
+    gram_reduce_kernel<<<(mp * np + 15) / 16, 256, 0, s>>>(ma, nb, mp, np, Z, partials, C, ldc, host_C);
 }
 
 // ---------------------------------------------------------------------------

@@ -201,8 +201,8 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                     const uint32_t* first = (const uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
                     uint32_t* hv = (uint32_t*)ctx_pinned(c, 64);
                     if (!vflag || !vref || !first || !hv) return SDPSR_OUT_OF_MEMORY;
-                    if (launch_verify_no_split(s, qv, current, first, vref, vflag)) {
-                        HIP_TRY(c, hipMemcpyAsync(hv, vflag, 4, hipMemcpyDeviceToHost, s));
+                    (void)vflag;
+                    if (launch_verify_no_split(s, qv, current, first, vref, hv)) {  // the verdict is stored straight into pinned host memory
                         HIP_TRY(c, hipStreamSynchronize(s));
                         HIP_TRY(c, hipGetLastError());
                         unchanged = hv[0] == 0;

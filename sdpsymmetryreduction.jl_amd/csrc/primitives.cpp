@@ -90,10 +90,11 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         ws.nblk = (int)nblk;
         ws.expect_small = (!mispredicted && c->table_log2_hint <= 12) ? 1 : 0;  // hint 12 <=> last dim <= 512
         const bool sym_fused = sym_n > 0 && sym_n * sym_n == len;  // verdict in counters[3], same read-back
-        launch_refine(c->stream, len, src, slot, labels, ws, sym_fused ? sym_n : 0);
         uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
         if (!h) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
-        HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        ws.host_counters = sym_fused ? nullptr : h;  // the plain label pass stores the counters into the pinned buffer itself
+        launch_refine(c->stream, len, src, slot, labels, ws, sym_fused ? sym_n : 0);
+        if (!ws.host_counters) HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         if (sym_n > 0 && symflag_dev && !sym_fused) {
             launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);  // flag = 1 if NOT symmetric
             HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

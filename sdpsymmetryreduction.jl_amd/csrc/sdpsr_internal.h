@@ -146,6 +146,7 @@ struct RefineWs {
     uint32_t* tab_lab;   // cap
     uint32_t* blk_cnt;   // nblk + 1
     int insert_wgs_per_cu = 0;  // sdpsr_opts.insert_wgs_per_cu (0 = default)
+    uint32_t* host_counters = nullptr;  // pinned host memory: counters[0..2] are also stored there by the label pass (plain label pass only)
     int expect_small = 0;  // host prediction: <= refine_small_k() classes (see launch_refine)
     uint32_t* first_idx = nullptr;  // optional: first-occurrence index of class l at [l - 1], l <= refine_first_cap()
     uint32_t* counters;  // [0] = inserted, [1] = overflow flag, [2] = nparts, [16..] slot list (refine_counters_bytes())
