@@ -325,6 +325,9 @@ int sdpsr_block_images(sdpsr_ctx* ctx, double* blks, double* Q_hat, double* phas
      blks            d * sum_sq doubles if that is <= blks_capacity (in doubles), else untouched: the caller reads
                      *dim_out * *sum_sq, allocates and calls sdpsr_block_images; blks_capacity = 0: sizes only;
      Q_hat           n * sum_s doubles under the same rule with qhat_capacity; may be NULL.
+   With device-resident P_out the partition is formed and read in the caller's buffer (no copy); once this call has
+   delivered the images itself, a further sdpsr_block_images needs a new sdpsr_block_diagonalize (sizes and Q_hat stay
+   available through sdpsr_block_sizes / sdpsr_q_hat).
    Status: that of the first stage that fails.  After SDPSR_NUMERICAL_INCONSISTENCY / SDPSR_DIMENSION_MISMATCH
    (the randomized failures of blockDiagonalize, "try again" in the reference) the partition outputs are valid and
    the caller retries with sdpsr_block_diagonalize on them; SDPSR_NOT_CONVERGED is reported after the other stages ran. */

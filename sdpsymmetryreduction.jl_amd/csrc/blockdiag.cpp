@@ -16,7 +16,7 @@ using namespace sdpsr;
 
 namespace sdpsr {
 int block_diagonalize_impl(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon, int32_t* nblocks, int64_t* sum_sq,
-                           int64_t* sum_s, double* phase_ms, int mem, bool trusted_symmetric, bool final_sync) {
+                           int64_t* sum_s, double* phase_ms, int mem, bool trusted_symmetric, bool final_sync, bool in_place) {
     CHECK_CTX(c);
     if (!P || n < 1 || d < 0 || !(epsilon > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
     const int64_t len = n * n;
@@ -27,9 +27,11 @@ int block_diagonalize_impl(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d
     c->bd_q_valid = false;
     PhaseTimer tm(c, phase_ms != nullptr);
     TotalEvents ev_total(phase_ms != nullptr, s);
-    // keep a device copy of the labels for phase 2
-    uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
+    // keep a device copy of the labels for phase 2 (or, in_place, the caller's device buffer itself)
+    in_place = in_place && mem == SDPSR_MEM_DEVICE;
+    uint32_t* L = in_place ? const_cast<uint32_t*>(P) : (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
     if (!L) return SDPSR_OUT_OF_MEMORY;
+    c->bd_labels_ext = in_place ? P : nullptr;
     c->bd_sym_labels = nullptr;
     c->bd_sym_epoch = 0;
     c->bd_trusted_symmetric = (trusted_symmetric && mem == SDPSR_MEM_DEVICE && P == L) ? L : nullptr;
@@ -137,7 +139,7 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     const int64_t n = c->bd_n, d = c->bd_d, S1 = c->bd_sum_s, S = c->bd_sum_sq, len = n * n;
     TotalEvents ev_total(phase_ms != nullptr, s);
     int st = SDPSR_OK;
-    uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
+    uint32_t* L = c->bd_labels_ext ? const_cast<uint32_t*>(c->bd_labels_ext) : (uint32_t*)ctx_buf(c, "bd_labels", len * 4);
     double* Qhat = (double*)ctx_buf(c, "bd_qhat", (size_t)n * S1 * 8);
     double* Qrm = (double*)ctx_buf(c, "bd_qrm", (size_t)n * S1 * 8);
     double* out = out_dev(c, "bd_blks", blks, (size_t)d * S, mem, &st);

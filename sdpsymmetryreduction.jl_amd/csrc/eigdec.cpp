@@ -534,6 +534,7 @@ int sdpsr_eigen_decomposition(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_
     c->bd_sym_epoch = 0;  // the verdict cached by sdpsr_block_diagonalize belongs to the labels it copied, not to these
     c->bd_sym_labels = nullptr;
     c->bd_trusted_symmetric = nullptr;
+    c->bd_labels_ext = nullptr;
     const uint32_t* L = in_dev(c, "bd_labels", P, (size_t)n * n, mem, &st);
     if (st) return st;
     c->bd_valid = false;
@@ -561,6 +562,7 @@ int sdpsr_eigen_decomposition_batched(sdpsr_ctx* c, int64_t n, const uint32_t* P
     c->bd_sym_epoch = 0;  // the verdict cached by sdpsr_block_diagonalize belongs to the labels it copied, not to these
     c->bd_sym_labels = nullptr;
     c->bd_trusted_symmetric = nullptr;
+    c->bd_labels_ext = nullptr;
     const uint32_t* L = in_dev(c, "bd_labels", P, (size_t)n * n, mem, &st);
     if (st) return st;
     c->bd_valid = false;

@@ -179,9 +179,10 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* 
 int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r, double atol,
                              uint32_t* P_out, int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem, int mem_out,
                              bool final_sync, int* labels_sym_out);
-// labels_in_place: P is ctx buffer "bd_labels" itself; trusted_symmetric: the caller made the labels and knows
+// trusted_symmetric: the caller made the labels and knows; in_place (device labels only): no copy into ctx buffer
+// "bd_labels" -- P itself serves phase 2 (c->bd_labels_ext) until the caller ends that arrangement
 int block_diagonalize_impl(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d, double epsilon, int32_t* nblocks, int64_t* sum_sq,
-                           int64_t* sum_s, double* phase_ms, int mem, bool trusted_symmetric, bool final_sync);
+                           int64_t* sum_s, double* phase_ms, int mem, bool trusted_symmetric, bool final_sync, bool in_place = false);
 
 // ---- blockDiagonalize: host pieces and drivers (eigdec.cpp, compress.cpp) ----
 struct EigInfo {

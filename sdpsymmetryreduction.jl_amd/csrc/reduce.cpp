@@ -22,30 +22,49 @@ extern "C" int sdpsr_jordan_reduce(sdpsr_ctx* c, int64_t n, const double* CL, co
     int st = check_len(c, len);
     if (st) return st;
     hipStream_t s = c->stream;
-    // the partition is formed in the buffer blockDiagonalize keeps its labels in
-    uint32_t* L = (uint32_t*)ctx_buf(c, "bd_labels", (size_t)len * 4);
+    // the partition is formed where blockDiagonalize reads its labels: in the caller's device buffer P_out when there
+    // is one (no copy at all), else in the ctx buffer "bd_labels"
+    const bool in_place = mem == SDPSR_MEM_DEVICE && P_out != nullptr;
+    uint32_t* L = in_place ? P_out : (uint32_t*)ctx_buf(c, "bd_labels", (size_t)len * 4);
     if (!L) return SDPSR_OUT_OF_MEMORY;
     c->bd_valid = false;
     c->bd_q_valid = false;
+    c->bd_labels_ext = nullptr;
     double pm_a[SDPSR_T_COUNT] = {}, pm_b[SDPSR_T_COUNT] = {}, pm_i[SDPSR_T_COUNT] = {};
     int labels_sym = 0;
     st = admissible_subspace_impl(c, n, CL, X0L, U, r, atol, L, dim_out, iters_out, phase_ms ? pm_a : nullptr, mem, SDPSR_MEM_DEVICE,
                                   /*final_sync=*/false, &labels_sym);
     const int st_loop = st;
     if (st && st != SDPSR_NOT_CONVERGED) return st;
-    if (P_out)  // stream-ordered; complete when the call returns (it ends with a synchronisation on every path)
-        HIP_TRY(c, hipMemcpyAsync(P_out, L, (size_t)len * 4, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    if (P_out && !in_place)  // stream-ordered; complete when the call returns (it ends with a synchronisation on every path)
+        HIP_TRY(c, hipMemcpyAsync(P_out, L, (size_t)len * 4, hipMemcpyDeviceToHost, s));
     const int64_t d = *dim_out;
     int32_t nb = 0;
     int64_t S = 0, S1 = 0;
     st = block_diagonalize_impl(c, n, L, d, epsilon, &nb, &S, &S1, phase_ms ? pm_b : nullptr, SDPSR_MEM_DEVICE, labels_sym != 0,
-                                /*final_sync=*/false);
+                                /*final_sync=*/false, in_place);
     if (nblocks) *nblocks = nb;
     if (sum_sq) *sum_sq = S;
     if (sum_s) *sum_s = S1;
+    bool images_done = false;
     if (st == SDPSR_OK && blks && d * S <= blks_capacity && (!Q_hat || n * S1 <= qhat_capacity)) {
         st = sdpsr_block_images(c, blks, (Q_hat && n * S1 <= qhat_capacity) ? Q_hat : nullptr, phase_ms ? pm_i : nullptr, mem);  // ends synchronised
-    } else {
+        images_done = st == SDPSR_OK;
+    }
+    if (in_place) {
+        // the caller's buffer stops serving phase 2 when this call returns: a later sdpsr_block_images (images not
+        // delivered here) finds the labels in the ctx buffer
+        if (!images_done && c->bd_valid) {
+            uint32_t* keep = (uint32_t*)ctx_buf(c, "bd_labels", (size_t)len * 4);
+            if (!keep) return SDPSR_OUT_OF_MEMORY;
+            HIP_TRY(c, hipMemcpyAsync(keep, P_out, (size_t)len * 4, hipMemcpyDeviceToDevice, s));
+        } else if (images_done) {
+            c->bd_valid = false;  // nothing left for a second sdpsr_block_images to work on (sizes and Q_hat stay available)
+        }
+        c->bd_labels_ext = nullptr;
+        c->bd_trusted_symmetric = nullptr;
+    }
+    {
         const hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess && st == SDPSR_OK) st = ctx_fail(c, SDPSR_HIP_ERROR, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     }

@@ -55,6 +55,7 @@ struct sdpsr_ctx {
     bool bdc_valid = false;
     uint32_t bd_sym_epoch = 0;            // != 0: "bd_symflag"[0] == epoch <=> bd_sym_labels are NOT symmetric (copy + check pass of blockDiagonalize)
     const uint32_t* bd_sym_labels = nullptr;
+    const uint32_t* bd_labels_ext = nullptr;  // sdpsr_jordan_reduce: the labels of the pending phase 2 live in the caller's device buffer, not in "bd_labels"
     const uint32_t* bd_trusted_symmetric = nullptr;  // labels the library made itself and knows to be symmetric (sdpsr_jordan_reduce)
     uint32_t epoch_counter = 0;
     // "ref_first"[l - 1] = first-occurrence index of class l in the label array `first_idx_labels` (written by the
