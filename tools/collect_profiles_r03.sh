@@ -28,11 +28,30 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_ins
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = power ]; then
 cd $R
-python3 tools/power_trace.py 0 4096 102 3 > $O/power_i8_product_launch.txt 2>&1
-python3 tools/power_trace.py 0 4096 104 3 > $O/power_i8_4ch.txt 2>&1
-python3 tools/power_trace.py 0 8192 4 3 > $O/power_i8_n8192.txt 2>&1
-python3 tools/power_trace.py 1 4096 1 3 > $O/power_f32.txt 2>&1
-python3 tools/power_trace.py 2 4096 1 3 > $O/power_f64.txt 2>&1
+( echo "# socket power (hwmon power1_input of the GPU in use, by PCI address) and sclk while ONE kernel runs in a ~3 s loop"; echo "# tools/power_trace.py <kind> <n> <aux>: kind 0 int8 square (aux 102 = the product launch: 2 channels, lower-triangle tiles; 104 = 4 channels; n 8192 aux 4 = full squares), 1 fp32 square, 2 fp64 GEMM" ) > $O/power_under_kernels.txt
+for A in "0 4096 102" "0 4096 104" "0 8192 4" "1 8192 1" "2 4096 1"; do python3 tools/power_trace.py $A 3 >> $O/power_under_kernels.txt 2>&1; done
 python3 tools/clock_under_kernels.py > $O/clock_under_kernels.txt 2>&1
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
+cd $R
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+python3 bench.py --steps 20 --warmup 3 --skip-roofline --flags 1024 > $O/ab_full_basis_image.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 3 --skip-roofline --flags 512 > $O/ab_no_verify_shortcut.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 3 --skip-roofline --flags 128 > $O/ab_small_eigen_on_device.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 3 --skip-roofline --channels 4 > $O/ab_channels4.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 3 --skip-roofline --channels 4 --workload theta_c32xk128 > $O/ab_channels4_theta.json 2> /dev/null
+python3 tools/config_times.py > $O/config_times.txt 2>&1
+python3 tools/config2_bd_phases.py > $O/config2_bd_phases.txt 2>&1
+for n in 900 1024 2048 4096; do for drv in 0 1; do python3 tools/eig_only.py $n $drv random 2>&1 | grep "syev n=" | tail -1 >> $O/eig_drivers.txt; done; done
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = seeds ]; then
+cd $R
+python3 tools/stress_seeds.py 300 > $O/stress_seeds.txt 2>&1
+python3 tools/big_instance_seeds.py 60 1 > $O/big_instance_seeds.txt 2>&1
+python3 tools/big_instance_seeds.py 30 0 >> $O/big_instance_seeds.txt 2>&1
+python3 tools/big_instance_seeds.py 20 1 1 >> $O/big_instance_seeds.txt 2>&1
+python3 tools/big_instance_seeds.py 20 1 512 >> $O/big_instance_seeds.txt 2>&1
+python3 tools/big_instance_seeds.py 20 1 0 4 >> $O/big_instance_seeds.txt 2>&1
+( python3 tools/bd_failure_compare.py device 8 5000 4 0; python3 tools/bd_failure_compare.py device 8 5000 4 64; python3 tools/bd_failure_compare.py device 8 5000 6 0; python3 tools/bd_failure_compare.py device 72 3000 0 0; python3 tools/bd_failure_rate.py 4096 2000 commutative 2>&1 | tail -3; python3 tools/bd_failure_rate.py 4104 3000 er7 2>&1 | tail -3 ) > $O/bd_failure_rates.txt 2>&1
 fi
 ls $O | head -50
