@@ -439,16 +439,18 @@ def main():
         ms = prof(4, n, aux=max(r, 1), reps=5)  # gather+project+signature: (4 + 8r)*2 read + 8 write per entry
         gbs = ((4.0 + 8.0 * max(r, 1)) * 2 + 8.0) * n * n / (ms * 1e-3) / 1e9
         kernels["project_sig"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm"}
-        # kernels of the default (module-compression) path that weigh most in the rocprofv3 statistics
+        # basis_image of the headline instance (every block 1 x 1): class sums of a PAIR of vectors (x = sum_k q_k and a
+        # sign-randomised copy for the self-check) + contraction; the projection formula runs when the check fails
         ph = phases(acc_timed, args.steps)
         S1 = len(w0.blocks)
-        bi_bytes = 4.0 * n * n + 8.0 * (n * n / 2) * S1 + 8.0 * d * n * S1 * 2  # labels + gathered Q-hat rows (L2) + class sums written & read
-        kernels["basis_image"] = {"ms": ph["basis_image"], "bound": "L2 gather", "algorithmic_bytes": round(bi_bytes),
-                                  "achieved": round(bi_bytes / (ph["basis_image"] * 1e-3) / 1e9, 1) if ph["basis_image"] > 0 else None, "unit": "GB/s",
-                                  "note": "phase timer (HIP events) of sdpsr_block_images: rows kernel + blocks kernel; labels 4 B*N^2 from HBM, "
-                                          "N^2/2 gathers of S1*8-byte rows of Q-hat from L2",
-                                  "rocprof_avg_us": {"basis_image_rows_kernel": rocprof_average_us("basis_image_rows_kernel"),
-                                                     "basis_image_blocks_kernel": rocprof_average_us("basis_image_blocks_kernel")}}
+        kernels["basis_image"] = {"ms": ph["basis_image"], "bound": "LDS read-modify-write latency (class_sums2_kernel) / L2 gathers (fallback)",
+                                  "algorithmic_bytes": round(4.0 * n * n), "unit": "ms",
+                                  "note": "phase timer (HIP events) of sdpsr_block_images, average over the steps: commutative shortcut "
+                                          "(bi_signed_sums + class_sums2 + bi_contract_check) plus, in the ~15 % of the steps whose invariance check fails, "
+                                          "the two-stage projection kernels (basis_image_rows + basis_image_blocks)",
+                                  "rocprof_avg_us": {"class_sums2_kernel": rocprof_average_us("class_sums2_kernel"),
+                                                     "bi_contract_check_kernel": rocprof_average_us("bi_contract_check_kernel"),
+                                                     "basis_image_rows_kernel (fallback)": rocprof_average_us("basis_image_rows_kernel")}}
         wdim = min(64, int(d))  # the compressed eigenproblem of the module-compression driver: w = dim <S>x <= dim(P)
         # solved on the host inside the read-back the driver makes anyway (small_eigen_host.cpp), while the device forms
         # the second generic element; the one-workgroup Jacobi kernel it replaced (SDPSR_FLAG_SMALL_EIGEN_ON_DEVICE) beside it

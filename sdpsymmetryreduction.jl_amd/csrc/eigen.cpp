@@ -20,7 +20,7 @@ bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double*
 void launch_splitk_reduce(hipStream_t s, int64_t len, int Z, int64_t stride, const double* P, double* C);
 void launch_bt_extract_panel(hipStream_t s, int64_t n, int64_t ld, const double* A, int64_t j0, int64_t r0, double* Vp,
                              double* VpT);
-void launch_bt_larft(hipStream_t s, const double* G, const double* tau, int64_t j0, int64_t n, double* T);
+void launch_bt_larft(hipStream_t s, const double* G, const double* tau, int64_t nblk, int64_t n, double* T);
 void launch_gemm_tn_f64_sub(hipStream_t s, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
                             int64_t ldb, double* C, int64_t ldc);
 
@@ -59,19 +59,26 @@ static int backtransform_device(sdpsr_ctx* c, int64_t n, const double* A, int64_
     double* VpT = (double*)ctx_buf(c, "bt_vpt", (size_t)ld * 128 * 8);
     double* X = (double*)ctx_buf(c, "bt_x", (size_t)ld * 128 * 8);
     double* W = (double*)ctx_buf(c, "bt_w", (size_t)ld * 128 * 8);
-    double* G = (double*)ctx_buf(c, "bt_g", (size_t)128 * 128 * 8);
-    double* T = (double*)ctx_buf(c, "bt_t", (size_t)128 * 128 * 8);
-    if (!Vp || !VpT || !X || !W || !G || !T) return SDPSR_OUT_OF_MEMORY;
     const int64_t nblk = (n - 1 + 127) / 128;
-    for (int64_t b = nblk - 1; b >= 0; --b) {
+    double* G = (double*)ctx_buf(c, "bt_g", (size_t)std::max<int64_t>(nblk, 1) * 128 * 128 * 8);
+    double* T = (double*)ctx_buf(c, "bt_t", (size_t)std::max<int64_t>(nblk, 1) * 128 * 128 * 8);
+    if (!Vp || !VpT || !X || !W || !G || !T) return SDPSR_OUT_OF_MEMORY;
+    // pass 1: the Gram matrices of all panels, then every T factor in ONE launch (one workgroup per block)
+    for (int64_t b = 0; b < nblk; ++b) {
         const int64_t j0 = 128 * b, r0 = j0, m = ld - r0;
         launch_bt_extract_panel(s, n, ld, A, j0, r0, Vp, VpT);
-        int st = bt_gemm_splitk(c, 128, 128, m, Vp + r0, ld, Vp + r0, ld, G);  // G = V'V
+        int st = bt_gemm_splitk(c, 128, 128, m, Vp + r0, ld, Vp + r0, ld, G + b * 128 * 128);  // G_b = V'V
         if (st) return st;
-        launch_bt_larft(s, G, tau, j0, n, T);
+    }
+    launch_bt_larft(s, G, tau, nblk, n, T);
+    // pass 2: the blocks applied last first
+    for (int64_t b = nblk - 1; b >= 0; --b) {
+        const int64_t j0 = 128 * b, r0 = j0, m = ld - r0;
+        const double* Tb = T + b * 128 * 128;
+        launch_bt_extract_panel(s, n, ld, A, j0, r0, Vp, VpT);
         // X[:, r] = (V T)[r, :]':  X = T' V' as 128 x m (rows r0..)
-        launch_gemm_tn_f64(s, 128, m, 128, T, 128, VpT + r0 * 128, 128, X + r0 * 128, 128, 1, 0, 0, 0);
-        st = bt_gemm_splitk(c, 128, ld, m, Vp + r0, ld, Z + r0, ld, W);  // W = V' Z
+        launch_gemm_tn_f64(s, 128, m, 128, Tb, 128, VpT + r0 * 128, 128, X + r0 * 128, 128, 1, 0, 0, 0);
+        int st = bt_gemm_splitk(c, 128, ld, m, Vp + r0, ld, Z + r0, ld, W);  // W = V' Z
         if (st) return st;
         launch_gemm_tn_f64_sub(s, m, ld, 128, X + r0 * 128, 128, W, 128, Z + r0, ld);  // Z -= (V T) W
     }

@@ -41,10 +41,16 @@ bt_extract_panel_kernel(int n, int64_t ld, const double* __restrict__ A, int j0,
 
 // T (128 x 128, column-major, upper triangular) from the Gram matrix G = V'V and tau (dlarft,
 // forward / columnwise):  T[j,j] = tau_j,  T[0:j, j] = -tau_j * T[0:j, 0:j] * G[0:j, j].
-// One workgroup; T lives in LDS (thread i owns row i, so the recurrence needs no barriers), G
-// passes through LDS 16 columns at a time, prefetched into registers a chunk ahead.
+// One workgroup per BLOCK of reflectors (blockIdx.x = b: reflectors 128 b ..): T_b depends on its own panel only, so
+// the T factors of all blocks are formed in one launch before the blocks are applied one after the other (the
+// recurrence is a 167-us dependent chain: 32 of them in sequence were 5.3 ms of the back-transformation at N = 4096).
+// T lives in LDS (thread i owns row i, so the recurrence needs no barriers), G passes through LDS 16 columns at a
+// time, prefetched into registers a chunk ahead.
 __global__ void __launch_bounds__(128)
-bt_larft_kernel(const double* __restrict__ G, const double* __restrict__ tau, int j0, int n, double* __restrict__ T) {
+bt_larft_kernel(const double* __restrict__ Gall, const double* __restrict__ tau, int n, double* __restrict__ Tall) {
+    const int j0 = BT_KB * (int)blockIdx.x;
+    const double* __restrict__ G = Gall + (int64_t)blockIdx.x * BT_KB * BT_KB;
+    double* __restrict__ T = Tall + (int64_t)blockIdx.x * BT_KB * BT_KB;
     extern __shared__ double sm[];
     double* sT = sm;                    // 128 x 128, ld 129 (row i read by thread i: conflict-free)
     double* sg = sT + 128 * 129;        // 16 columns of G at a time: sg[c * 128 + i]
@@ -119,8 +125,9 @@ void launch_bt_extract_panel(hipStream_t s, int64_t n, int64_t ld, const double*
     dim3 grid((unsigned)((ld - r0) / 64), 2);
     bt_extract_panel_kernel<<<grid, 256, 0, s>>>((int)n, ld, A, (int)j0, (int)r0, Vp, VpT);
 }
-void launch_bt_larft(hipStream_t s, const double* G, const double* tau, int64_t j0, int64_t n, double* T) {
-    bt_larft_kernel<<<1, 128, (128 * 129 + 16 * 128) * 8, s>>>(G, tau, (int)j0, (int)n, T);
+// G, T: nblk consecutive 128 x 128 matrices (block b at offset b * 128 * 128)
+void launch_bt_larft(hipStream_t s, const double* G, const double* tau, int64_t nblk, int64_t n, double* T) {
+    bt_larft_kernel<<<(unsigned)nblk, 128, (128 * 129 + 16 * 128) * 8, s>>>(G, tau, (int)n, T);
 }
 
 }  // namespace sdpsr

@@ -3,7 +3,8 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 pkg = load_package()
-cases = [("int8 N=4096 4ch lower (product launch)", 0, 4096, 104, 40, 4 * 2 * 4096 ** 3 * (33 / 64.0)),
+cases = [("int8 N=4096 2ch lower (product launch)", 0, 4096, 102, 40, 2 * 2 * 4096 ** 3 * (33 / 64.0)),
+         ("int8 N=4096 4ch lower (round-2 launch)", 0, 4096, 104, 40, 4 * 2 * 4096 ** 3 * (33 / 64.0)),
          ("int8 N=8192 4ch full", 0, 8192, 4, 10, 4 * 2 * 8192 ** 3),
          ("fp32 N=8192", 1, 8192, 1, 10, 2 * 8192 ** 3),
          ("fp64 N=4096", 2, 4096, 1, 10, 2 * 4096 ** 3)]
