@@ -120,7 +120,13 @@ enum {
     /* basis_image: always the projection formula Q_k' 1[P==i] Q_k (src/diagonalize.jl:64-89); by default, when every
        block is 1 x 1, the images are read off as eigenvalues, blks[i][k] = q_k'(1[P==i] x) with x = sum_k q_k, under
        a randomized self-check that falls back to the projection formula (see sdpsr_block_images) */
-    SDPSR_FLAG_FULL_BASIS_IMAGE = 1u << 10
+    SDPSR_FLAG_FULL_BASIS_IMAGE = 1u << 10,
+    /* refinement: the insert pass always hashes every entry; by default, when the refined partition has at most
+       128 classes, entries are compared with short per-class candidate lists in LDS and only new classes are hashed */
+    SDPSR_FLAG_REFINE_NO_CLASSLIST = 1u << 11,
+    /* dense driver: the panel form of the tridiagonalisation (two launches per column, rank-64 trailing updates on
+       the matrix cores) at every order; by default orders <= 2048 take the one-launch-per-column row form */
+    SDPSR_FLAG_SYTRD_PANELS = 1u << 12
 };
 
 typedef struct sdpsr_opts {

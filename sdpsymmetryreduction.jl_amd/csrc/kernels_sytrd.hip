@@ -659,6 +659,219 @@ sytrd_syr2k_mfma_kernel(SytrdArgs a, int j1, int T0) {
 }
 
 // ---------------------------------------------------------------------------
+// Orders n <= SR_NMAX: ONE launch per column (round 3).  At these orders the panel form above is pure latency -- two
+// dependent launches per column, 13.4 us per column at n = 1024 -- and its two chip-wide dependencies per column (the
+// norm of the updated column, then p = A v) can be folded into one:
+//   * the whole symmetric trailing matrix is kept (both triangles), a workgroup owns ROWS of it (row i -> workgroup
+//     i mod G, two rows per wave): the product y_i = A(i, :) v of an owned row is complete inside one wave, there are no
+//     partial products to add up across workgroups;
+//   * the update is the unblocked one, A <- A - v w' - w v' (dsytd2), applied LAZILY: launch j applies the update of
+//     column j-1 to its rows in the same pass that multiplies them by v_j (one read + one write of the trailing
+//     matrix per column: n^3/3 x 16 bytes in all, 5.7 GB at n = 1024, from the L2 of the XCD that owns the row --
+//     that is why this form stops at SR_NMAX);
+//   * every workgroup forms the reflector of column j redundantly from row j (= column j) of the previous version
+//     and the full vectors v_{j-1}, y_{j-1} = A v_{j-1} and the per-workgroup partial dots y'v left by launch j-1
+//     (w_{j-1} = tau y - tau^2/2 (y'v) v needs the chip-wide scalar y'v: the sum of G partials, every workgroup adds
+//     them in the same order).  Same loads, same instruction sequence: bitwise the same v_j in every workgroup.
+// So the chain per column is one kernel boundary + (vector loads -> two block reductions -> row pass from registers,
+// whose loads were issued at the top of the kernel).  The two products of the update are rounded separately and
+// added (a - (v_i w_c + w_i v_c)): the stored matrix stays bitwise symmetric.
+// Memory: line a of the allocation (A + a ld) is row a = column a.  Reflector j is stored LAPACK-style on line j,
+// positions >= j+2, one launch late (launch j still reads line j as the matrix row).
+// ---------------------------------------------------------------------------
+constexpr int SR_NMAX = 2048;
+constexpr int SR_THREADS = 256;
+constexpr int SR_RPW = 2;  // rows per wave
+
+struct SytrdRowArgs {
+    double* A;
+    int64_t ld;
+    int n;
+    int G;         // workgroups = ceil(n / 8)
+    double* vbuf;  // 2 x ld: v_j (absolute row index), by parity of j
+    double* ybuf;  // 2 x ld: A_j v_j
+    double* pdot;  // 2 x 256: per-workgroup partial of (A_j v_j)'v_j
+    double* d;
+    double* e;
+    double* tau;
+};
+
+__device__ __forceinline__ double sr_wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// NCH: 128-column chunks of a row that can be active (ceil(ld / 128) at most)
+template <int NCH>
+__global__ void __launch_bounds__(SR_THREADS)
+sytrd_row_kernel(SytrdRowArgs a, int j) {
+    constexpr int NT = NCH / 2 > 0 ? NCH / 2 : 1;  // 256-entry slices of the vectors
+    __shared__ double s_vp[NCH * 128], s_wp[NCH * 128], s_vj[NCH * 128];
+    __shared__ double s_red[3][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = a.n, G = a.G, b = blockIdx.x;
+    const int64_t ld = a.ld;
+    const int k0 = (j + 1) >> 7, c0 = k0 << 7;  // first active chunk / its first column
+    const int par = j & 1, pp = par ^ 1;
+    double* __restrict__ A = a.A;
+
+    // ---- loads that depend on nothing: the owned rows, the vectors of the previous column, row j
+    int rowi[SR_RPW];
+    double2 xr[SR_RPW][NCH];
+    {
+        int first = j + 1 + ((b - (j + 1)) % G + G) % G;
+#pragma unroll
+        for (int r = 0; r < SR_RPW; ++r) {
+            const int i = first + G * (wv + 4 * r);
+            rowi[r] = i < n ? i : -1;
+            const double* __restrict__ line = A + (int64_t)(i < n ? i : 0) * ld + c0 + 2 * lane;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                xr[r][k] = double2{0.0, 0.0};
+                if (i < n && c0 + 128 * k < n) xr[r][k] = *reinterpret_cast<const double2*>(line + 128 * k);
+            }
+        }
+    }
+    double vpv[NT], ypv[NT], rjv[NT];
+    const double* __restrict__ vprev = a.vbuf + (int64_t)pp * ld;
+    const double* __restrict__ yprev = a.ybuf + (int64_t)pp * ld;
+    const double* __restrict__ linej = A + (int64_t)j * ld;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int i = c0 + tid + 256 * t;
+        const bool in = i > j && i < n;
+        vpv[t] = (in && j > 0) ? vprev[i] : 0.0;
+        ypv[t] = (in && j > 0) ? yprev[i] : 0.0;
+        rjv[t] = in ? linej[i] : 0.0;
+    }
+    const double tau_p = j > 0 ? a.tau[j - 1] : 0.0;
+    const double yp_j = j > 0 ? yprev[j] : 0.0;  // entry j of the previous product (v_{j-1}(j) = 1)
+    const double ajj = linej[j];
+    double pd = (j > 0 && tid < G) ? a.pdot[pp * 256 + tid] : 0.0;
+
+    // ---- s = y'v of the previous column, then w_{j-1} (LDS) and the updated column x
+    pd = sr_wave_sum(pd);
+    if (lane == 0) s_red[0][wv] = pd;
+    __syncthreads();
+    const double sdot = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    const double hts = 0.5 * tau_p * tau_p * sdot;  // w = tau y - (tau^2 s / 2) v
+    const double wp_j = tau_p * yp_j - hts;
+    double xv[NT];
+    double xn2 = 0.0, alpha = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int i = c0 + tid + 256 * t;
+        const double wpi = tau_p * ypv[t] - hts * vpv[t];
+        s_vp[tid + 256 * t] = vpv[t];
+        s_wp[tid + 256 * t] = wpi;
+        xv[t] = rjv[t] - (__dmul_rn(vpv[t], wp_j) + wpi);  // - (v_i w_j + w_i v_j), v_j = 1
+        if (i > j + 1 && i < n) xn2 = fma(xv[t], xv[t], xn2);
+        if (i == j + 1) alpha = xv[t];
+    }
+    // norm of x below its leading entry and the leading entry itself, to every thread
+    xn2 = sr_wave_sum(xn2);
+    alpha = sr_wave_sum(alpha);  // one lane holds it, the others 0
+    if (lane == 0) {
+        s_red[1][wv] = xn2;
+        s_red[2][wv] = alpha;
+    }
+    __syncthreads();
+    xn2 = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    alpha = (s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3]);
+    double beta, tau, scale;
+    if (xn2 == 0.0) {  // dlarfg: H = I
+        tau = 0.0;
+        beta = alpha;
+        scale = 0.0;
+    } else {
+        beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    double* __restrict__ vout = a.vbuf + (int64_t)par * ld;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int i = c0 + tid + 256 * t;
+        double v = 0.0;
+        if (i == j + 1) v = 1.0;
+        else if (i > j + 1 && i < n) v = xv[t] * scale;
+        s_vj[tid + 256 * t] = v;
+        if (b == 0 && i > j && i < n) vout[i] = v;
+    }
+    if (b == 0 && tid == 0) {
+        a.d[j] = ajj - (wp_j + wp_j);
+        a.e[j] = beta;
+        a.tau[j] = tau;
+    }
+    // reflector j-1 to its LAPACK place (line j-1, positions >= j+1): nobody reads that line any more
+    if (j > 0 && b == (G > 1 ? 1 : 0)) {
+        double* __restrict__ ref = A + (int64_t)(j - 1) * ld;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int i = c0 + tid + 256 * t;
+            if (i > j && i < n) ref[i] = vpv[t];
+        }
+    }
+    __syncthreads();
+
+    // ---- owned rows: update of column j-1, product with v_j
+    double pdw = 0.0;
+#pragma unroll
+    for (int r = 0; r < SR_RPW; ++r) {
+        const int i = rowi[r];
+        if (i < 0) continue;  // wave-uniform
+        const double vi = s_vp[i - c0], wi = s_wp[i - c0], vji = s_vj[i - c0];
+        double acc0 = 0.0, acc1 = 0.0;
+        double* __restrict__ line = A + (int64_t)i * ld + c0 + 2 * lane;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (c0 + 128 * k < n) {
+                const double2 vp2 = *reinterpret_cast<const double2*>(&s_vp[128 * k + 2 * lane]);
+                const double2 wp2 = *reinterpret_cast<const double2*>(&s_wp[128 * k + 2 * lane]);
+                const double2 vj2 = *reinterpret_cast<const double2*>(&s_vj[128 * k + 2 * lane]);
+                double2 x = xr[r][k];
+                x.x = x.x - (__dmul_rn(vi, wp2.x) + __dmul_rn(wi, vp2.x));
+                x.y = x.y - (__dmul_rn(vi, wp2.y) + __dmul_rn(wi, vp2.y));
+                acc0 = fma(x.x, vj2.x, acc0);
+                acc1 = fma(x.y, vj2.y, acc1);
+                if (j > 0) *reinterpret_cast<double2*>(line + 128 * k) = x;
+            }
+        }
+        const double y = sr_wave_sum(acc0 + acc1);
+        if (lane == 0) a.ybuf[(int64_t)par * ld + i] = y;
+        pdw = fma(y, vji, pdw);
+    }
+    if (lane == 0) s_red[0][wv] = pdw;  // (s_red[0] was last read before the two barriers above)
+    __syncthreads();
+    if (tid == 0) a.pdot[par * 256 + b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+}
+
+// upper triangle <- lower triangle (the callers promise the lower one only): line a, positions < a
+__global__ void __launch_bounds__(256)
+sytrd_row_mirror_kernel(int n, int64_t ld, double* __restrict__ A) {
+    __shared__ double tile[64][65];
+    // tile pair (I, J), I > J: block (rows 64 I.., line 64 J..) is valid, its mirror is written; I == J in place
+    int t = blockIdx.x, I = 0;
+    while (t > I) {
+        t -= I + 1;
+        ++I;
+    }
+    const int J = t;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4) {
+        const int line = 64 * J + c, pos = 64 * I + tx;
+        tile[c][tx] = (line < n && pos < n) ? A[(int64_t)line * ld + pos] : 0.0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        const int line = 64 * I + c, pos = 64 * J + tx;
+        if (line < n && pos < n && pos < line) A[(int64_t)line * ld + pos] = tile[tx][c];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host driver.  A: n x n inside an ld x ld allocation, ld a multiple of 128 (tiles read whole
 // 128-row / 64-column blocks; entries outside the lower triangle of the leading n x n part are
 // read but never used).
@@ -798,11 +1011,48 @@ static bool emit_sytrd(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, dou
     return em.ok;
 }
 
+// one launch per column (sytrd_row_kernel): n <= SR_NMAX
+static bool emit_sytrd_rows(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
+    const int n = (int)n64;
+    if (n == 1) {
+        em.copy8(d, A);
+        return em.ok;
+    }
+    SytrdRowArgs a;
+    a.A = A;
+    a.ld = ld;
+    a.n = n;
+    a.G = (n + 7) / 8;
+    a.vbuf = ws;
+    a.ybuf = ws + 2 * ld;
+    a.pdot = ws + 4 * ld;
+    a.d = d;
+    a.e = e;
+    a.tau = tau;
+    const int T = (n + 63) / 64;
+    em.kernel(reinterpret_cast<const void*>(&sytrd_row_mirror_kernel), (unsigned)(T * (T + 1) / 2), 256, 0, n, ld, A);
+    const int nch_all = (n + 127) / 128;
+    for (int j = 0; j <= n - 2; ++j) {
+        const int nch = nch_all - ((j + 1) >> 7);  // chunks still active
+        const void* fn = nch <= 2   ? reinterpret_cast<const void*>(&sytrd_row_kernel<2>)
+                         : nch <= 4 ? reinterpret_cast<const void*>(&sytrd_row_kernel<4>)
+                         : nch <= 8 ? reinterpret_cast<const void*>(&sytrd_row_kernel<8>)
+                                    : reinterpret_cast<const void*>(&sytrd_row_kernel<16>);
+        em.kernel(fn, (unsigned)a.G, SR_THREADS, 0, a, j);
+    }
+    em.copy8(d + (n - 1), A + (int64_t)(n - 1) * ld + (n - 1));  // tau(n-2) = 0: the last diagonal entry is final
+    return em.ok;
+}
+static bool sytrd_use_rows(const sdpsr_ctx* c, int64_t n, int64_t ld) {
+    return n <= SR_NMAX && ld >= n && !(c && (c->opts.flags & SDPSR_FLAG_SYTRD_PANELS));
+}
+
 static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
-                                double* ws) {
+                                double* ws, bool rows) {
     SytrdEmitter em;
     em.s = s;
-    emit_sytrd(em, n64, A, ld, d, e, tau, ws);
+    if (rows) emit_sytrd_rows(em, n64, A, ld, d, e, tau, ws);
+    else emit_sytrd(em, n64, A, ld, d, e, tau, ws);
 }
 
 // measurement hook: only the symv launches of a full tridiagonalisation (same grid shapes and
@@ -831,6 +1081,7 @@ void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, 
 // one ctx are serialised by contract, so no lock is needed.
 struct SytrdGraph {
     int64_t n = 0, ld = 0;
+    bool rows = false;
     const void *A = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr, *ws = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t last_use = 0;
@@ -849,8 +1100,9 @@ void sytrd_graph_cache_destroy(SytrdGraphCache* g) {
 void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
     hipStream_t s = c->stream;
     const bool no_graph = (c->opts.flags & SDPSR_FLAG_NO_GRAPH) != 0;  // profiling: per-kernel statistics of the launches
+    const bool rows = sytrd_use_rows(c, n64, ld);
     if (no_graph || n64 < 64) {
-        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
+        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, rows);
         return;
     }
     if (!c->sytrd_graphs) c->sytrd_graphs = new SytrdGraphCache();
@@ -858,7 +1110,7 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
     ++gc.clock;
     SytrdGraph* slot = nullptr;
     for (auto& g : gc.slots)
-        if (g.exec && g.n == n64 && g.ld == ld && g.A == A && g.d == d && g.e == e && g.tau == tau && g.ws == ws) slot = &g;
+        if (g.exec && g.n == n64 && g.ld == ld && g.rows == rows && g.A == A && g.d == d && g.e == e && g.tau == tau && g.ws == ws) slot = &g;
     if (!slot) {
         SytrdGraph* victim = &gc.slots[0];
         for (auto& g : gc.slots)
@@ -875,18 +1127,19 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
         if (ok) {
             SytrdEmitter em;
             em.graph = graph;
-            ok = emit_sytrd(em, n64, A, ld, d, e, tau, ws);
+            ok = rows ? emit_sytrd_rows(em, n64, A, ld, d, e, tau, ws) : emit_sytrd(em, n64, A, ld, d, e, tau, ws);
         }
         if (ok) ok = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0) == hipSuccess;
         if (graph) hipGraphDestroy(graph);
         if (!ok) {  // graph construction failed: plain launches
             victim->exec = nullptr;
             (void)hipGetLastError();
-            launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
+            launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, rows);
             return;
         }
         victim->n = n64;
         victim->ld = ld;
+        victim->rows = rows;
         victim->A = A;
         victim->d = d;
         victim->e = e;
@@ -897,7 +1150,7 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
     slot->last_use = gc.clock;
     if (hipGraphLaunch(slot->exec, s) != hipSuccess) {
         (void)hipGetLastError();
-        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws);
+        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, rows);
     }
 }
 

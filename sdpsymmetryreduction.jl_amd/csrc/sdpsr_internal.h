@@ -147,6 +147,7 @@ struct RefineWs {
     uint32_t* tab_lab;   // cap
     uint32_t* blk_cnt;   // nblk + 1
     int insert_wgs_per_cu = 0;  // sdpsr_opts.insert_wgs_per_cu (0 = default)
+    int no_classlist = 0;       // SDPSR_FLAG_REFINE_NO_CLASSLIST: always the hash form of the insert pass
     uint32_t* host_counters = nullptr;  // pinned host memory: counters[0..2] are also stored there by the label pass (plain label pass only)
     int expect_small = 0;  // host prediction: <= refine_small_k() classes (see launch_refine)
     uint32_t* first_idx = nullptr;  // optional: first-occurrence index of class l at [l - 1], l <= refine_first_cap()
@@ -173,6 +174,7 @@ struct SigSource {
     int64_t n = 0, ld = 0;                                        // SIG_CHAN_* (launch_sig_i32 / launch_sig_f32)
     int T = 0;
     const void* C = nullptr;
+    int64_t d_old = 0;                                            // number of classes of L when the caller knows it (0 = unknown): few classes take the class-list insert
     int packed = 0;                                               // lower triangle only, densely packed (symmetric labels; SIG_PROJ: and symmetric basis, needs n)
     int lab_packed = 0;                                           // (with packed) L is the packed lower triangle itself: label of packed entry e = L[e]
     const uint32_t* zero_flag = nullptr;                          // device constant 0 when packed (the kernels' "lower" flag)

@@ -18,7 +18,8 @@ else:
     A = np.ascontiguousarray(np.concatenate([[0.0], rng.random(d)])[Ls])  # C order: empty_like(tA) below must be row-major
 dev = torch.device('cuda:0')
 tA = torch.from_numpy(A).to(dev); tV = torch.empty_like(tA); tw = torch.empty(n, dtype=torch.float64, device=dev)
-with pkg.Context(seed=1, eig_driver=drv) as ctx:
+flags = int(os.environ.get("SDPSR_TOOL_FLAGS", "0"))
+with pkg.Context(seed=1, eig_driver=drv, flags=flags) as ctx:
     lib = ctx._lib
     for rep in range(3):
         torch.cuda.synchronize(); t = time.time()

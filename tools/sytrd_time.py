@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 pkg = load_package()
 ns = [int(x) for x in sys.argv[1:]] or [4096]
-with pkg.Context(seed=1) as ctx:
+with pkg.Context(seed=1, flags=int(os.environ.get("SDPSR_TOOL_FLAGS", "0"))) as ctx:
     lib = ctx._lib
     def prof(kind, n, aux=0, reps=3):
         v = C.c_double(0); ctx.check(pkg._lib.load_prof_library().sdpsr_profile_kernel(ctx._h, kind, n, aux, reps, C.byref(v))); return v.value
