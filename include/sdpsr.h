@@ -121,12 +121,14 @@ enum {
        block is 1 x 1, the images are read off as eigenvalues, blks[i][k] = q_k'(1[P==i] x) with x = sum_k q_k, under
        a randomized self-check that falls back to the projection formula (see sdpsr_block_images) */
     SDPSR_FLAG_FULL_BASIS_IMAGE = 1u << 10,
-    /* refinement: the insert pass always hashes every entry; by default, when the refined partition has at most
-       128 classes, entries are compared with short per-class candidate lists in LDS and only new classes are hashed */
-    SDPSR_FLAG_REFINE_NO_CLASSLIST = 1u << 11,
+    /* (1u << 11: unused) */
     /* dense driver: the panel form of the tridiagonalisation (two launches per column, rank-64 trailing updates on
        the matrix cores) at every order; by default orders <= 2048 take the one-launch-per-column row form */
-    SDPSR_FLAG_SYTRD_PANELS = 1u << 12
+    SDPSR_FLAG_SYTRD_PANELS = 1u << 12,
+    /* eigen_decomposition: the coupling matrix of the eigenspaces (block norms, src/eigen_decomposition.jl:177-217) is
+       always read back and thresholded on the host; by default, from 256 eigenspaces on, its extrema, the histogram
+       counts of the Otsu threshold and one bit per pair are formed on the device (same classes) */
+    SDPSR_FLAG_COUPLING_ON_HOST = 1u << 13
 };
 
 typedef struct sdpsr_opts {

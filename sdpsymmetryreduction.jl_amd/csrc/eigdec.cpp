@@ -43,53 +43,27 @@ struct DisjointSets {
     }
 };
 
-// otsu_threshold + log_histogram, src/eigen_decomposition.jl:83-139
-double otsu_threshold(const std::vector<double>& X, double atol) {
-    const int nb = std::max((int)std::ceil(-std::log10(2.220446049250313e-16)), 4);  // 16
-    double mn = INFINITY, mx = 0;
-    {  // eight independent running minima / maxima (one chain is bound by the latency of min / max: 2 x 4 clocks per value)
-        double mns[8], mxs[8];
-        for (int q = 0; q < 8; ++q) mns[q] = INFINITY, mxs[q] = 0;
-        const size_t nx = X.size(), n8 = nx & ~size_t(7);
-        const double* xp = X.data();
-        for (size_t e = 0; e < n8; e += 8)
-            for (int q = 0; q < 8; ++q) {
-                const double a = std::fabs(xp[e + q]);
-                mns[q] = std::min(mns[q], a);  // std::min(a, b) = (b < a) ? b : a: a NaN in b never replaces a, as in the scalar loop
-                mxs[q] = std::max(mxs[q], a);
-            }
-        for (size_t e = n8; e < nx; ++e) {
-            const double a = std::fabs(xp[e]);
-            mns[0] = std::min(mns[0], a);
-            mxs[0] = std::max(mxs[0], a);
-        }
-        for (int q = 0; q < 8; ++q) mn = std::min(mn, mns[q]), mx = std::max(mx, mxs[q]);
-    }
+// otsu_threshold + log_histogram, src/eigen_decomposition.jl:83-139, in three steps so that the values may stay on
+// the device (isomorphism_classes_device): extrema -> edges, counts per number of edges below a value -> threshold
+constexpr int OTSU_NB = 16;  // max(ceil(-log10(eps(Float64))), 4)
+static void otsu_edges(double mn, double mx, double atol, double (&edges)[OTSU_NB + 1]) {
     if (mn < atol) mn = atol;
-    std::vector<double> edges(nb + 1);
     const double l0 = std::log(mn), l1 = std::log(mx);
-    for (int i = 0; i <= nb; ++i) {
+    for (int i = 0; i <= OTSU_NB; ++i) {
         // Julia range(a, b, length=n): a + i*(b-a)/(n-1), endpoints exact
-        double t = (i == nb) ? l1 : l0 + (l1 - l0) * (double)i / (double)nb;
+        double t = (i == OTSU_NB) ? l1 : l0 + (l1 - l0) * (double)i / (double)OTSU_NB;
         edges[i] = std::exp(t);
     }
+}
+// cnt[c], c = 0..17: number of values with exactly c edges <= them (a NaN: 17)
+static double otsu_pick(const double (&edges)[OTSU_NB + 1], const int64_t (&cnt)[OTSU_NB + 2]) {
+    const int nb = OTSU_NB;
     std::vector<double> counts(nb, 0.0);
     {
-        // something(findfirst(b -> b > x, edges), nb + 1) (1-based) = 1 + #{edges <= x} for ascending edges:
-        // counted without branches (the loop vectorises; neig^2 values -- a million at neig = 1024 -- go through it)
+        // something(findfirst(b -> b > x, edges), nb + 1) (1-based) = 1 + #{edges <= x} for ascending edges;
+        // f = min(c + 1, nb + 1): no edge above x (c = 17: x >= the last edge, or a NaN) is the default nb + 1
         std::vector<int64_t> hist(nb + 2, 0);
-        if (nb == 16) {
-            int64_t cnt[18];
-            host_count_edges17(X.data(), X.size(), edges.data(), cnt);  // cnt[c]: c edges <= x
-            // f = min(c + 1, nb + 1): no edge above x (c = 17: x >= the last edge, or a NaN) is the default nb + 1
-            for (int cidx = 0; cidx <= 17; ++cidx) hist[cidx + 1 < nb + 1 ? cidx + 1 : nb + 1] += cnt[cidx];
-        } else {
-            for (double x : X) {
-                int le = 0;
-                for (int i = 0; i <= nb; ++i) le += !(edges[i] > x);
-                ++hist[le + 1 < nb + 1 ? le + 1 : nb + 1];
-            }
-        }
+        for (int cidx = 0; cidx <= 17; ++cidx) hist[cidx + 1 < nb + 1 ? cidx + 1 : nb + 1] += cnt[cidx];
         for (int f = 1; f <= nb + 1; ++f) {
             const int bin = std::min(std::max(f - 1, 1), nb);
             counts[bin - 1] += (double)hist[f];
@@ -125,6 +99,33 @@ double otsu_threshold(const std::vector<double>& X, double atol) {
     }
     return edges[best + 1];
 }
+double otsu_threshold(const std::vector<double>& X, double atol) {
+    double mn = INFINITY, mx = 0;
+    {  // eight independent running minima / maxima (one chain is bound by the latency of min / max: 2 x 4 clocks per value)
+        double mns[8], mxs[8];
+        for (int q = 0; q < 8; ++q) mns[q] = INFINITY, mxs[q] = 0;
+        const size_t nx = X.size(), n8 = nx & ~size_t(7);
+        const double* xp = X.data();
+        for (size_t e = 0; e < n8; e += 8)
+            for (int q = 0; q < 8; ++q) {
+                const double a = std::fabs(xp[e + q]);
+                mns[q] = std::min(mns[q], a);  // std::min(a, b) = (b < a) ? b : a: a NaN in b never replaces a, as in the scalar loop
+                mxs[q] = std::max(mxs[q], a);
+            }
+        for (size_t e = n8; e < nx; ++e) {
+            const double a = std::fabs(xp[e]);
+            mns[0] = std::min(mns[0], a);
+            mxs[0] = std::max(mxs[0], a);
+        }
+        for (int q = 0; q < 8; ++q) mn = std::min(mn, mns[q]), mx = std::max(mx, mxs[q]);
+    }
+    double edges[OTSU_NB + 1];
+    otsu_edges(mn, mx, atol, edges);
+    // counted without branches (the loop vectorises; neig^2 values go through it)
+    int64_t cnt[OTSU_NB + 2];
+    host_count_edges17(X.data(), X.size(), edges, cnt);  // cnt[c]: c edges <= x
+    return otsu_pick(edges, cnt);
+}
 
 
 // Otsu threshold + union-find + __isconsistent on a symmetric neig x neig coupling matrix
@@ -136,6 +137,67 @@ int isomorphism_classes(sdpsr_ctx* c, const std::vector<double>& norms, int neig
     for (int i = 0; i < neig; ++i)
         for (int j = i + 1; j < neig; ++j)
             if (norms[(size_t)i * neig + j] >= thr) K.unite(i, j);
+    kpart.resize(neig);
+    for (int i = 0; i < neig; ++i) kpart[i] = K.find(i);
+    std::vector<int> first(neig, -1);
+    for (int i = 0; i < neig; ++i)
+        if (first[kpart[i]] < 0) first[kpart[i]] = i;
+    for (int i = 0; i < neig; ++i)
+        if (first[kpart[i]] != kpart[i])
+            return ctx_fail(c, SDPSR_NUMERICAL_INCONSISTENCY,
+                            "eigen_decomposition: the K-partition seems inconsistent with eigenspaces. Decrease atol, or simply try again.");
+    return SDPSR_OK;
+}
+
+// The same with the coupling matrix on the device (kernels_blockdiag.hip coupling_*): the matrix is symmetrised with the
+// dimension rule there, the host sees its extrema, the 18 counts and one bit per pair.  The union-find visits the
+// pairs in the reference's order (i, then j > i); a pair whose ends already share a root is a no-op there too.
+int isomorphism_classes_device(sdpsr_ctx* c, unsigned long long* dnorms, int neig, const std::vector<int32_t>& dims, double atol,
+                               std::vector<int>& kpart) {
+    hipStream_t s = c->stream;
+    const int W = (neig + 63) / 64;
+    int32_t* ddims = (int32_t*)ctx_buf(c, "bd_dims", (size_t)neig * 4);
+    unsigned long long* stat = (unsigned long long*)ctx_buf(c, "bd_cstat", 32 * 8);
+    unsigned long long* dbits = (unsigned long long*)ctx_buf(c, "bd_cbits", (size_t)neig * W * 8);
+    if (!ddims || !stat || !dbits) return SDPSR_OUT_OF_MEMORY;
+    int st = h2d_sync(c, ddims, dims.data(), (size_t)neig * 4);
+    if (st) return st;
+    HIP_TRY(c, hipMemsetAsync(stat, 0, 32 * 8, s));
+    launch_coupling_symmetrize_minmax(s, neig, dnorms, ddims, stat);
+    unsigned long long hs[32];
+    st = d2h_sync(c, hs, stat, 16);
+    if (st) return st;
+    auto as_double = [](unsigned long long b) {
+        double x;
+        memcpy(&x, &b, 8);
+        return x;
+    };
+    const double mn = hs[0] ? as_double(~hs[0]) : INFINITY, mx = as_double(hs[1]);
+    double edges[OTSU_NB + 1];
+    otsu_edges(mn, mx, atol, edges);
+    launch_coupling_count(s, neig, dnorms, edges, stat);
+    st = d2h_sync(c, hs, stat, 20 * 8);
+    if (st) return st;
+    int64_t cnt[OTSU_NB + 2];
+    for (int q = 0; q <= 17; ++q) cnt[q] = (int64_t)hs[2 + q];
+    const double thr = otsu_pick(edges, cnt);
+    launch_coupling_bits(s, neig, dnorms, thr, dbits);
+    const unsigned long long* hb = (const unsigned long long*)ctx_pinned(c, (size_t)neig * W * 8);
+    if (!hb) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
+    HIP_TRY(c, hipMemcpyAsync((void*)hb, dbits, (size_t)neig * W * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    DisjointSets K(neig);
+    for (int i = 0; i < neig; ++i) {
+        const unsigned long long* row = hb + (size_t)i * W;
+        for (int w = i / 64; w < W; ++w) {
+            unsigned long long m = row[w];
+            while (m) {
+                const int j = 64 * w + __builtin_ctzll(m);
+                m &= m - 1;
+                K.unite(i, j);
+            }
+        }
+    }
     kpart.resize(neig);
     for (int i = 0; i < neig; ++i) kpart[i] = K.find(i);
     std::vector<int> first(neig, -1);
@@ -294,7 +356,6 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
             launch_block_norms(s, n, ld, Ap, dspace, neig, dnorms);
         }
         tm.end();
-        norms.resize((size_t)neig * neig);
     }
     auto dimof = [&](int b) { return info.ptrs[b + 1] - info.ptrs[b]; };
     // The coupling of an isomorphic pair of eigenspaces under ONE generic element is the maximum over
@@ -308,8 +369,19 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
     // independent generic element (block_norms accumulates maxima: a coupling can only grow) and
     // the classes are formed again, up to twice.  The common case pays nothing;
     // SDPSR_FLAG_SINGLE_COUPLING_ELEMENT keeps the reference's single element (:259-262).
+    // many eigenspaces: the coupling matrix stays on the device (isomorphism_classes_device)
+    const bool classes_on_device = !have_norms && neig >= 256 && !(c->opts.flags & SDPSR_FLAG_COUPLING_ON_HOST);
     for (int extra = 0;; ++extra) {
+        if (classes_on_device) {
+            std::vector<int32_t> dims(neig);
+            for (int i = 0; i < neig; ++i) dims[i] = dimof(i);
+            // (a raised matrix of a later pass is symmetric already: maxima of symmetric blocks were added to both halves)
+            st = isomorphism_classes_device(c, dnorms, neig, dims, atol, info.kpart);
+            tm.collect();
+            dbg_mark(c, "eigen_decomposition: Otsu + union-find done (coupling matrix on the device)");
+        } else {
         if (!(have_norms && extra == 0)) {
+            norms.resize((size_t)neig * neig);
             st = d2h_sync(c, norms.data(), dnorms, (size_t)neig * neig * 8);
             if (st) return st;
             tm.collect();
@@ -324,6 +396,7 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
         dbg_mark(c, "eigen_decomposition: block norms on the host");
         st = isomorphism_classes(c, norms, neig, atol, info.kpart);
         dbg_mark(c, "eigen_decomposition: Otsu + union-find done");
+        }
         if (expect_dim < 0 || extra >= 2 || (c->opts.flags & SDPSR_FLAG_SINGLE_COUPLING_ELEMENT)) return st;
         if (st != SDPSR_OK && st != SDPSR_NUMERICAL_INCONSISTENCY) return st;
         if (st == SDPSR_OK) {

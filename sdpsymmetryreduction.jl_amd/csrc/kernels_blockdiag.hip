@@ -156,6 +156,91 @@ void launch_small_cluster_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld,
                                                                 (int32_t*)pack, (unsigned long long*)(pack + o_norms), Tout, einfo,
                                                                 (double*)(pack + o_vals));
 }
+// ---------------------------------------------------------------------------
+// Isomorphism classes of MANY eigenspaces (neig >= 256, e.g. the 1024 one-dimensional eigenspaces of a partition
+// without symmetry): the neig x neig coupling matrix stays on the device.  What the host needs from it
+// (src/eigen_decomposition.jl:83-139, 205-217) is: min / max of the entries (-> the 17 edges of the log-histogram), how
+// many entries have c = 0..17 edges <= them (-> the Otsu threshold), and which pairs i < j reach the threshold (one bit
+// each, for the union-find).  Three small kernels with a 16- / 144-byte / neig^2 / 8-byte read-back each instead of
+// 8 neig^2 bytes through PCIe and four host passes over them.  Every quantity is an exact function of the entries
+// (extrema, integer counts, comparisons): the classes are the ones the host code finds.
+//   stat[0] = max of ~bits(x) over the entries (= ~bits(min); 0 when there is no entry), stat[1] = max of bits(x),
+//   stat[2 + c] = number of entries with exactly c edges <= x.   (x >= 0: the bit pattern orders like the value; a NaN
+//   never replaces an extremum and counts as 17, as in the host loops.)
+// ---------------------------------------------------------------------------
+// blocks between eigenspaces of different dimension count as zero (:185-186); norms[i, j] (i <= j: row space i) is
+// mirrored like end_norm[i, j] = end_norm[j, i]
+__global__ void __launch_bounds__(256)
+coupling_symmetrize_minmax_kernel(int neig, unsigned long long* __restrict__ norms, const int32_t* __restrict__ dims,
+                                  unsigned long long* __restrict__ stat) {
+    const int64_t len = (int64_t)neig * neig;
+    double mn = INFINITY, mx = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / neig), j = (int)(e - (int64_t)i * neig);
+        if (i > j) continue;
+        const unsigned long long v = (dims[i] != dims[j]) ? 0ull : norms[e];
+        norms[e] = v;
+        norms[(int64_t)j * neig + i] = v;
+        const double a = fabs(__longlong_as_double((long long)v));
+        if (a < mn) mn = a;
+        if (mx < a) mx = a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double on = __shfl_xor(mn, o, 64), ox = __shfl_xor(mx, o, 64);
+        if (on < mn) mn = on;
+        if (mx < ox) mx = ox;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mn < INFINITY) atomicMax(&stat[0], ~(unsigned long long)__double_as_longlong(mn));
+        if (mx > 0.0) atomicMax(&stat[1], (unsigned long long)__double_as_longlong(mx));
+    }
+}
+struct CouplingEdges {
+    double e[17];
+};
+__global__ void __launch_bounds__(256)
+coupling_count_kernel(int64_t len, const unsigned long long* __restrict__ norms, CouplingEdges ed,
+                      unsigned long long* __restrict__ stat) {
+    __shared__ unsigned int h[18];
+    if (threadIdx.x < 18) h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += (int64_t)gridDim.x * blockDim.x) {
+        const double x = __longlong_as_double((long long)norms[e]);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) c += (ed.e[i] > x) ? 0 : 1;
+        atomicAdd(&h[c], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 18 && h[threadIdx.x]) atomicAdd(&stat[2 + threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+// bits[i * W + w], bit b: pair (i, j = 64 w + b), j > i, coupling >= thr
+__global__ void __launch_bounds__(256)
+coupling_bits_kernel(int neig, int W, const unsigned long long* __restrict__ norms, double thr,
+                     unsigned long long* __restrict__ bits) {
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= (int64_t)neig * W) return;  // wave-uniform
+    const int i = (int)(wave / W), w = (int)(wave - (int64_t)i * W);
+    const int j = 64 * w + (threadIdx.x & 63);
+    const bool on = j > i && j < neig && __longlong_as_double((long long)norms[(int64_t)i * neig + j]) >= thr;
+    const unsigned long long m = __ballot(on);
+    if ((threadIdx.x & 63) == 0) bits[wave] = m;
+}
+void launch_coupling_symmetrize_minmax(hipStream_t s, int neig, unsigned long long* norms, const int32_t* dims, unsigned long long* stat) {
+    coupling_symmetrize_minmax_kernel<<<grid_for((int64_t)neig * neig, 256), 256, 0, s>>>(neig, norms, dims, stat);
+}
+void launch_coupling_count(hipStream_t s, int neig, const unsigned long long* norms, const double* edges17, unsigned long long* stat) {
+    CouplingEdges ed;
+    for (int i = 0; i < 17; ++i) ed.e[i] = edges17[i];
+    coupling_count_kernel<<<grid_for((int64_t)neig * neig, 256), 256, 0, s>>>((int64_t)neig * neig, norms, ed, stat);
+}
+void launch_coupling_bits(hipStream_t s, int neig, const unsigned long long* norms, double thr, unsigned long long* bits) {
+    const int W = (neig + 63) / 64;
+    const int64_t threads = (int64_t)neig * W * 64;
+    coupling_bits_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(neig, W, norms, thr, bits);
+}
+
 void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
                         const int32_t* space_of, int neig, unsigned long long* norms) {
     block_norms_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, M, space_of, neig, norms);

@@ -871,31 +871,19 @@ struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by c
         for (int t = 0; t < T; ++t) r.c[t] = __builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
         return r;
     }
-    // the entry as (old label, 64-bit words): what the class-list insert compares instead of a hashed signature
-    static constexpr int kWords = (T + 1) / 2;
-    __device__ __forceinline__ double class_draw(uint32_t) const { return 0.0; }
-    __device__ __forceinline__ void words(const Raw& r, double, uint64_t (&w)[kWords]) const {
+    __device__ __forceinline__ uint64_t sig(const Raw& r) const {
         int32_t c[T + (T & 1)];
 #pragma unroll
         for (int t = 0; t < T; ++t) c[t] = (int32_t)r.c[t];  // exact: f32 channels hold integers < 2^24
         if constexpr ((T & 1) != 0) c[T] = 0;
-#pragma unroll
-        for (int t = 0; t < T; t += 2) w[t / 2] = (uint64_t)(uint32_t)c[t] | ((uint64_t)(uint32_t)c[t + 1] << 32);
-    }
-    __device__ __forceinline__ uint64_t sig_words(uint32_t l, const uint64_t (&w)[kWords]) const {
-        uint64_t h = sdpsr_sig_start(l);
+        uint64_t h = sdpsr_sig_start(r.l);
         bool allz = true;
 #pragma unroll
-        for (int i = 0; i < kWords; ++i) {
-            allz = allz && w[i] == 0;
-            h = sdpsr_sig_mix(h, w[i]);
+        for (int t = 0; t < T; t += 2) {
+            allz = allz && (c[t] == 0) && (c[t + 1] == 0);
+            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)c[t] | ((uint64_t)(uint32_t)c[t + 1] << 32));
         }
-        return finish_sig(l, allz, h);
-    }
-    __device__ __forceinline__ uint64_t sig(const Raw& r) const {
-        uint64_t w[kWords];
-        words(r, 0.0, w);
-        return sig_words(r.l, w);
+        return finish_sig(r.l, allz, h);
     }
     __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const { return sig(fetch(i, j, e)); }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
@@ -941,32 +929,20 @@ struct SrcJoint {
         for (int t = 0; t < T; ++t) r.c[t] = __builtin_nontemporal_load(&Cij[(int64_t)t * ld * ld]);
         return r;
     }
-    // the entry as (old label, 64-bit words): code of the rounded projection, channel pairs.  x = the class's draw
-    // (a per-class constant: the class-list insert keeps it in LDS instead of hashing it per entry)
-    static constexpr int kWords = 1 + T / 2;
-    __device__ __forceinline__ double class_draw(uint32_t l) const { return l ? sdpsr_class_uniform(key, l) : 0.0; }
-    __device__ __forceinline__ void words(const Raw& r, double x, uint64_t (&w)[kWords]) const {
+    __device__ __forceinline__ uint64_t sig(const Raw& r) const {
+        const double x = r.l ? sdpsr_class_uniform(key, r.l) : 0.0;
         double p = 0;
 #pragma unroll
         for (int k = 0; k < R; ++k) p = fma(r.u[k], coef[k], p);
-        w[0] = sdpsr_round_key(x - p, atol, scale);
+        const uint64_t kb = sdpsr_round_key(x - p, atol, scale);
+        uint64_t h = sdpsr_sig_mix(sdpsr_sig_start(r.l), kb);
+        bool allz = kb == 0;
 #pragma unroll
-        for (int t = 0; t < T; t += 2) w[1 + t / 2] = (uint64_t)(uint32_t)r.c[t] | ((uint64_t)(uint32_t)r.c[t + 1] << 32);
-    }
-    __device__ __forceinline__ uint64_t sig_words(uint32_t l, const uint64_t (&w)[kWords]) const {
-        uint64_t h = sdpsr_sig_start(l);
-        bool allz = true;
-#pragma unroll
-        for (int i = 0; i < kWords; ++i) {
-            allz = allz && w[i] == 0;
-            h = sdpsr_sig_mix(h, w[i]);
+        for (int t = 0; t < T; t += 2) {
+            h = sdpsr_sig_mix(h, (uint64_t)(uint32_t)r.c[t] | ((uint64_t)(uint32_t)r.c[t + 1] << 32));
+            allz = allz && r.c[t] == 0 && r.c[t + 1] == 0;
         }
-        return finish_sig(l, allz, h);
-    }
-    __device__ __forceinline__ uint64_t sig(const Raw& r) const {
-        uint64_t w[kWords];
-        words(r, class_draw(r.l), w);
-        return sig_words(r.l, w);
+        return finish_sig(r.l, allz, h);
     }
     __device__ __forceinline__ uint64_t at(uint32_t i, uint32_t j, int64_t e) const { return sig(fetch(i, j, e)); }
     __device__ __forceinline__ uint64_t operator()(int64_t e) const {
@@ -1197,154 +1173,6 @@ refine_insert_kernel(int64_t len, const SRC src,
         need_clear = l_count > LDS_SLOTS / 2;  // uniform (read after the barrier above)
         bypass = need_clear;
         __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Insert pass for FEW old classes (d_old <= CL_DMAX), hash-free on the hit path.  A refinement only ever splits
-// classes, and an old class splits into a handful of new ones: so instead of hashing (label, values) into a 64-bit
-// signature and probing a hash table, every workgroup keeps, per OLD class, a short list of the value tuples it has
-// met (CL_KC candidates of kWords 64-bit words, in LDS) and an entry is COMPARED with the candidates of its class --
-// a 16-byte LDS read and a compare, typically one or two.  The class's random draw (a per-class constant) sits in
-// the same table.  Only a NEW candidate (a few per workgroup and refinement) is hashed, by the source's own signature
-// function, and published to the global table exactly as the hash pass does -- slots, first indices, counters and
-// the slot list downstream are the same objects.  An entry whose class list is full (more than CL_KC new classes
-// inside one old class) or whose label exceeds CL_DMAX takes the hash route on its own.
-// PMC of the hash pass (round 3): 185 VALU wave-instructions per 64 entries, about half of them signature hashing
-// (nine 64-bit multiplies at quarter rate) -- VALU-busy for half the pass.
-// ---------------------------------------------------------------------------
-constexpr int CL_DMAX = 128;  // old classes with a candidate list (labels 0 .. CL_DMAX)
-constexpr int CL_KC = 4;      // candidates per old class
-
-template <class SRC, int INSERT_PER_THREAD>
-__global__ void __launch_bounds__(REFINE_THREADS)
-refine_insert_classlist_kernel(int64_t len, const SRC src, uint32_t* __restrict__ slot_out, unsigned long long* __restrict__ tab_sig,
-                               uint32_t* __restrict__ tab_min, uint32_t mask, uint32_t* counters) {
-    constexpr int INSERT_CHUNK = REFINE_THREADS * INSERT_PER_THREAD;
-    constexpr int NW = SRC::kWords;
-    constexpr int NCAND = (CL_DMAX + 1) * CL_KC;
-    constexpr uint32_t PENDING = 0xFFFFFFFEu;
-    __shared__ unsigned long long c_w[NW][NCAND];  // word-major: the lanes of a wave mostly read the same few candidates
-    __shared__ uint32_t c_state[NCAND];            // 0 empty, 1 being written, 2 valid
-    __shared__ uint32_t c_min[NCAND];              // smallest entry index of the candidate in the chunk that created it
-    __shared__ uint32_t c_gslot[NCAND];            // global slot (PENDING until published)
-    __shared__ double c_x[CL_DMAX + 1];            // the classes' draws
-    __shared__ uint32_t l_overflow, l_new;
-    for (int i = threadIdx.x; i < NCAND; i += REFINE_THREADS) c_state[i] = 0u;
-    for (int i = threadIdx.x; i <= CL_DMAX; i += REFINE_THREADS) c_x[i] = src.class_draw((uint32_t)i);
-    const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
-    const int nn = src.order();
-    const bool low = src.lower();
-    for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x) {
-        if (threadIdx.x == 0) {
-            l_overflow = __builtin_nontemporal_load(&counters[1]);
-            l_new = 0u;
-        }
-        __syncthreads();
-        if (l_overflow) return;  // uniform: the host repeats the pass with a larger table
-        const int64_t base = blk * INSERT_CHUNK;
-        // >= 0: candidate index; -1: zero signature; <= -2: resolved global slot (-2 - g), hash route
-        int mine[INSERT_PER_THREAD];
-        typename SRC::Raw raw[INSERT_PER_THREAD];
-        {
-            uint32_t wi = 0, wj = 0;
-            if (base + threadIdx.x < len) IjWalk::locate(nn, low, base + threadIdx.x, wi, wj);
-#pragma unroll
-            for (int q = 0; q < INSERT_PER_THREAD; ++q) {  // all loads of the chunk first
-                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-                if (e < len) raw[q] = src.fetch(wi, wj, e);
-                IjWalk::step(nn, low, wi, wj, REFINE_THREADS);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-            const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-            mine[q] = -1;
-            if (e >= len) continue;
-            const uint32_t l = raw[q].l;
-            const bool listed = l <= (uint32_t)CL_DMAX;
-            uint64_t w[NW];
-            src.words(raw[q], listed ? c_x[l] : src.class_draw(l), w);
-            bool allz = l == 0u;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) allz = allz && w[i] == 0ull;
-            if (allz) continue;  // the zero class: no slot
-            int found = -3;
-            if (listed) {
-                const int cb = (int)l * CL_KC;
-                int k = 0;
-                bool done = false;
-                while (!done) {
-                    // (each trip completes both sides of the branches below before the next read of the state: a lane
-                    // that lost the race for an empty candidate sees it valid on its next trip, also inside one wave)
-                    const uint32_t st = __hip_atomic_load(&c_state[cb + k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (st == 2u) {
-                        bool eq = true;
-#pragma unroll
-                        for (int i = 0; i < NW; ++i) eq = eq && c_w[i][cb + k] == w[i];
-                        if (eq) {
-                            found = cb + k;
-                            done = true;
-                        } else if (++k == CL_KC) {
-                            done = true;  // list full: hash route
-                        }
-                    } else if (st == 0u) {
-                        if (atomicCAS(&c_state[cb + k], 0u, 1u) == 0u) {
-#pragma unroll
-                            for (int i = 0; i < NW; ++i) c_w[i][cb + k] = w[i];
-                            c_min[cb + k] = 0xFFFFFFFFu;
-                            c_gslot[cb + k] = PENDING;
-                            __hip_atomic_store(&c_state[cb + k], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            l_new = 1u;
-                            found = cb + k;
-                            done = true;
-                        }
-                    }
-                }
-            }
-            if (found >= 0) {
-                // first index: only while the candidate is unpublished (the chunk that created it holds the workgroup's
-                // smallest index of the class: chunks come in increasing index order)
-                if (c_gslot[found] == PENDING && c_min[found] > (uint32_t)e) atomicMin(&c_min[found], (uint32_t)e);
-                mine[q] = found;
-            } else {
-                const uint64_t sg = src.sig_words(l, w);
-                const uint32_t g = global_find_or_insert(sg, tab_sig, mask, counters);
-                if (g != NO_SLOT) {
-                    if (tab_min[g] > (uint32_t)e) atomicMin(&tab_min[g], (uint32_t)e);
-                    mine[q] = -2 - (int)g;
-                }
-            }
-        }
-        __syncthreads();
-        if (l_new) {  // uniform after the barrier: publish the candidates this chunk created
-            for (int i = threadIdx.x; i < NCAND; i += REFINE_THREADS) {
-                if (c_state[i] == 2u && c_gslot[i] == PENDING) {
-                    uint64_t w[NW];
-#pragma unroll
-                    for (int k = 0; k < NW; ++k) w[k] = c_w[k][i];
-                    const uint64_t sg = src.sig_words((uint32_t)(i / CL_KC), w);
-                    const uint32_t g = global_find_or_insert(sg, tab_sig, mask, counters);
-                    if (g != NO_SLOT) {
-                        const uint32_t m0 = c_min[i];
-                        if (tab_min[g] > m0) atomicMin(&tab_min[g], m0);
-                    }
-                    c_gslot[i] = g;
-                }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-            const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
-            if (e < len) {
-                uint32_t out = NO_SLOT;
-                if (mine[q] >= 0) out = c_gslot[mine[q]];
-                else if (mine[q] <= -2) out = (uint32_t)(-2 - mine[q]);
-                slot_out[e] = out;
-            }
-        }
-        __syncthreads();  // l_new / l_overflow are rewritten at the top of the next chunk
     }
 }
 
@@ -1620,16 +1448,6 @@ static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SR
                                                                 (uint32_t)(cap - 1), ws.counters);
 }
 
-// class-list form of the insert pass (d_old <= CL_DMAX, matrix-walking sources with a words() interface)
-template <class SRC, int PER>
-static void launch_insert_classlist(hipStream_t s, int wgs_per_cu, int64_t len, const SRC& src, uint32_t* slot, const RefineWs& ws, size_t cap) {
-    const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
-    const int gcap = 256 * (wgs_per_cu > 0 ? wgs_per_cu : 4);
-    const int g = (int)(nchunk < gcap ? nchunk : gcap);
-    refine_insert_classlist_kernel<SRC, PER><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
-                                                                          (uint32_t)(cap - 1), ws.counters);
-}
-
 template <typename CT>
 static bool launch_insert_chan(hipStream_t s, int gcap, int64_t len, const SigSource& q, uint32_t* slot, const RefineWs& ws,
                                size_t cap) {
@@ -1848,14 +1666,9 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
             break;
         case SIG_JOINT_I32: {
             const int32_t* Cj = (const int32_t*)q.C;
-            // few old classes (q.d_old known and small): the hash-free class-list pass; else the hash pass
-            const bool cl = q.d_old > 0 && q.d_old <= CL_DMAX && !ws.no_classlist;
-#define SDPSR_JOINT_CASE(RR, TT)                                                                                                       \
-    do {                                                                                                                               \
-        const SrcJoint<RR, TT> sj{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, q.lab_packed};                          \
-        if (cl) launch_insert_classlist<SrcJoint<RR, TT>, 8>(s, ws.insert_wgs_per_cu, len, sj, slot, ws, cap);                         \
-        else launch_insert<SrcJoint<RR, TT>, 8>(s, gcap, len, sj, slot, ws, cap);                                                      \
-    } while (0)
+#define SDPSR_JOINT_CASE(RR, TT)                                                                                                   \
+    launch_insert<SrcJoint<RR, TT>, 8>(s, gcap, len, SrcJoint<RR, TT>{q.U, q.L, q.coef, q.key, q.atol, q.scale, Cj, q.ld, (int)q.n, \
+                                                                      q.lab_packed}, slot, ws, cap)
             const int rr = q.r < 0 ? 0 : (q.r > 4 ? 4 : q.r);
             if (q.T == 2) {
                 switch (rr) {

@@ -673,7 +673,7 @@ sytrd_syr2k_mfma_kernel(SytrdArgs a, int j1, int T0) {
 //     and the full vectors v_{j-1}, y_{j-1} = A v_{j-1} and the per-workgroup partial dots y'v left by launch j-1
 //     (w_{j-1} = tau y - tau^2/2 (y'v) v needs the chip-wide scalar y'v: the sum of G partials, every workgroup adds
 //     them in the same order).  Same loads, same instruction sequence: bitwise the same v_j in every workgroup.
-// So the chain per column is one kernel boundary + (vector loads -> two block reductions -> row pass from registers,
+// So the chain per column is one kernel boundary + (vector loads -> wave reduction, block reduction -> row pass from registers,
 // whose loads were issued at the top of the kernel).  The two products of the update are rounded separately and
 // added (a - (v_i w_c + w_i v_c)): the stored matrix stays bitwise symmetric.
 // Memory: line a of the allocation (A + a ld) is row a = column a.  Reflector j is stored LAPACK-style on line j,
@@ -696,10 +696,25 @@ struct SytrdRowArgs {
     double* tau;
 };
 
+// Wave-wide sum on the DPP path (quad permutes, row rotations, four read-lanes) instead of six ds_bpermute round
+// trips of a 64-bit value: the kernel below is one dependent chain with three of these in it.  All 64 lanes must be
+// active.  The result is uniform.
+template <int CTRL>
+__device__ __forceinline__ double sr_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sr_readlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
 __device__ __forceinline__ double sr_wave_sum(double x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    x += sr_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += sr_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += sr_dpp<0x124>(x);  // row_ror:4
+    x += sr_dpp<0x128>(x);  // row_ror:8: every lane holds the sum of its row of 16
+    return (sr_readlane(x, 0) + sr_readlane(x, 16)) + (sr_readlane(x, 32) + sr_readlane(x, 48));
 }
 
 // NCH: 128-column chunks of a row that can be active (ceil(ld / 128) at most)
@@ -731,6 +746,8 @@ sytrd_row_kernel(SytrdRowArgs a, int j) {
             for (int k = 0; k < NCH; ++k) {
                 xr[r][k] = double2{0.0, 0.0};
                 if (i < n && c0 + 128 * k < n) xr[r][k] = *reinterpret_cast<const double2*>(line + 128 * k);
+                if (c0 + 128 * k + 2 * lane >= n) xr[r][k].x = 0.0;  // padding columns may hold anything
+                if (c0 + 128 * k + 2 * lane + 1 >= n) xr[r][k].y = 0.0;
             }
         }
     }
@@ -749,13 +766,15 @@ sytrd_row_kernel(SytrdRowArgs a, int j) {
     const double tau_p = j > 0 ? a.tau[j - 1] : 0.0;
     const double yp_j = j > 0 ? yprev[j] : 0.0;  // entry j of the previous product (v_{j-1}(j) = 1)
     const double ajj = linej[j];
-    double pd = (j > 0 && tid < G) ? a.pdot[pp * 256 + tid] : 0.0;
+    double pd = 0.0;  // every wave adds up all G partials itself: no barrier in front of w_{j-1}
+    if (j > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (64 * q + lane < G) pd += a.pdot[pp * 256 + 64 * q + lane];
+    }
 
     // ---- s = y'v of the previous column, then w_{j-1} (LDS) and the updated column x
-    pd = sr_wave_sum(pd);
-    if (lane == 0) s_red[0][wv] = pd;
-    __syncthreads();
-    const double sdot = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    const double sdot = sr_wave_sum(pd);
     const double hts = 0.5 * tau_p * tau_p * sdot;  // w = tau y - (tau^2 s / 2) v
     const double wp_j = tau_p * yp_j - hts;
     double xv[NT];
@@ -843,7 +862,7 @@ sytrd_row_kernel(SytrdRowArgs a, int j) {
         if (lane == 0) a.ybuf[(int64_t)par * ld + i] = y;
         pdw = fma(y, vji, pdw);
     }
-    if (lane == 0) s_red[0][wv] = pdw;  // (s_red[0] was last read before the two barriers above)
+    if (lane == 0) s_red[0][wv] = pdw;
     __syncthreads();
     if (tid == 0) a.pdot[par * 256 + b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
 }
@@ -972,7 +991,10 @@ static void emit_form(SytrdEmitter& em, unsigned grid, const SytrdArgs& a, int j
     em.kernel(reinterpret_cast<const void*>(&sytrd_form_kernel), grid, SY_THREADS, 0, a, j, cf, do_finish, do_form, n_vav, S0, SEG, G);
 }
 
-static bool emit_sytrd(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
+// stop > 0 (a multiple of 128): only columns 0 .. stop-1; the trailing matrix A(stop:, stop:) is left updated (lower
+// triangle), column `stop` not formed -- the row form takes over from there
+static bool emit_sytrd(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws,
+                       int stop = -1) {
     const int n = (int)n64;
     SytrdArgs a = sytrd_args(n64, A, ld, d, e, tau, ws);
     em.zero(ws, sytrd_workspace_doubles(n, ld) * sizeof(double));
@@ -1004,6 +1026,7 @@ static bool emit_sytrd(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, dou
                 em.kernel(reinterpret_cast<const void*>(&sytrd_syr2k_mfma_kernel), (unsigned)(nt * (nt + 1) / 2), SY_THREADS,
                           128 * 1024, a, jn, T0);
             }
+            if (jn == stop) return em.ok;
             if (n - jn > 0) emit_form(em, nb_form, a, jn, 0, 0, 1, 0, 0, 1, 0);
             cf = 0;
         }
@@ -1043,15 +1066,23 @@ static bool emit_sytrd_rows(SytrdEmitter& em, int64_t n64, double* A, int64_t ld
     em.copy8(d + (n - 1), A + (int64_t)(n - 1) * ld + (n - 1));  // tau(n-2) = 0: the last diagonal entry is final
     return em.ok;
 }
+// the default: row form up to SR_NMAX; beyond, the panel form until the trailing matrix has come down to SR_NMAX
+// (there a column of the panel form is two launch latencies, 13-14 us, against one latency + 16 m^2 bytes of the row form)
 static bool sytrd_use_rows(const sdpsr_ctx* c, int64_t n, int64_t ld) {
-    return n <= SR_NMAX && ld >= n && !(c && (c->opts.flags & SDPSR_FLAG_SYTRD_PANELS));
+    return ld >= n && !(c && (c->opts.flags & SDPSR_FLAG_SYTRD_PANELS));
+}
+static bool emit_sytrd_default(SytrdEmitter& em, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
+    if (n <= SR_NMAX) return emit_sytrd_rows(em, n, A, ld, d, e, tau, ws);
+    const int64_t j0 = (n - SR_NMAX + 127) / 128 * 128;
+    if (!emit_sytrd(em, n, A, ld, d, e, tau, ws, (int)j0)) return false;
+    return emit_sytrd_rows(em, n - j0, A + j0 * ld + j0, ld, d + j0, e + j0, tau + j0, ws);
 }
 
 static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
                                 double* ws, bool rows) {
     SytrdEmitter em;
     em.s = s;
-    if (rows) emit_sytrd_rows(em, n64, A, ld, d, e, tau, ws);
+    if (rows) emit_sytrd_default(em, n64, A, ld, d, e, tau, ws);
     else emit_sytrd(em, n64, A, ld, d, e, tau, ws);
 }
 
@@ -1127,7 +1158,7 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
         if (ok) {
             SytrdEmitter em;
             em.graph = graph;
-            ok = rows ? emit_sytrd_rows(em, n64, A, ld, d, e, tau, ws) : emit_sytrd(em, n64, A, ld, d, e, tau, ws);
+            ok = rows ? emit_sytrd_default(em, n64, A, ld, d, e, tau, ws) : emit_sytrd(em, n64, A, ld, d, e, tau, ws);
         }
         if (ok) ok = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0) == hipSuccess;
         if (graph) hipGraphDestroy(graph);

@@ -186,7 +186,6 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                 qj.packed = 1;
                 qj.L = jl2 ? Lp : L;
                 qj.lab_packed = jl2 ? 1 : 0;
-                qj.d_old = current;
                 // Rounds that are expected NOT to refine -- a confirm round, and the first iteration (an
                 // input that is closed already) -- first ask the cheap question "does any entry differ
                 // from the representative of its class?" (one streaming compare pass, kernels_partition.hip

@@ -87,7 +87,6 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
             return SDPSR_OUT_OF_MEMORY;
         ws.log2cap = log2cap;
         ws.insert_wgs_per_cu = c->opts.insert_wgs_per_cu;
-        ws.no_classlist = (c->opts.flags & SDPSR_FLAG_REFINE_NO_CLASSLIST) ? 1 : 0;
         ws.nblk = (int)nblk;
         ws.expect_small = (!mispredicted && c->table_log2_hint <= 12) ? 1 : 0;  // hint 12 <=> last dim <= 512
         const bool sym_fused = sym_n > 0 && sym_n * sym_n == len;  // verdict in counters[3], same read-back

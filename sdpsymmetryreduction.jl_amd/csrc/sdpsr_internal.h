@@ -147,7 +147,6 @@ struct RefineWs {
     uint32_t* tab_lab;   // cap
     uint32_t* blk_cnt;   // nblk + 1
     int insert_wgs_per_cu = 0;  // sdpsr_opts.insert_wgs_per_cu (0 = default)
-    int no_classlist = 0;       // SDPSR_FLAG_REFINE_NO_CLASSLIST: always the hash form of the insert pass
     uint32_t* host_counters = nullptr;  // pinned host memory: counters[0..2] are also stored there by the label pass (plain label pass only)
     int expect_small = 0;  // host prediction: <= refine_small_k() classes (see launch_refine)
     uint32_t* first_idx = nullptr;  // optional: first-occurrence index of class l at [l - 1], l <= refine_first_cap()
@@ -174,7 +173,6 @@ struct SigSource {
     int64_t n = 0, ld = 0;                                        // SIG_CHAN_* (launch_sig_i32 / launch_sig_f32)
     int T = 0;
     const void* C = nullptr;
-    int64_t d_old = 0;                                            // number of classes of L when the caller knows it (0 = unknown): few classes take the class-list insert
     int packed = 0;                                               // lower triangle only, densely packed (symmetric labels; SIG_PROJ: and symmetric basis, needs n)
     int lab_packed = 0;                                           // (with packed) L is the packed lower triangle itself: label of packed entry e = L[e]
     const uint32_t* zero_flag = nullptr;                          // device constant 0 when packed (the kernels' "lower" flag)
@@ -285,6 +283,9 @@ void launch_small_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const d
 size_t small_cluster_pack_bytes(int64_t n);
 void launch_small_cluster_qtaq_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* A, const double* Q,
                                            const double* evals, double atol, const int* einfo, char* pack, double* Tout);
+void launch_coupling_symmetrize_minmax(hipStream_t s, int neig, unsigned long long* norms, const int32_t* dims, unsigned long long* stat);
+void launch_coupling_count(hipStream_t s, int neig, const unsigned long long* norms, const double* edges17, unsigned long long* stat);
+void launch_coupling_bits(hipStream_t s, int neig, const unsigned long long* norms, double thr, unsigned long long* bits);
 void launch_block_norms(hipStream_t s, int64_t n, int64_t ld, const double* M,
                         const int32_t* space_of, int neig, unsigned long long* norms);
 // y = A * x for symmetric A (n x n, ld) and nv vectors (columns of X, ldx): Y[:,v]

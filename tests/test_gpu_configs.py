@@ -293,6 +293,35 @@ def test_config2_qap_grid30_block_diagonalize_full_size(pkg, problems):
     assert max(sizes) >= 36 and sum(sizes) <= 900
 
 
+def test_coupling_classes_on_device_equal_host_classes(pkg, problems):
+    """From 256 eigenspaces on, the isomorphism classes (Otsu threshold + union-find, src/eigen_decomposition.jl:83-139,
+    205-217) are formed from extrema, histogram counts and pair bits computed on the device; SDPSR_FLAG_COUPLING_ON_HOST
+    reads the coupling matrix back as before.  Same seed, same draws: the outcome (eigenspaces, classes, or the
+    reference's NumericalInconsistency) must be the same run by run -- on the 900 one-dimensional eigenspaces in 16
+    classes of configs[2] and on the single class of a partition without symmetry."""
+    flow, dist = problems.grid_qap_instance(5, 6, seed=4)
+    Cv, A, b = problems.qap_problem(flow, dist)
+    with pkg.Context(seed=1) as ctx:
+        P2 = pkg.admissible_subspace(Cv, A, b, ctx=ctx)
+    Cv, A, b = problems.theta_prime_problem(problems.gnp_adjacency(320, 0.5, seed=3))
+    with pkg.Context(seed=1) as ctx:
+        P1 = pkg.admissible_subspace(Cv, A, b, ctx=ctx)
+    assert P1.nparts == 320 * 321 // 2
+    for P, atol in ((P2, 1e-8), (P1, 1.5e-8)):
+        outcomes = []
+        for flags in (0, pkg._lib.FLAG_COUPLING_ON_HOST):
+            runs = []
+            with pkg.Context(seed=5, flags=flags) as ctx:
+                for _ in range(6):
+                    try:
+                        runs.append(pkg.eigen_decomposition(P, atol=atol, ctx=ctx))
+                    except pkg.NumericalInconsistency:
+                        runs.append("inconsistent")
+            outcomes.append(runs)
+        assert outcomes[0] == outcomes[1], outcomes
+        assert any(r != "inconsistent" and r[0] >= 256 for r in outcomes[0]), outcomes
+
+
 def test_config4_n8192_block_diagonalize_full_size(pkg, problems):
     """configs[4] through blockDiagonalize at N = 8192: all blocks of size 1 (commutative scheme), blks against host
     products on sampled classes, spectrum invariant with the full 8192 x 8192 spectrum from torch's solver."""

@@ -166,6 +166,26 @@ def test_syev_matches_lapack(pkg, gpu_ctx):
         assert np.abs(A @ V - V * w).max() < 1e-9
 
 
+def test_syev_row_form_panel_form_and_hybrid(pkg):
+    """The tridiagonalisation has two forms: one launch per column with row-owning workgroups (n <= 2048, default) and
+    Householder panels with trailing updates on the matrix cores (SDPSR_FLAG_SYTRD_PANELS, and the leading columns of
+    larger orders, whose last 2048 columns are handed to the row form).  All three against LAPACK."""
+    lib = pkg.load_library()
+    rng = np.random.default_rng(7)
+    for n, flags in ((777, 0), (777, pkg._lib.FLAG_SYTRD_PANELS), (1536, 0), (2304, 0)):
+        A = rng.standard_normal((n, n))
+        A = np.asfortranarray((A + A.T) / 2)
+        A[np.triu_indices(n, 1)] = 1e300  # only the lower triangle is referenced (the row form mirrors it first)
+        Asym = np.tril(A) + np.tril(A, -1).T
+        w = np.zeros(n)
+        V = np.zeros((n, n), order="F")
+        with pkg.Context(seed=1, flags=flags) as ctx:
+            ctx.check(lib.sdpsr_syev_f64(ctx._h, n, C.c_void_p(A.ctypes.data), C.c_void_p(w.ctypes.data), C.c_void_p(V.ctypes.data), 0))
+        assert np.allclose(w, np.linalg.eigvalsh(Asym), rtol=1e-10, atol=1e-10), (n, flags)
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-10, (n, flags)
+        assert np.abs(Asym @ V - V * w).max() < 1e-9, (n, flags)
+
+
 def test_syev_degenerate_spectrum_residual(pkg, problems, gpu_ctx):
     """Generic elements of symmetric algebras have a handful of eigenvalues with huge
     multiplicities: the tridiagonalisation deflates after ~dim columns and then works on

@@ -5,11 +5,15 @@ from __graft_entry__ import load_package
 pkg = load_package(); pr = pkg.problems
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "golden_partitions.npz"))
 def timeit(f, reps=3):
-    best = 1e9
+    best = 1e9; r = None
     for _ in range(reps):
-        t = time.perf_counter(); r = f(); best = min(best, time.perf_counter() - t)
+        for attempt in range(4):  # NumericalInconsistency / DimensionMismatch: "simply try again" (the reference's advice)
+            try:
+                t = time.perf_counter(); r = f(); best = min(best, time.perf_counter() - t); break
+            except (pkg.NumericalInconsistency, pkg.DimensionMismatch) as e:
+                print("         (retry after %s)" % type(e).__name__)
     return best * 1e3, r
-with pkg.Context(seed=1) as ctx:
+with pkg.Context(seed=1, flags=int(os.environ.get("SDPSR_TOOL_FLAGS", "0"))) as ctx:
     # config 1: G(1024, 0.5)
     Cv, A, b = pr.theta_prime_problem(pr.gnp_adjacency(1024, 0.5, seed=11))
     setup = pkg.admissible_setup(Cv, A, b)
@@ -18,7 +22,7 @@ with pkg.Context(seed=1) as ctx:
     ms, r = timeit(lambda: pkg.eigen_decomposition(P, atol=1.5e-8, ctx=ctx), reps=2)
     print("         eigen_decomposition (dense, 1024 eigenspaces): %.1f ms -> %s" % (ms, r))
     os.environ["SDPSR_DEBUG"] = "1"  # phase marks of one more run on stderr
-    pkg.eigen_decomposition(P, atol=1.5e-8, ctx=ctx)
+    timeit(lambda: pkg.eigen_decomposition(P, atol=1.5e-8, ctx=ctx), reps=1)
     del os.environ["SDPSR_DEBUG"]
     # config 2: QAP grid 30
     flow, dist = pr.grid_qap_instance(5, 6, seed=4)
