@@ -989,6 +989,11 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned 
     // repeats the pass with a larger table, nobody should keep walking a full one)
     uint32_t idx = (uint32_t)sg & mask;
     for (int probe = 0; probe < MAX_PROBES; ++probe) {
+        // a probe sequence that gets long in a table that has overflowed meanwhile (the flag goes up at 75 %) stops:
+        // the host repeats the pass with a larger table anyway.  (A refinement that jumps from a handful of classes to
+        // ~len/2 -- partitions without symmetry -- used to walk up to MAX_PROBES slots of the full table for every
+        // remaining entry: 1.0 and 1.5 ms per failed attempt at len = 524 800, configs[1].)
+        if ((probe & 7) == 7 && __builtin_nontemporal_load(&counters[1])) return NO_SLOT;
         unsigned long long cur = tab[idx];  // slots are write-once: a stale read can only be 0
         if (cur == sg) return idx;
         if (cur == 0ull) {
@@ -1036,7 +1041,12 @@ refine_insert_kernel(int64_t len, const SRC src,
     // showed two thirds of the wave cycles in s_waitcnt on the chunk's own loads.  The prefetched registers took the
     // joint source from 71 to 172 VGPRs (2 waves per SIMD instead of 7) and the pass got SLOWER at every grid size
     // tried, 1-6 workgroups per CU: refine phase of theta_c32xk128 0.91-1.17 ms against 0.79.  Latency is hidden by
-    // resident workgroups here, not by software pipelining; removed.)
+    // resident workgroups here, not by software pipelining; removed.
+    // Two more forms measured and removed in round 3 (both bit-exact on the golden partitions): per-old-class candidate
+    // lists in LDS compared word by word, so that only NEW classes are hashed (joint pass 94 us against 80, with 8 or 4
+    // candidates per class: the extra LDS reads cost more than the nine 64-bit multiplies they replace); and the waves
+    // of a workgroup running free inside a chunk -- creator lanes resolve their own slots, other waves spin on the LDS
+    // word, one barrier per chunk instead of three -- 80.3 us against 79.6: the barriers are not what the waves wait for.)
     for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x) {
         if (need_clear) {
             for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {

@@ -88,7 +88,8 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         ws.log2cap = log2cap;
         ws.insert_wgs_per_cu = c->opts.insert_wgs_per_cu;
         ws.nblk = (int)nblk;
-        ws.expect_small = (!mispredicted && c->table_log2_hint <= 12) ? 1 : 0;  // hint 12 <=> last dim <= 512
+        // hint 12 <=> last dim <= 512; a table grown after an overflow in this call holds more than 0.75 * 2^12 classes
+        ws.expect_small = (!mispredicted && c->table_log2_hint <= 12 && log2cap <= 12) ? 1 : 0;
         const bool sym_fused = sym_n > 0 && sym_n * sym_n == len;  // verdict in counters[3], same read-back
         uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
         if (!h) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
