@@ -209,6 +209,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
     partition_set_device_attributes();
     sytrd_set_device_attributes();
     small_syev_set_device_attributes();
+    stedc_set_device_attributes();
     batched_set_device_attributes();
     backtransform_set_device_attributes();
     complex_set_device_attributes();

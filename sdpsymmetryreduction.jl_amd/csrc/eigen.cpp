@@ -23,6 +23,12 @@ void launch_bt_extract_panel(hipStream_t s, int64_t n, int64_t ld, const double*
 void launch_bt_larft(hipStream_t s, const double* G, const double* tau, int64_t nblk, int64_t n, double* T);
 void launch_gemm_tn_f64_sub(hipStream_t s, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
                             int64_t ldb, double* C, int64_t ldc);
+// kernels_stedc.hip: divide and conquer for the tridiagonal problem
+size_t stedc_workspace_bytes(int64_t ld);
+size_t stedc_descriptors(int64_t ld, std::vector<int>& out);
+void* stedc_descriptor_slot(void* ws, int64_t ld);
+bool launch_stedc(hipStream_t s, int64_t n, int64_t ld, const double* d, const double* e, double* w, double* Z, double* W1, double* W2,
+                  void* ws);
 
 // C (m x n, dense: ldc == m) = A' B with the K range split over workgroups when the output alone
 // would leave most CUs idle; partial tiles are summed in fixed order.
@@ -146,7 +152,26 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             if (hipMemsetAsync(Z, 0, (size_t)ldz * ldz * sizeof(double), c->stream) != hipSuccess)
                 return ctx_fail(c, SDPSR_HIP_ERROR, "memset of the eigenvector buffer failed");
         }
-        if (c->opts.eig_driver == 3)
+        // the tridiagonal problem: own divide and conquer (kernels_stedc.hip); eig_driver 5 keeps rocSOLVER's stedc
+        const bool own_dc = own && c->opts.eig_driver != 5 && ldz <= 8192;
+        if (own_dc) {
+            void* dws = ctx_buf(c, "eig_dc_ws", stedc_workspace_bytes(ldz));
+            double* W1 = (double*)ctx_buf(c, "eig_dc_w1", (size_t)ldz * ldz * sizeof(double));
+            double* W2 = (double*)ctx_buf(c, "eig_dc_w2", (size_t)ldz * ldz * sizeof(double));
+            double* wtmp = (double*)ctx_buf(c, "eig_dc_w", (size_t)n * sizeof(double));
+            if (!dws || !W1 || !W2 || !wtmp) return SDPSR_OUT_OF_MEMORY;
+            std::vector<int> desc;
+            const size_t db = stedc_descriptors(ldz, desc);
+            int hst = h2d_sync(c, stedc_descriptor_slot(dws, ldz), desc.data(), db);
+            if (hst) return hst;
+            // (d = w and the output eigenvalues share the caller's array: the solver reads d, e in its first launch only)
+            if (!launch_stedc(c->stream, n, ldz, w, E, wtmp, Z, W1, W2, dws))
+                return ctx_fail(c, SDPSR_HIP_ERROR, "tridiagonal divide and conquer: launch failed");
+            if (hipMemcpyAsync(w, wtmp, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                hipMemsetAsync(info, 0, 2 * sizeof(rocblas_int), c->stream) != hipSuccess)
+                return ctx_fail(c, SDPSR_HIP_ERROR, "tridiagonal divide and conquer: copy failed");
+            rs = rocblas_status_success;
+        } else if (c->opts.eig_driver == 3)
             rs = rocsolver_dsteqr(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)ldz, info);
         else
             rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)ldz, info);

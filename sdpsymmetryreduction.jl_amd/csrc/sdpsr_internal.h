@@ -216,6 +216,7 @@ void module_set_device_attributes();
 void partition_set_device_attributes();
 void sytrd_set_device_attributes();
 void small_syev_set_device_attributes();
+void stedc_set_device_attributes();
 void batched_set_device_attributes();
 void backtransform_set_device_attributes();
 void complex_set_device_attributes();
