@@ -242,6 +242,8 @@ void sdpsr_destroy(sdpsr_ctx* c) {
     if (c->pinned_small) hipHostFree(c->pinned_small);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_bt_fork) hipEventDestroy(c->ev_bt_fork);
+    if (c->ev_bt_join) hipEventDestroy(c->ev_bt_join);
     if (c->ev_wait) hipEventDestroy(c->ev_wait);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);

@@ -59,34 +59,48 @@ static int bt_gemm_splitk(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const d
 // Z <- Q Z with Q = H_0 ... H_{n-2} from the tridiagonalisation (reflectors below the subdiagonal of
 // A, tau): compact-WY blocks of 128 reflectors, last block first, every product on the fp64
 // matrix cores (kernels_backtransform.hip has the plan).  Z: ld x ld, zero padded.
-static int backtransform_device(sdpsr_ctx* c, int64_t n, const double* A, int64_t ld, const double* tau, double* Z) {
+// Two halves: what depends on the reflectors only -- the panels V_b, their Gram matrices, every T_b, X_b = T_b' V_b' --
+// is launched by backtransform_prepare and runs on the side stream BESIDE the tridiagonal solver (which touches neither
+// A nor these buffers); backtransform_apply then needs two products per block, W = V_b' Z and Z -= X_b' W.
+static int backtransform_prepare(sdpsr_ctx* c, int64_t n, const double* A, int64_t ld, const double* tau) {
     hipStream_t s = c->stream;
-    double* Vp = (double*)ctx_buf(c, "bt_vp", (size_t)ld * 128 * 8);
-    double* VpT = (double*)ctx_buf(c, "bt_vpt", (size_t)ld * 128 * 8);
-    double* X = (double*)ctx_buf(c, "bt_x", (size_t)ld * 128 * 8);
-    double* W = (double*)ctx_buf(c, "bt_w", (size_t)ld * 128 * 8);
     const int64_t nblk = (n - 1 + 127) / 128;
+    const size_t per = (size_t)ld * 128 * 8;
+    double* VpAll = (double*)ctx_buf(c, "bt_vp_all", per * std::max<int64_t>(nblk, 1));
+    double* VpTAll = (double*)ctx_buf(c, "bt_vpt_all", per * std::max<int64_t>(nblk, 1));
+    double* XAll = (double*)ctx_buf(c, "bt_x_all", per * std::max<int64_t>(nblk, 1));
     double* G = (double*)ctx_buf(c, "bt_g", (size_t)std::max<int64_t>(nblk, 1) * 128 * 128 * 8);
     double* T = (double*)ctx_buf(c, "bt_t", (size_t)std::max<int64_t>(nblk, 1) * 128 * 128 * 8);
-    if (!Vp || !VpT || !X || !W || !G || !T) return SDPSR_OUT_OF_MEMORY;
-    // pass 1: the Gram matrices of all panels, then every T factor in ONE launch (one workgroup per block)
+    if (!VpAll || !VpTAll || !XAll || !G || !T) return SDPSR_OUT_OF_MEMORY;
+    // the Gram matrices of all panels, then every T factor in ONE launch (one workgroup per block)
     for (int64_t b = 0; b < nblk; ++b) {
         const int64_t j0 = 128 * b, r0 = j0, m = ld - r0;
-        launch_bt_extract_panel(s, n, ld, A, j0, r0, Vp, VpT);
+        double* Vp = VpAll + b * ld * 128;
+        launch_bt_extract_panel(s, n, ld, A, j0, r0, Vp, VpTAll + b * ld * 128);
         int st = bt_gemm_splitk(c, 128, 128, m, Vp + r0, ld, Vp + r0, ld, G + b * 128 * 128);  // G_b = V'V
         if (st) return st;
     }
     launch_bt_larft(s, G, tau, nblk, n, T);
-    // pass 2: the blocks applied last first
-    for (int64_t b = nblk - 1; b >= 0; --b) {
-        const int64_t j0 = 128 * b, r0 = j0, m = ld - r0;
-        const double* Tb = T + b * 128 * 128;
-        launch_bt_extract_panel(s, n, ld, A, j0, r0, Vp, VpT);
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t r0 = 128 * b, m = ld - r0;
         // X[:, r] = (V T)[r, :]':  X = T' V' as 128 x m (rows r0..)
-        launch_gemm_tn_f64(s, 128, m, 128, Tb, 128, VpT + r0 * 128, 128, X + r0 * 128, 128, 1, 0, 0, 0);
-        int st = bt_gemm_splitk(c, 128, ld, m, Vp + r0, ld, Z + r0, ld, W);  // W = V' Z
+        launch_gemm_tn_f64(s, 128, m, 128, T + b * 128 * 128, 128, VpTAll + b * ld * 128 + r0 * 128, 128, XAll + b * ld * 128 + r0 * 128, 128, 1, 0, 0, 0);
+    }
+    if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation launch failed");
+    return SDPSR_OK;
+}
+static int backtransform_apply(sdpsr_ctx* c, int64_t n, int64_t ld, double* Z) {
+    hipStream_t s = c->stream;
+    const int64_t nblk = (n - 1 + 127) / 128;
+    double* VpAll = (double*)ctx_buf(c, "bt_vp_all", (size_t)ld * 128 * 8 * std::max<int64_t>(nblk, 1));
+    double* XAll = (double*)ctx_buf(c, "bt_x_all", (size_t)ld * 128 * 8 * std::max<int64_t>(nblk, 1));
+    double* W = (double*)ctx_buf(c, "bt_w", (size_t)ld * 128 * 8);
+    if (!VpAll || !XAll || !W) return SDPSR_OUT_OF_MEMORY;
+    for (int64_t b = nblk - 1; b >= 0; --b) {  // the blocks applied last first
+        const int64_t r0 = 128 * b, m = ld - r0;
+        int st = bt_gemm_splitk(c, 128, ld, m, VpAll + b * ld * 128 + r0, ld, Z + r0, ld, W);  // W = V' Z
         if (st) return st;
-        launch_gemm_tn_f64_sub(s, m, ld, 128, X + r0 * 128, 128, W, 128, Z + r0, ld);  // Z -= (V T) W
+        launch_gemm_tn_f64_sub(s, m, ld, 128, XAll + b * ld * 128 + r0 * 128, 128, W, 128, Z + r0, ld);  // Z -= (V T) W
     }
     if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation launch failed");
     return SDPSR_OK;
@@ -138,6 +152,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
         const int64_t ldz = own ? lda : n;
         double* Z = (double*)ctx_buf(c, "eig_Z", (size_t)ldz * ldz * sizeof(double));
         if (!Z) return SDPSR_OUT_OF_MEMORY;
+        bool bt_forked = false;
         if (!own) {
             rs = rocsolver_dsytrd(h, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)lda, w, E, tau);
             if (rs != rocblas_status_success)
@@ -149,6 +164,28 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             launch_sytrd(c, n, A, lda, w, E, tau, ws);
             if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: tridiagonalisation done"); }
             if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "sytrd launch failed");
+            // first half of the back-transformation on the side stream, beside the tridiagonal solver
+            bool side_ok = c->side_stream || hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess;
+            if (side_ok && !c->ev_bt_fork)
+                side_ok = hipEventCreateWithFlags(&c->ev_bt_fork, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&c->ev_bt_join, hipEventDisableTiming) == hipSuccess;
+            hipStream_t main_stream = c->stream;
+            if (side_ok && c->side_stream != main_stream && hipEventRecord(c->ev_bt_fork, main_stream) == hipSuccess &&
+                hipStreamWaitEvent(c->side_stream, c->ev_bt_fork, 0) == hipSuccess) {
+                c->stream = c->side_stream;  // every helper launches on c->stream
+                c->main_shadow = main_stream;
+                const int pst = backtransform_prepare(c, n, A, lda, tau);
+                const bool rec = hipEventRecord(c->ev_bt_join, c->side_stream) == hipSuccess;
+                c->stream = main_stream;
+                c->main_shadow = nullptr;
+                if (pst || !rec) {
+                    hipStreamSynchronize(c->side_stream);
+                    return pst ? pst : ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation: event record failed");
+                }
+                bt_forked = true;
+            } else {
+                (void)hipGetLastError();
+            }
             if (hipMemsetAsync(Z, 0, (size_t)ldz * ldz * sizeof(double), c->stream) != hipSuccess)
                 return ctx_fail(c, SDPSR_HIP_ERROR, "memset of the eigenvector buffer failed");
         }
@@ -179,7 +216,13 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver tridiagonal solver status " + std::to_string(rs));
         if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: tridiagonalisation + tridiagonal solver done"); }
         if (own) {
-            const int bst = backtransform_device(c, n, A, lda, tau, Z);
+            if (bt_forked) {
+                if (hipStreamWaitEvent(c->stream, c->ev_bt_join, 0) != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation: join failed");
+            } else {
+                const int pst = backtransform_prepare(c, n, A, lda, tau);
+                if (pst) return pst;
+            }
+            const int bst = backtransform_apply(c, n, lda, Z);
             if (bst) return bst;
         } else {
             rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,

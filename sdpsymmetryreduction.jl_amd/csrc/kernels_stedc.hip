@@ -373,8 +373,41 @@ dc_setup_kernel(DcArgs g, DcScratch w) {
 }
 
 // ---------------------------------------------------------------------------
-// merge, step 2: one wave per secular root
+// merge, step 2: one wave per secular root.  TPL > 0: the root's terms (w_i^2, d_i - d_K) sit in TPL registers per
+// lane for the 63 evaluations (k <= 64 TPL); TPL = 0: read from memory every time (k beyond 1024).
 // ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dc_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dc_readlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// all 64 lanes active; uniform result (quad permutes, row rotations, four read-lanes)
+__device__ __forceinline__ double dc_wave_sum_dpp(double x) {
+    x += dc_dpp<0xB1>(x);
+    x += dc_dpp<0x4E>(x);
+    x += dc_dpp<0x124>(x);
+    x += dc_dpp<0x128>(x);
+    return (dc_readlane(x, 0) + dc_readlane(x, 16)) + (dc_readlane(x, 32) + dc_readlane(x, 48));
+}
+// 1 / x from the hardware seed and two Newton steps (the secular function is evaluated ~64 k times per root; the
+// IEEE division sequence is five times the instructions).  Out of the seed's range: the division.
+__device__ __forceinline__ double dc_recip(double x) {
+    const double ax = fabs(x);
+    if (ax > 1e-290 && ax < 1e290) {
+        double r = __builtin_amdgcn_rcp(x);
+        r = fma(fma(-x, r, 1.0), r, r);
+        r = fma(fma(-x, r, 1.0), r, r);
+        return r;
+    }
+    return 1.0 / x;
+}
+
+template <int TPL>
 __global__ void __launch_bounds__(DC_THREADS)
 dc_secular_kernel(DcArgs g) {
     const DcMerge m = g.desc[blockIdx.y];
@@ -386,21 +419,37 @@ dc_secular_kernel(DcArgs g) {
     const double* __restrict__ dl = g.dl + a;
     const double* __restrict__ wz = g.wz + a;
     const double rho = g.rho[a];
-    // 1 + rho sum_i w_i^2 / ((d_i - d_K) - mu)
-    auto gfun = [&](int K, double mu) -> double {
-        const double dK = dl[K];
-        double s = 0.0;
-        for (int i = lane; i < k; i += 64) {
-            const double w = wz[i];
-            s += (w * w) / ((dl[i] - dK) - mu);
+    constexpr int NR = TPL > 0 ? TPL : 1;
+    double w2[NR], dd[NR];  // this lane's terms: w_i^2 (0 beyond k) and d_i - d_K
+    if (TPL > 0) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int i = lane + 64 * q;
+            const double w = i < k ? wz[i] : 0.0;
+            w2[q] = w * w;
+            dd[q] = i < k ? dl[i] : 1e300;  // (terms beyond k: 0 over a denominator that never vanishes)
         }
-        return 1.0 + rho * dc_wave_sum(s);
+    }
+    // 1 + rho sum_i w_i^2 / ((d_i - d_K) - mu); dK = 0 after the terms have been shifted
+    auto gfun = [&](double dK, double mu) -> double {
+        double s = 0.0;
+        if (TPL > 0) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) s = fma(w2[q], dc_recip((dd[q] - dK) - mu), s);
+        } else {
+            for (int i = lane; i < k; i += 64) {
+                const double w = wz[i];
+                s = fma(w * w, dc_recip((dl[i] - dK) - mu), s);
+            }
+        }
+        return fma(rho, dc_wave_sum_dpp(s), 1.0);
     };
     int K;
     double hi, sign;
     if (j < k - 1) {
-        const double half = 0.5 * (dl[j + 1] - dl[j]);
-        const double fm = gfun(j, half);
+        const double dj = dl[j];
+        const double half = 0.5 * (dl[j + 1] - dj);
+        const double fm = gfun(dj, half);
         if (fm >= 0) {
             K = j;
             sign = 1.0;
@@ -411,18 +460,28 @@ dc_secular_kernel(DcArgs g) {
         hi = half;
     } else {
         double s = 0.0;
-        for (int i = lane; i < k; i += 64) s += wz[i] * wz[i];
+        if (TPL > 0) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) s += w2[q];
+        } else {
+            for (int i = lane; i < k; i += 64) s += wz[i] * wz[i];
+        }
         K = k - 1;
         sign = 1.0;
-        hi = rho * dc_wave_sum(s);
+        hi = rho * dc_wave_sum_dpp(s);
+    }
+    const double dK = dl[K];
+    if (TPL > 0) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) dd[q] = (lane + 64 * q < k) ? dd[q] - dK : 1e300;
     }
     // bisection on the bit pattern of t = |mu| in (0, hi]:  sign = +1: g(t) < 0 below the root;  sign = -1 (mu = -t):
-    // g(-t) > 0 below the root
+    // g(-t) > 0 below the root.  (A NaN -- a difference of 0 at the far end of the bracket -- reads as "below".)
     long long lb = 0, hb = __double_as_longlong(hi);
     while (hb - lb > 1) {
         const long long mb = lb + ((hb - lb) >> 1);
         const double t = __longlong_as_double(mb);
-        const double val = gfun(K, sign * t);
+        const double val = gfun(TPL > 0 ? 0.0 : dK, sign * t);
         const bool upper = sign > 0 ? (val >= 0) : (val <= 0);
         if (upper) hb = mb;
         else lb = mb;
@@ -431,7 +490,7 @@ dc_secular_kernel(DcArgs g) {
         const double mu = sign * __longlong_as_double(hb);
         g.Kidx[a + j] = K;
         g.mu[a + j] = mu;
-        g.lam[a + j] = dl[K] + mu;
+        g.lam[a + j] = dK + mu;
     }
 }
 
@@ -723,7 +782,10 @@ bool launch_stedc(hipStream_t s, int64_t n, int64_t ld, const double* d, const d
         for (int q = 0; q < L.count; ++q) Nmax = std::max(Nmax, hdesc[L.first + q].n1 + hdesc[L.first + q].n2);
         dc_setup_kernel<<<(unsigned)L.count, DC_THREADS, 0, s>>>(g, sc);
         const unsigned wg4 = (unsigned)((Nmax + 3) / 4);
-        dc_secular_kernel<<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
+        if (Nmax <= 64) dc_secular_kernel<1><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
+        else if (Nmax <= 256) dc_secular_kernel<4><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
+        else if (Nmax <= 1024) dc_secular_kernel<16><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
+        else dc_secular_kernel<0><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
         dc_zhat_kernel<<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
         dc_build_u_kernel<<<dim3((unsigned)Nmax, (unsigned)L.count), DC_THREADS, (size_t)Nmax * 8, s>>>(g);
         double* out = root ? Z : QTnext;

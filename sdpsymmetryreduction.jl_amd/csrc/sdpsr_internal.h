@@ -32,6 +32,7 @@ struct sdpsr_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;  // lazily created: work that overlaps a one-workgroup kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wait = nullptr;
+    hipEvent_t ev_bt_fork = nullptr, ev_bt_join = nullptr;  // eigen.cpp: first pass of the back-transformation beside the tridiagonal solver
     hipStream_t main_shadow = nullptr;  // the main stream while `stream` temporarily points at side_stream
     bool own_stream = false;
     std::string err;

@@ -186,6 +186,45 @@ def test_syev_row_form_panel_form_and_hybrid(pkg):
         assert np.abs(Asym @ V - V * w).max() < 1e-9, (n, flags)
 
 
+def test_tridiagonal_divide_and_conquer_hard_cases(pkg):
+    """The tridiagonal eigensolver of the dense driver (csrc/kernels_stedc.hip: divide and conquer with the secular roots
+    by bisection on the shift's bit pattern) on the matrices that break careless ones -- Wilkinson, glued Wilkinson,
+    graded, decoupled blocks, a handful of eigenvalues with huge multiplicities, the identity -- through sdpsr_syev_f64
+    (the tridiagonalisation of a tridiagonal matrix is the identity); orders with and without padding to 128.
+    eig_driver = 5 (rocSOLVER's stedc behind the same tridiagonalisation) must agree."""
+    import scipy.linalg as sl
+    lib = pkg.load_library()
+
+    def cases(n, rng):
+        yield "random", rng.standard_normal(n), rng.standard_normal(n - 1)
+        yield "1-2-1", 2 * np.ones(n), -np.ones(n - 1)
+        yield "wilkinson", np.abs(np.arange(n) - n // 2).astype(float), np.ones(n - 1)
+        yield "graded", 10.0 ** (-np.arange(n) * 12.0 / n), 10.0 ** (-np.arange(n - 1) * 12.0 / n)
+        yield "decoupled blocks", rng.standard_normal(n), rng.standard_normal(n - 1) * (rng.random(n - 1) < 0.5)
+        Q0, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        Dg = np.repeat(rng.standard_normal(6) * 3, n // 6 + 1)[:n]
+        A = (Q0 * Dg) @ Q0.T
+        H = sl.hessenberg((A + A.T) / 2)
+        yield "six eigenvalues", np.diag(H).copy(), np.diag(H, -1).copy()
+        yield "glued wilkinson", np.tile(np.abs(np.arange(21) - 10.0), n // 21 + 1)[:n], np.where((np.arange(n - 1) + 1) % 21 == 0, 1e-8, 1.0)
+        yield "identity", np.ones(n), np.zeros(n - 1)
+
+    for drv, orders in ((0, (130, 200, 640, 1100)), (5, (200,))):
+        with pkg.Context(seed=1, eig_driver=drv) as ctx:
+            for n in orders:
+                for name, d, e in cases(n, np.random.default_rng(n)):
+                    T = np.asfortranarray(np.diag(d) + np.diag(e, 1) + np.diag(e, -1))
+                    w = np.zeros(n)
+                    V = np.zeros((n, n), order="F")
+                    ctx.check(lib.sdpsr_syev_f64(ctx._h, n, C.c_void_p(T.ctypes.data), C.c_void_p(w.ctypes.data), C.c_void_p(V.ctypes.data), 0))
+                    wl = np.linalg.eigvalsh(T)
+                    sc = np.abs(wl).max()
+                    assert np.all(np.diff(w) >= 0), (drv, n, name)
+                    assert np.abs(w - wl).max() <= 2e-13 * sc, (drv, n, name, np.abs(w - wl).max() / sc)
+                    assert np.abs(T @ V - V * w).max() <= 1e-12 * sc, (drv, n, name)
+                    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12, (drv, n, name)
+
+
 def test_syev_degenerate_spectrum_residual(pkg, problems, gpu_ctx):
     """Generic elements of symmetric algebras have a handful of eigenvalues with huge
     multiplicities: the tridiagonalisation deflates after ~dim columns and then works on
