@@ -386,8 +386,8 @@ def main():
                 workloads[name] = measure(wk, ctx, 10)
                 del wk
                 torch.cuda.empty_cache()
-        # the headline instance with the dense eigensolver forced (hand-written tridiagonalisation,
-        # rocSOLVER stedc, own compact-WY back-transformation on the full n x n generic element)
+        # the headline instance with the dense eigensolver forced (hand-written tridiagonalisation, own tridiagonal
+        # divide and conquer, own compact-WY back-transformation on the full n x n generic element)
         ctx_d = pkg.Context(device=local, seed=2000, square_mode=mode, eig_driver=4)
         try:
             variants["dense_eigensolver"] = measure(w0, ctx_d, 3)
@@ -480,7 +480,15 @@ def main():
                                  "bound": "hbm", "launches_per_reduction": n - 1, "algorithmic_bytes_per_launch": round(avg_bytes), "traffic": tr, "traffic_source": src,
                                  "note": "dense driver only; back-to-back launches from the host (not graph-replayed): includes host launch cost"}
         ms6 = prof(6, n, reps=2)
-        kernels["sytrd_total"] = {"ms": round(ms6, 3), "note": "whole tridiagonalisation (graph replay): symv + form + MFMA syr2k launches"}
+        kernels["sytrd_total"] = {"ms": round(ms6, 3), "note": "whole tridiagonalisation (graph replay): panel form (symv + form + MFMA syr2k launches) for the first n - 2048 columns, one launch per column (sytrd_row_kernel) for the last 2048"}
+        # the row form alone at the orders where the dense driver is the default: 16 (n-j)^2 bytes per column
+        # (trailing matrix read + written once), n^3 / 3 * 16 per reduction
+        for nr in (1024, 2048):
+            msr = prof(6, nr, reps=3)
+            by = 16.0 * nr ** 3 / 3.0
+            kernels["sytrd_rows_n%d" % nr] = {"ms": round(msr, 3), "us_per_column": round(msr * 1e3 / (nr - 1), 2), "bound": "latency" if nr <= 1024 else "hbm",
+                                              "achieved": round(by / (msr * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (msr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              "algorithmic_bytes_per_reduction": round(by), "note": "sytrd_row_kernel: one launch per column, graph replay"}
         # `roofline`: the kernel that carries the O(N^3) work of the default path and its only
         # MFMA-bound one, launched as the product path launches it: TP channels, lower-triangle tiles
         # of the symmetric product.  frac = EXECUTED ops / peak (hardware efficiency); the figure

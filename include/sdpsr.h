@@ -140,7 +140,11 @@ typedef struct sdpsr_opts {
                                channels, at 2 (I + 1) instead of 4 I channel squares for I iterations) */
     int32_t max_iters;      /* 0 = default (10000) */
     int32_t confirm_rounds; /* extra no-change square rounds demanded before stopping (default with channels = 0: 1) */
-    int32_t eig_driver;     /* 0 = default */
+    int32_t eig_driver;     /* driver of diagonalize: 0 = default (module compression when dim(P) is small against n, else
+                               the dense eigensolver: own tridiagonalisation, own tridiagonal divide and conquer, own
+                               back-transformation); 4 = dense forced; 5 = dense with rocSOLVER's stedc for the tridiagonal
+                               problem; 6 = module compression forced; 1, 2, 3 = rocSOLVER syevd / sytrd + stedc + ormtr /
+                               sytrd + steqr + ormtr (comparison only) */
     /* ---- ABI 0.3 (reserved, zero, in 0.2) ---- */
     uint32_t flags;             /* SDPSR_FLAG_* */
     int32_t round_mode;         /* sdpsr_round_mode */
