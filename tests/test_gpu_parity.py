@@ -172,7 +172,7 @@ def test_syev_row_form_panel_form_and_hybrid(pkg):
     larger orders, whose last 2048 columns are handed to the row form).  All three against LAPACK."""
     lib = pkg.load_library()
     rng = np.random.default_rng(7)
-    for n, flags in ((777, 0), (777, pkg._lib.FLAG_SYTRD_PANELS), (1536, 0), (2304, 0)):
+    for n, flags in ((777, 0), (777, pkg._lib.FLAG_SYTRD_PANELS), (1536, 0), (2304, 0), (2500, 0)):
         A = rng.standard_normal((n, n))
         A = np.asfortranarray((A + A.T) / 2)
         A[np.triu_indices(n, 1)] = 1e300  # only the lower triangle is referenced (the row form mirrors it first)

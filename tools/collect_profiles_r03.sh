@@ -42,7 +42,10 @@ python3 bench.py --steps 20 --warmup 3 --skip-roofline --channels 4 > $O/ab_chan
 python3 bench.py --steps 20 --warmup 3 --skip-roofline --channels 4 --workload theta_c32xk128 > $O/ab_channels4_theta.json 2> /dev/null
 python3 tools/config_times.py > $O/config_times.txt 2>&1
 python3 tools/config2_bd_phases.py > $O/config2_bd_phases.txt 2>&1
-for n in 900 1024 2048 4096; do for drv in 0 1; do python3 tools/eig_only.py $n $drv random 2>&1 | grep "syev n=" | tail -1 >> $O/eig_drivers.txt; done; done
+python3 tools/stedc_check.py 200 777 1024 > $O/stedc_check.txt 2>&1
+for f in 0 4096; do echo "sdpsr_opts.flags = $f (4096 = SDPSR_FLAG_SYTRD_PANELS: the panel form at every order)" >> $O/sytrd_time.txt; SDPSR_TOOL_FLAGS=$f python3 tools/sytrd_time.py 512 1024 2048 3072 4096 >> $O/sytrd_time.txt 2>&1; done
+( cd /tmp; SDPSR_TOOL_FLAGS=256 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dense1024 -o eig -- python3 $R/tools/eig_only.py 1024 0 random > $O/dense1024.log 2>&1 )
+for n in 900 1024 2048 4096; do for drv in 0 5 1; do python3 tools/eig_only.py $n $drv random 2>&1 | grep "syev n=" | tail -1 >> $O/eig_drivers.txt; done; done
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = seeds ]; then
 cd $R

@@ -13,11 +13,12 @@ def stats(sub):
 
 
 pairs = [(stats("bench"), "r03_bench_n4096_kernel_stats.csv"), (stats("bench_theta"), "r03_bench_theta_c32xk128_kernel_stats.csv"),
-         (stats("bench_er7"), "r03_bench_theta_er7xk72_kernel_stats.csv"), (stats("dense"), "r03_bench_dense_driver_kernel_stats.csv")]
+         (stats("bench_er7"), "r03_bench_theta_er7xk72_kernel_stats.csv"), (stats("dense"), "r03_bench_dense_driver_kernel_stats.csv"),
+         (stats("dense1024"), "r03_syev_n1024_kernel_stats.csv")]
 for name in ("bench_under_rocprof.json", "bench_theta_under_rocprof.json", "bench_er7_under_rocprof.json", "dense_under_rocprof.json",
              "power_under_kernels.txt", "clock_under_kernels.txt", "config_times.txt", "config2_bd_phases.txt", "eig_drivers.txt",
              "stress_seeds.txt", "big_instance_seeds.txt", "bd_failure_rates.txt", "ab_full_basis_image.json", "ab_no_verify_shortcut.json",
-             "ab_small_eigen_on_device.json", "ab_channels4.json", "ab_channels4_theta.json"):
+             "ab_small_eigen_on_device.json", "ab_channels4.json", "ab_channels4_theta.json", "stedc_check.txt", "sytrd_time.txt"):
     pairs.append((os.path.join(src, name), "r03_" + name))
 pairs.append((os.path.join(src, "bench_default.json"), "r03_bench_n4096.json"))
 for a, b in pairs:
