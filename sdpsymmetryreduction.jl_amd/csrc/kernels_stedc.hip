@@ -789,6 +789,7 @@ bool launch_stedc(hipStream_t s, int64_t n, int64_t ld, const double* d, const d
         else if (Nmax <= 256) dc_secular_kernel<4><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
         else if (Nmax <= 1024) dc_secular_kernel<16><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
         else if (Nmax <= 2048) dc_secular_kernel<32><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
+        else if (Nmax <= 4096) dc_secular_kernel<64><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
         else dc_secular_kernel<0><<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
         dc_zhat_kernel<<<dim3(wg4, (unsigned)L.count), DC_THREADS, 0, s>>>(g);
         dc_build_u_kernel<<<dim3((unsigned)Nmax, (unsigned)L.count), DC_THREADS, (size_t)Nmax * 8, s>>>(g);

@@ -76,7 +76,9 @@ static SymvGeom symv_geometry(int n, int j, int cf) {
     g.nstr = nstrips - g.S0;
     long tiles = 0;
     for (int S = g.S0; S < nstrips; ++S) tiles += nt128 - (S >> 1);
-    int seg = (int)((tiles + 383) / 384);  // ~1.5 workgroups per CU, each streaming `seg` tiles back to back
+    // ~1.5 workgroups per CU, each streaming `seg` tiles back to back (round 3, N = 4096, whole tridiagonalisation in the
+    // panel form with 256 / 384 / 512 / 768 / 1024 / 2048 workgroups aimed at: 72.8 / 72.1 / 74.2 / 75.9 / 77.3 / 77.7 ms)
+    int seg = (int)((tiles + 383) / 384);
     if (seg < 1) seg = 1;
     if (seg > 8) seg = 8;
     g.SEG = seg;
