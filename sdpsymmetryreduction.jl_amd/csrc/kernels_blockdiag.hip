@@ -619,7 +619,9 @@ __device__ __forceinline__ void bo_mfma_block(int s, int sp, int64_t p_begin, in
                     acc[u][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(yb[tj], xa[u], acc[u][tj], 0, 0, 0);
         }
     }
-    // D[jj][ii]: ii = lane & 15 (row a), jj = (lane >> 4) + 4 * reg (column b)
+    // D[jj][ii]: ii = lane & 15 (row a), jj = (lane >> 4) + 4 * reg (column b).  (Round 3 tried sending the block through
+    // LDS so that every wave instruction writes 1 KiB of consecutive addresses, 16 bytes per lane, instead of four 128-byte
+    // pieces at stride 8 s: images of configs[2] 6.8 -> 8.0 ms.  The stores as they are were not the limit; not kept.)
 #pragma unroll
     for (int u = 0; u < TA; ++u) {
         const int ti = wave + 4 * u;
