@@ -20,6 +20,7 @@ rocprofv3 -L > $O/counters_list.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_i8tri_$C -o p -- python3 $R/tools/pmc_probe.py 0 4096 102 > /dev/null 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_insert_$C -o p -- python3 $R/bench.py --steps 4 --warmup 2 --skip-roofline --workload theta_c32xk128 > /dev/null 2>&1
+  for NN in 1024 2048; do SDPSR_TOOL_FLAGS=256 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_rows${NN}_$C -o p -- python3 $R/tools/eig_only.py $NN 0 random > /dev/null 2>&1; done
 done
 # the insert pass of the refinement (refine_insert_kernel<SrcJoint<2,2>,8,1024> in theta_c32xk128): instruction mix and stalls
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_insert_A -o p -- python3 $R/bench.py --steps 4 --warmup 2 --skip-roofline --workload theta_c32xk128 > $O/pmc_insert_A.log 2>&1

@@ -63,6 +63,17 @@ out = {
     "insert_pair": traffic("insert", "refine_insert_kernel<sdpsr::SrcPair", "refine_insert_kernel<SrcPair,8,1024> (initial partition, packed)", lenp * 20),
     "verify_joint_r2_t2": traffic("insert", "verify_lower_kernel<2, 2, true>", "verify_lower_kernel<2,2,true> (compare with class representatives, packed)", lenp * 28),
 }
+# the row form of the tridiagonalisation: launches of sytrd_row_kernel<NCH> while the trailing matrix spans NCH chunks of 128 columns
+# (tools/sytrd_time.py with SDPSR_FLAG_NO_GRAPH).  Algorithmic bytes of launch j: 16 (n - j - 1)^2 (read + write of the trailing matrix);
+# averaged over the launches of the variant.
+def row_alg(n, nch):
+    js = [j for j in range(n - 1) if (((n + 127) // 128 - ((j + 1) >> 7)) <= nch) and (nch == 2 or ((n + 127) // 128 - ((j + 1) >> 7)) > nch // 2)]
+    return sum(16.0 * (n - j - 1) ** 2 for j in js) / max(1, len(js))
+for nn, nch in ((2048, 16), (2048, 8), (1024, 8), (1024, 4)):
+    t = traffic("rows%d" % nn, "sytrd_row_kernel<%d>" % nch, "sytrd_row_kernel<%d> of a tridiagonalisation of order %d (launches with %d..%d chunks of 128 columns left)" % (nch, nn, nch // 2 + 1, nch),
+                row_alg(nn, nch))
+    if t:
+        out["sytrd_rows_n%d_nch%d" % (nn, nch)] = t
 sq = {}
 for tag, pat in (("joint", "refine_insert_kernel<sdpsr::SrcJoint"), ("pair", "refine_insert_kernel<sdpsr::SrcPair"), ("verify", "verify_lower_kernel<2, 2, true>")):
     a = counters("pmc_insert_A", pat)
