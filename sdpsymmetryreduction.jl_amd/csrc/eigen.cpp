@@ -153,6 +153,15 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
         double* Z = (double*)ctx_buf(c, "eig_Z", (size_t)ldz * ldz * sizeof(double));
         if (!Z) return SDPSR_OUT_OF_MEMORY;
         bool bt_forked = false;
+        // an error return between the fork and the join below must not leave the side stream reading A (the caller's
+        // buffer in sdpsr_syev_f64) behind
+        struct SideGuard {
+            sdpsr_ctx* c;
+            bool armed;
+            ~SideGuard() {
+                if (armed && c->side_stream) hipStreamSynchronize(c->side_stream);
+            }
+        } side_guard{c, false};
         if (!own) {
             rs = rocsolver_dsytrd(h, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)lda, w, E, tau);
             if (rs != rocblas_status_success)
@@ -183,6 +192,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
                     return pst ? pst : ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation: event record failed");
                 }
                 bt_forked = true;
+                side_guard.armed = true;
             } else {
                 (void)hipGetLastError();
             }
@@ -218,6 +228,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
         if (own) {
             if (bt_forked) {
                 if (hipStreamWaitEvent(c->stream, c->ev_bt_join, 0) != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation: join failed");
+                side_guard.armed = false;  // the main stream now waits for the side stream's work itself
             } else {
                 const int pst = backtransform_prepare(c, n, A, lda, tau);
                 if (pst) return pst;

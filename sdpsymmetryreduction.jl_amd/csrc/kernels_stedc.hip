@@ -46,7 +46,7 @@ struct DcArgs {
     int *ndorig, *dforig, *Kidx, *meta;  // meta[4 a + 0..3] = k, number of rotations, number of runs, -
     double* rotc;    // 2 ld: (c, s) of rotation i
     int* rotab;      // 2 ld: (deflated row, partner row)
-    int* runoff;     // ld + 1 per level range: rotation index where run t starts (runoff[a + t]), end sentinel
+    int* runoff;     // 2 ld: rotation index where run t of merge q (of the level) starts: runoff[a + q + t]; N + 1 entries per merge
     const DcMerge* desc;
     int nmerge;
 };
