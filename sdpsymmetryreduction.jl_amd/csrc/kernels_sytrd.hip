@@ -678,6 +678,9 @@ sytrd_syr2k_mfma_kernel(SytrdArgs a, int j1, int T0) {
 // So the chain per column is one kernel boundary + (vector loads -> wave reduction, block reduction -> row pass from registers,
 // whose loads were issued at the top of the kernel).  The two products of the update are rounded separately and
 // added (a - (v_i w_c + w_i v_c)): the stored matrix stays bitwise symmetric.
+// (Measured and not kept, round 3: the last 128 columns inside ONE workgroup with the 128 x 128 block in LDS -- dsytd2 with
+// four barriers per column -- takes as long as the 128 launches it replaces, 4 us per column: one CU's LDS moves the
+// block three times per column.)
 // Memory: line a of the allocation (A + a ld) is row a = column a.  Reflector j is stored LAPACK-style on line j,
 // positions >= j+2, one launch late (launch j still reads line j as the matrix row).
 // ---------------------------------------------------------------------------
