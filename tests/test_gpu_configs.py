@@ -372,3 +372,51 @@ def test_bench_forced_disagreement_reaches_the_hash_meet():
     js = _run_bench({"SDPSR_BENCH_FORCE_DISAGREE": "1"}, "--workload", "theta_c32xk128")
     assert js["n_gpus"] == 2 and js["value"] > 0
     assert js["partition_meets"]["warmup"] == 2 and js["partition_meets"]["timed"] == 0
+
+
+@pytest.mark.gpu
+def test_rccl_backend_runs_the_agreement_collectives_single_rank():
+    """gpurun exposes one GPU, so RCCL cannot be run with two ranks here (it refuses two ranks on one device; the two-rank
+    flow is tested over gloo above).  What CAN be shown on this box is that the `nccl` (= RCCL) branch of the agreement
+    step executes with the device tensors and dtypes it uses: process group with device_id, the 16-byte all_gather of the
+    device checksum, the MIN / MAX all-reduce of int32 labels, the SUM all-reduce of int64 keys and the device relabel --
+    here in a group of one rank, where every collective must return its input."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import numpy as np, torch, torch.distributed as dist
+from __graft_entry__ import load_package
+pkg = load_package()
+dev = torch.device("cuda:0")
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl"
+L, d = pkg.problems.synthetic_jordan_partition(512, seed=3)
+tP = torch.from_numpy(np.asfortranarray(L).ravel(order="F").astype(np.int32)).to(dev)
+with pkg.Context(seed=1) as ctx:
+    words = pkg.partition_checksum(tP, ctx=ctx)
+    assert pkg.parallel.checksums_agree(words, device=dev)          # all_gather of two int64 words on the device
+    agreed, lab = pkg.parallel.agree_partition(tP, lambda sig: pkg.relabel_keys(sig, ctx=ctx), checksum=lambda t: pkg.partition_checksum(t, ctx=ctx))
+    assert agreed and bool((lab == tP).all())
+    lo, hi = tP.clone(), tP.clone()                                   # the collectives of a disagreement, issued directly
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert bool((lo == tP).all()) and bool((hi == tP).all())
+    sig = (tP.to(torch.int64) + 1) * 0x1E3779B97F4A7C15
+    ref = sig.clone()
+    dist.all_reduce(sig, op=dist.ReduceOp.SUM)
+    assert bool((sig == ref).all())
+    new, nparts = pkg.relabel_keys(sig - 0x1E3779B97F4A7C15, ctx=ctx)  # zero stays zero, first-occurrence order: the same partition
+    assert int(nparts) == d and bool((new == tP).all())
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
