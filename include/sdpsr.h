@@ -353,7 +353,7 @@ int sdpsr_jordan_reduce(sdpsr_ctx* ctx, int64_t n, const double* CL, const doubl
    over C + check_block_sizes with sum s_k^2 == dim(P) (:13-23); the partition handed to
    basis_image is the desymmetrized one (src/compat.jl:54-57).
    n <= 64: every step in single-workgroup kernels (the reference's own complex tests are 3 x 3
-   and 4 x 4, test/runtests.jl:43-57).  64 < n <= 3072: the Hermitian elements go through their real
+   and 4 x 4, test/runtests.jl:43-57).  64 < n <= 4096: the Hermitian elements go through their real
    symmetric embedding (2n x 2n: the real dense eigensolver and the fp64 MFMA GEMMs; eigenspaces
    are extracted per eigenvalue cluster, SDPSR_NUMERICAL_INCONSISTENCY if a cluster does not
    split evenly).  Larger n: SDPSR_BAD_ARGUMENT.

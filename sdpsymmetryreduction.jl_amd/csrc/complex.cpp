@@ -151,7 +151,7 @@ int sdpsr_block_diagonalize_complex(sdpsr_ctx* c, int64_t n, const uint32_t* P, 
                                     int64_t* sum_s, int mem) {
     CHECK_CTX(c);
     if (!P || n < 1 || d < 0 || !(epsilon > 0)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
-    if (n > 3072) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "complex path: this version covers n <= 3072 (see sdpsr.h)");
+    if (n > 4096) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "complex path: this version covers n <= 4096 (see sdpsr.h)");
     const bool small = n <= 64;  // one-workgroup kernels; larger orders go through the real embedding
     const int64_t len = n * n;
     hipStream_t s = c->stream;

@@ -1270,3 +1270,26 @@ def test_commutative_basis_image_shortcut_equals_projection_formula(pkg, problem
             got = np.array([[bd.blks[i][k][0, 0] for k in range(d)] for i in range(d)])
             want = np.array([[ref[i][k][0, 0] for k in range(d)] for i in range(d)])
             assert np.allclose(got, want, atol=1e-9), (name, flags, seed, np.abs(got - want).max())
+
+
+@pytest.mark.gpu
+def test_complex_path_largest_orders(pkg, problems):
+    """blockDiagonalize(P; complex=true) beyond n = 3072 (the limit of rounds 1-2; now 4096: the embedded real problem of
+    order 2 n <= 8192 goes through the row / panel tridiagonalisation and the tridiagonal divide and conquer): C[S3] (x)
+    {I, J - I} on 560 points, n = 3360, non-commutative, blocks [1, 1, 1, 1, 2, 2] known by construction; orthonormal
+    Q_hat, blks == Q_k^H 1[P==i] Q_k on every class, sum s^2 == dim(P)."""
+    Lm, _ = problems.kron_with_complete(_s3_cayley_labels(), 560, seed=6)
+    n = Lm.shape[0]
+    assert n == 3360
+    with pkg.Context(seed=11) as ctx:
+        P = pkg.Partition.from_matrix(Lm, ctx=ctx)
+        bd = pkg.blockDiagonalize(P, complex=True, ctx=ctx, retries=3)
+    assert sorted(bd.blkSizes) == [1, 1, 1, 1, 2, 2]
+    Pd = bd.partition
+    assert sum(s * s for s in bd.blkSizes) == Pd.nparts
+    Mlab = np.asarray(Pd.matrix)
+    for k, q in enumerate(bd.Q_hat):
+        assert np.allclose(q.conj().T @ q, np.eye(q.shape[1]), atol=1e-9)
+        for c in range(Pd.nparts):
+            M = (Mlab == c + 1).astype(np.float64)
+            assert np.allclose(bd.blks[c][k], q.conj().T @ (M @ q), atol=1e-7), (k, c)
