@@ -110,9 +110,10 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         }
         if (h[1]) {  // table too small for this many classes
             if (sort_ok) {  // 2^16, 2^20 slots, then the sorted relabel (it wins beyond ~2^18 classes)
-                // (up to 2^21 entries a table of 2^16 slots that overflows means more than one class per 43 entries: the
-                // sorted relabel right away -- 0.25 ms at 524 800 entries, all distinct, against 0.5 ms for the 2^20 table)
-                if (log2cap >= 20 || (log2cap >= 16 && len <= (int64_t(1) << 21))) use_sort = true;
+                // (up to 2^21 entries the sorted relabel follows the FIRST overflow -- more than 3072 classes: it takes
+                // 0.25 ms at 524 800 entries whatever their number, a failing pass over a 2^16-slot table 0.66 ms, a
+                // successful one over 2^20 slots with all entries distinct 0.5 ms)
+                if (log2cap >= 20 || len <= (int64_t(1) << 21)) use_sort = true;
                 else log2cap = std::min(full, log2cap < 16 ? 16 : 20);
                 continue;
             }
