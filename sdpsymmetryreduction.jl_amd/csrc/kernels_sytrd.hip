@@ -681,6 +681,10 @@ sytrd_syr2k_mfma_kernel(SytrdArgs a, int j1, int T0) {
 // (Measured and not kept, round 3: the last 128 columns inside ONE workgroup with the 128 x 128 block in LDS -- dsytd2 with
 // four barriers per column -- takes as long as the 128 launches it replaces, 4 us per column: one CU's LDS moves the
 // block three times per column.)
+// (Also measured and not kept: writing the trailing matrix back every SECOND column only -- a launch that finds two pending
+// rank-2 updates applies both in registers, the older pair (v, w) read ready-made -- i.e. a quarter less trailing-matrix
+// traffic: 17.3 ms at n = 2048 with or without the skipped stores, against 15.8 for this kernel (two more vectors per
+// launch in LDS).  The writes ride along with the reads; they are not what a column waits for.)
 // Memory: line a of the allocation (A + a ld) is row a = column a.  Reflector j is stored LAPACK-style on line j,
 // positions >= j+2, one launch late (launch j still reads line j as the matrix row).
 // ---------------------------------------------------------------------------
