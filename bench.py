@@ -394,6 +394,53 @@ def main():
             variants["dense_eigensolver"]["note"] = "eig_driver=4: diagonalize on the full n x n generic element"
         finally:
             ctx_d.close()
+        # two independent restarts IN FLIGHT on the one GPU: two host threads, each with its own ctx (own stream, own
+        # buffers, own seed) and its own copy of the headline instance.  Not the headline figure (that is one reduction
+        # at a time): it shows how much of a step is host round trips and launch gaps that a second restart fills
+        import threading
+        for nth in (2, 4):
+            wks = [build(args.workload) for _ in range(nth)]
+            cxs = [pkg.Context(device=local, seed=3000 + i, square_mode=mode, flags=opt_flags, channels=args.channels) for i in range(nth)]
+            try:
+                for wk, cx in zip(wks, cxs):
+                    retrying(lambda: one_step(wk, Acc(), cx, check=True, collective=False))
+                    retrying(lambda: one_step(wk, Acc(), cx, check=True, collective=False))
+                steps2 = max(10, args.steps)
+                errs = []
+                gate = threading.Barrier(nth + 1)
+
+                def run(wk, cx):
+                    try:
+                        a2 = Acc()
+                        gate.wait()
+                        for _ in range(steps2):
+                            retrying(lambda: one_step(wk, a2, cx, collective=False, timers=False))
+                        cx.synchronize()
+                    except Exception as exc:  # noqa: BLE001
+                        errs.append(repr(exc))
+
+                ths = [threading.Thread(target=run, args=(wk, cx)) for wk, cx in zip(wks, cxs)]
+                for th in ths:
+                    th.start()
+                torch.cuda.synchronize()
+                gate.wait()
+                t2 = time.perf_counter()
+                for th in ths:
+                    th.join()
+                torch.cuda.synchronize()
+                el2 = time.perf_counter() - t2
+                if not errs:
+                    for wk, cx in zip(wks, cxs):
+                        retrying(lambda: one_step(wk, Acc(), cx, check=True, collective=False))  # still the generator's closure
+                    variants["%d_restarts_in_flight" % nth] = {"value": round(nth * steps2 / el2, 3), "unit": "reductions/s", "threads": nth, "steps_per_thread": steps2,
+                                                          "note": "%d ctx threads on one GPU, one reduction at a time each; informational (the headline is one ctx)" % nth}
+                else:
+                    variants["%d_restarts_in_flight" % nth] = {"error": errs[0][:200]}
+            finally:
+                for cx in cxs:
+                    cx.close()
+                del wks
+                torch.cuda.empty_cache()
 
     # ---- roofline leg: per-launch duration of the hot kernels, HIP events on ctx's stream ----
     lib = ctx._lib
