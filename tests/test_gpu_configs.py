@@ -420,3 +420,69 @@ print("RCCL_ONE_RANK_OK")
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_four_restarts_in_flight_on_one_gpu(pkg, problems, golden):
+    """Independent restarts on one GPU, one ctx per host thread (the bench's N_restarts_in_flight variants):
+    four threads run the whole path concurrently -- two on the commutative scheme at N = 1024 (module compression), one on
+    the non-commutative ER(7) algebra, one on a partition without symmetry at n = 512 (dense eigensolver: row
+    tridiagonalisation, side-stream back-transformation, tridiagonal divide and conquer, device-side classes) -- and every
+    run must end on its known answer: nothing is shared between the ctxs."""
+    import threading
+    Ls, ds = problems.synthetic_jordan_partition(1024, seed=4)
+    Cs, As, bs = problems.partition_as_sdp(Ls, seed=1)
+    Le = golden["er7_P"].astype(np.int64)
+    de = int(Le.max())
+    Ce, Ae, be = problems.partition_as_sdp(Le, seed=2)
+    Cg, Ag, bg = problems.theta_prime_problem(problems.gnp_adjacency(512, 0.5, seed=9))
+    errs = []
+
+    def scheme(seed):
+        try:
+            with pkg.Context(seed=seed) as ctx:
+                for _ in range(4):
+                    P = pkg.admissible_subspace(Cs, As, bs, ctx=ctx)
+                    assert P.nparts == ds and np.array_equal(P.matrix, Ls)
+                    bd = pkg.blockDiagonalize(P, ctx=ctx, retries=3)
+                    assert sorted(bd.blkSizes) == [1] * ds
+        except Exception as exc:  # noqa: BLE001
+            errs.append(("scheme", seed, repr(exc)))
+
+    def er7(seed):
+        try:
+            with pkg.Context(seed=seed) as ctx:
+                for _ in range(6):
+                    P = pkg.admissible_subspace(Ce, Ae, be, ctx=ctx)
+                    assert P.nparts == de and np.array_equal(P.matrix, Le)
+                    bd = pkg.blockDiagonalize(P, ctx=ctx, retries=3)
+                    assert sorted(bd.blkSizes) == sorted(int(x) for x in golden["er7_blk"])
+        except Exception as exc:  # noqa: BLE001
+            errs.append(("er7", seed, repr(exc)))
+
+    def generic(seed):
+        try:
+            with pkg.Context(seed=seed) as ctx:
+                for _ in range(3):
+                    P = pkg.admissible_subspace(Cg, Ag, bg, ctx=ctx)
+                    assert P.nparts == 512 * 513 // 2
+                    Qh = None
+                    for attempt in range(8):  # one class of 512 coupled eigenspaces: the reference's own consistency check
+                        try:                   # rejects a fair share of the draws ("simply try again")
+                            Qh = pkg.diagonalize(P, ctx=ctx)
+                            break
+                        except (pkg.NumericalInconsistency, pkg.DimensionMismatch):
+                            continue
+                    assert Qh is not None
+                    assert [q.shape for q in Qh] == [(512, 512)]
+                    assert np.abs(Qh[0].T @ Qh[0] - np.eye(512)).max() < 1e-9
+        except Exception as exc:  # noqa: BLE001
+            errs.append(("generic", seed, repr(exc)))
+
+    ths = [threading.Thread(target=scheme, args=(11,)), threading.Thread(target=scheme, args=(12,)),
+           threading.Thread(target=er7, args=(13,)), threading.Thread(target=generic, args=(14,))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
