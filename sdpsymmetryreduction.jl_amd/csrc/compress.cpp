@@ -419,15 +419,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     };
     bool forked = false;
     auto ensure_side = [&]() -> int {
-        if (!c->side_stream) {
-            if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                return SDPSR_HIP_ERROR;
-            }
-        }
-        return SDPSR_OK;
+        return ctx_ensure_side(c) ? SDPSR_OK : SDPSR_HIP_ERROR;
     };
     gen.fork = [&]() -> int {
         forked = false;

@@ -65,6 +65,24 @@ void* ctx_pinned(sdpsr_ctx* c, size_t bytes) {  // shared with eigen.cpp
     return c->pinned;
 }
 
+// the side stream of the ctx and the events of its three users (generic-element prefetch of the drivers, first half of
+// the back-transformation, projection beside the square): created together, on first use
+bool ctx_ensure_side(sdpsr_ctx* c) {
+    if (!c->side_stream && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) {
+        c->side_stream = nullptr;
+        (void)hipGetLastError();
+        return false;
+    }
+    hipEvent_t* evs[] = {&c->ev_fork, &c->ev_join, &c->ev_bt_fork, &c->ev_bt_join};
+    for (hipEvent_t* e : evs)
+        if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
+            *e = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+    return true;
+}
+
 bool dbg_on() { return getenv("SDPSR_DEBUG") != nullptr; }
 void dbg_mark(sdpsr_ctx* c, const char* what) {
     if (!dbg_on()) return;

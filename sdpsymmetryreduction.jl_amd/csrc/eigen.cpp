@@ -174,10 +174,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: tridiagonalisation done"); }
             if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "sytrd launch failed");
             // first half of the back-transformation on the side stream, beside the tridiagonal solver
-            bool side_ok = c->side_stream || hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess;
-            if (side_ok && !c->ev_bt_fork)
-                side_ok = hipEventCreateWithFlags(&c->ev_bt_fork, hipEventDisableTiming) == hipSuccess &&
-                          hipEventCreateWithFlags(&c->ev_bt_join, hipEventDisableTiming) == hipSuccess;
+            const bool side_ok = ctx_ensure_side(c);
             hipStream_t main_stream = c->stream;
             if (side_ok && c->side_stream != main_stream && hipEventRecord(c->ev_bt_fork, main_stream) == hipSuccess &&
                 hipStreamWaitEvent(c->side_stream, c->ev_bt_fork, 0) == hipSuccess) {

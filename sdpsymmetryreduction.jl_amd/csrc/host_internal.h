@@ -64,6 +64,7 @@ int out_finish(sdpsr_ctx* c, T* host, const T* dev, size_t count, int mem) {
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+bool ctx_ensure_side(sdpsr_ctx* c);
 int d2h_sync(sdpsr_ctx* c, void* host, const void* dev, size_t bytes);
 // Upload of a small host array.  Up to 32 KiB go through a ring of pinned slots and stay
 // stream-ordered (the caller's buffer is free on return, no host wait)

@@ -157,6 +157,9 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
         if (!separate && packed_proj && keep_packed && (T == 2 || T == 4) && c->table_log2_hint < 21) {
             const bool jl = packed_valid;
             if (!jl) need_full();
+            // (Round 3 measured this dot-product pass on the side stream BESIDE the channel gather and the int8 square -- two
+            // independent readers of the same labels: theta_c32xk128 477 against 480 reductions/s in sequence, closed_scheme
+            // 1016 against 1028.  The square slows by what the overlapped pass takes from it; kept in sequence.)
             launch_proj_coef_lower(s, n, r, dU, jl ? Lp : L, jl ? 1 : 0, key, partial, nblk, coef);
             tm.end();
             int64_t dj = current;
