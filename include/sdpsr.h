@@ -155,7 +155,11 @@ typedef struct sdpsr_opts {
                                    Partition{T} (admissible_subspace defaults to UInt16, src/partitions.jl:84):
                                    SDPSR_LABEL_OVERFLOW where the reference throws InexactError (see below) */
     int32_t insert_wgs_per_cu;  /* measurement knob: resident workgroups per CU of the refinement's insert pass (0 = default) */
-    int32_t reserved[4];
+    int32_t square_kernel;      /* int8 square of symmetric labels (src/partitions.jl:172): 0 = default (one persistent launch
+                                   of 256 x 256 macro-tiles once they fill the chip, 128 x 128 tiles below that), 1 = always
+                                   128 x 128 tiles (the launch of ABI 0.3), 64 / 128 = always the persistent launch, with
+                                   64-byte K stages in a ring of four / two 128-byte stages.  Same integers every way. */
+    int32_t reserved[3];
 } sdpsr_opts;
 
 /* phase_ms slots filled by sdpsr_admissible_subspace / sdpsr_block_diagonalize
@@ -259,6 +263,11 @@ int sdpsr_project_out(sdpsr_ctx* ctx, int64_t len, double* x, const double* U, i
 int sdpsr_square_f64(sdpsr_ctx* ctx, int64_t n, const double* X, double* X2, int mem);
 int sdpsr_square_f32(sdpsr_ctx* ctx, int64_t n, const float* X, float* X2, int mem);
 int sdpsr_square_i8(sdpsr_ctx* ctx, int64_t n, const int8_t* X, int32_t* X2, int mem);
+/* The square step as the int8 loop runs it: `batch` (1..8) SYMMETRIC n x n int8 matrices (the channel matrices of one
+   draw, batch-major; symmetry is the caller's word, as the loop has it from the labels), squared exactly in one launch
+   that computes the lower-triangle tiles only (sdpsr_opts.square_kernel picks the kernel); X2 receives the full
+   matrices, the upper triangles mirrored.  mul!(X2, X, X), src/partitions.jl:172, for symmetric X. */
+int sdpsr_square_i8_symmetric(sdpsr_ctx* ctx, int64_t n, int64_t batch, const int8_t* X, int32_t* X2, int mem);
 /* C = A' * B, all column-major fp64: A is k x m (lda), B is k x n (ldb), C m x n (ldc).
    The Q'AQ products of src/eigen_decomposition.jl:203 and the block products of :70. */
 int sdpsr_gemm_tn_f64(sdpsr_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A,

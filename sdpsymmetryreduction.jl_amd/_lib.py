@@ -55,7 +55,8 @@ class Opts(C.Structure):
         ("refine_path", C.c_int32),
         ("label_bits", C.c_int32),
         ("insert_wgs_per_cu", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("square_kernel", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -103,6 +104,7 @@ def load_library():
         "sdpsr_square_f64": (C.c_int, [vp, i64, vp, vp, C.c_int]),
         "sdpsr_square_f32": (C.c_int, [vp, i64, vp, vp, C.c_int]),
         "sdpsr_square_i8": (C.c_int, [vp, i64, vp, vp, C.c_int]),
+        "sdpsr_square_i8_symmetric": (C.c_int, [vp, i64, i64, vp, vp, C.c_int]),
         "sdpsr_gemm_tn_f64": (C.c_int, [vp, i64, i64, i64, vp, i64, vp, i64, vp, i64, C.c_int]),
         "sdpsr_admissible_subspace": (C.c_int, [vp, i64, vp, vp, vp, i64, dbl, vp, pi64, pi32, vp, C.c_int]),
         "sdpsr_admissible_subspace_dense": (C.c_int, [vp, i64, i64, vp, vp, vp, dbl, vp, pi64, pi32, vp, C.c_int]),

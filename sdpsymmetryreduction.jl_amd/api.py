@@ -67,7 +67,7 @@ class Context:
 
     def __init__(self, device=0, seed=0, square_mode=L.SQUARE_AUTO, channels=0, max_iters=0,
                  confirm_rounds=0, eig_driver=0, flags=0, round_mode="nearest", basis_image_kernel="auto",
-                 refine_path="auto", label_bits=0, insert_wgs_per_cu=0):
+                 refine_path="auto", label_bits=0, insert_wgs_per_cu=0, square_kernel=0):
         """``flags``: OR of ``_lib.FLAG_*``; ``round_mode``: "nearest" (default) or "trunc" (the
         reference's ``unsafe_round``, src/utils.jl:49-53); ``label_bits``: 0, or the width of the
         reference's label type ``T`` in ``Partition{T}`` to get ``LabelOverflow`` where it would throw."""
@@ -85,6 +85,7 @@ class Context:
         o.refine_path = L.REFINE_PATHS[refine_path] if isinstance(refine_path, str) else int(refine_path)
         o.label_bits = int(label_bits)
         o.insert_wgs_per_cu = int(insert_wgs_per_cu)
+        o.square_kernel = int(square_kernel)
         h = C.c_void_p()
         st = self._lib.sdpsr_create(int(device), C.c_uint64(seed & (2 ** 64 - 1)), C.byref(o), C.byref(h))
         if st != 0:

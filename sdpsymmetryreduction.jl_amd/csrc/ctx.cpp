@@ -222,6 +222,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
         c->num_cus = 256;
     // per-device kernel attributes (dynamic LDS above 64 KiB); cheap and idempotent
     gemm_set_device_attributes();
+    gemm_sym_set_device_attributes();
     blockdiag_set_device_attributes();
     module_set_device_attributes();
     partition_set_device_attributes();

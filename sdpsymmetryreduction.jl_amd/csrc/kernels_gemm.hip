@@ -748,7 +748,11 @@ void launch_gemm_tn_f64_sub(hipStream_t s, int64_t m, int64_t n, int64_t k, cons
 // C = X'X with only the lower-triangle tiles computed while *nonsym_flag == 0 (device-side
 // decision, no host round trip); the consumer must then read C[i,j] for i >= j only
 void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc,
-                           int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag) {
+                           int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag, int num_cus, int variant) {
+    // the persistent 256 x 256 launch of kernels_gemm_sym.hip when the shapes allow it (num_cus = 0: never)
+    if (nonsym_flag && variant != 1 &&
+        launch_i8_symsquare(s, n, k, X, ldx, C, ldc, batch, strideX, strideC, nonsym_flag, num_cus, variant))
+        return;
     launch_gemm<KIND_I8>(s, n, n, k, X, ldx, X, ldx, C, ldc, batch, strideX, strideX, strideC, nonsym_flag);
 }
 void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X, int64_t ldx, float* C, int64_t ldc,

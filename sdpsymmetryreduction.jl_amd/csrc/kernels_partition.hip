@@ -321,6 +321,18 @@ void launch_pad_copy(hipStream_t s, int64_t n, int64_t ld, const void* src, void
     else
         pad_copy_kernel<double><<<g, 256, 0, s>>>(n, ld, (const double*)src, (double*)dst);
 }
+// dst (n x n) from the LOWER triangle of the padded src (ld x ld), mirrored: dst[i, j] = src[max(i, j), min(i, j)]
+__global__ void unpad_mirror_lower_i32_kernel(int64_t n, int64_t ld, const int32_t* __restrict__ src, int32_t* __restrict__ dst) {
+    const int64_t total = n * n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += stride) {
+        const int64_t j = c / n, i = c - j * n;
+        dst[c] = i >= j ? src[i + j * ld] : src[j + i * ld];
+    }
+}
+void launch_unpad_mirror_lower_i32(hipStream_t s, int64_t n, int64_t ld, const int32_t* src, int32_t* dst) {
+    unpad_mirror_lower_i32_kernel<<<grid_for(n * n, 256), 256, 0, s>>>(n, ld, src, dst);
+}
 void launch_unpad_copy(hipStream_t s, int64_t n, int64_t ld, const void* src, void* dst,
                        int elem_bytes) {
     int g = grid_for(n * n, 256);

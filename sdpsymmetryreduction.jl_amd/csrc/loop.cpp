@@ -53,7 +53,10 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
 
     const int mode = c->opts.square_mode;
     const int T = (mode == SDPSR_SQUARE_F64) ? 1 : c->opts.channels;
-    const int64_t ld = round_up(n, 128);
+    // int8 channels: padded to whole 256 x 256 macro-tiles of the persistent square (kernels_gemm_sym.hip)
+    const bool sq256 = mode == SDPSR_SQUARE_I8 && (c->opts.square_kernel == 64 || c->opts.square_kernel == 128 ||
+                                                   (c->opts.square_kernel == 0 && i8_symsquare_pays(n, T, c->num_cus)));
+    const int64_t ld = round_up(n, sq256 ? 256 : 128);
     void* Xp = nullptr;
     void* Cp = nullptr;
     double* Y = nullptr;
@@ -170,7 +173,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                 const bool jl2 = packed_valid;
                 if (jl2) launch_gather_i8_sym_packed(s, n, ld, T, Lp, key2, (int8_t*)Xp, current);
                 else launch_gather_i8(s, n, ld, T, L, key2, (int8_t*)Xp, current);
-                launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, zero_flag);
+                launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, zero_flag, c->num_cus, c->opts.square_kernel);
                 tm.end();
                 tm.begin(SDPSR_T_REFINE);
                 SigSource qj;
@@ -341,7 +344,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                     launch_gather_i8(s, n, ld, T, Lleft, key2, Xl, d2);
                     launch_gemm_tn_i8(s, ld, ld, ld, Xl, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, ld * ld);
                 } else {
-                    launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, lower);
+                    launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xp, ld, (int32_t*)Cp, ld, T, ld * ld, ld * ld, lower, c->num_cus, c->opts.square_kernel);
                 }
                 qs.kind = SIG_CHAN_I32;
             } else if (mode == SDPSR_SQUARE_F32) {

@@ -340,6 +340,29 @@ int sdpsr_square_i8(sdpsr_ctx* c, int64_t n, const int8_t* X, int32_t* X2, int m
     return square_generic<int8_t, int32_t>(c, n, X, X2, mem, launch_gemm_tn_i8);
 }
 
+// `batch` symmetric int8 matrices squared in ONE launch, as the loop squares its channel matrices (lower-triangle
+// tiles only, the persistent macro-tile launch by sdpsr_opts.square_kernel); results mirrored into full matrices
+int sdpsr_square_i8_symmetric(sdpsr_ctx* c, int64_t n, int64_t batch, const int8_t* X, int32_t* X2, int mem) {
+    CHECK_CTX(c);
+    if (!X || !X2 || n < 1 || batch < 1 || batch > 8) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    int st = SDPSR_OK;
+    const int sk = c->opts.square_kernel;
+    const bool sq256 = sk == 64 || sk == 128 || (sk == 0 && i8_symsquare_pays(n, (int)batch, c->num_cus));
+    const int64_t ld = round_up(n, sq256 ? 256 : 128);
+    const int8_t* dX = in_dev(c, "sq_in", X, (size_t)batch * n * n, mem, &st);
+    int8_t* Xp = (int8_t*)ctx_buf(c, "sq_xpad", (size_t)batch * ld * ld);
+    int32_t* Cp = (int32_t*)ctx_buf(c, "sq_cpad", (size_t)batch * ld * ld * 4);
+    int32_t* dC = out_dev(c, "sq_out", X2, (size_t)batch * n * n, mem, &st);
+    uint32_t* zflag = (uint32_t*)ctx_buf(c, "sq_zero", 64);
+    if (st || !Xp || !Cp || !zflag) return st ? st : SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemsetAsync(zflag, 0, 64, c->stream));
+    for (int64_t b = 0; b < batch; ++b) launch_pad_copy(c->stream, n, ld, dX + b * n * n, Xp + b * ld * ld, 1);
+    launch_gemm_tn_i8_sym(c->stream, ld, ld, Xp, ld, Cp, ld, (int)batch, ld * ld, ld * ld, zflag, c->num_cus, sk);
+    for (int64_t b = 0; b < batch; ++b) launch_unpad_mirror_lower_i32(c->stream, n, ld, Cp + b * ld * ld, dC + b * n * n);
+    HIP_TRY(c, hipGetLastError());
+    return out_finish(c, X2, dC, (size_t)batch * n * n, mem);
+}
+
 int sdpsr_gemm_tn_f64(sdpsr_ctx* c, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda,
                       const double* B, int64_t ldb, double* C, int64_t ldc, int mem) {
     CHECK_CTX(c);

@@ -38,13 +38,19 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         // aux = batch (channels of one launch, as the product path launches them); operands of
         // all channels are distinct memory
         // aux >= 100: the lower-triangle launch of the product path (symmetric labels), batch aux - 100
+        // aux 100..: the default kernel of that launch (int8: the persistent 256 x 256 launch of kernels_gemm_sym.hip);
+        // 200..: int8 with 128 x 128 tiles (round 3's launch); 300..: the persistent launch with two 128-byte stages
         const bool tri = aux >= 100 && kind <= 1;
-        if (tri) aux -= 100;
+        // 1000 * d + 100..: diagnostic build d of the persistent launch (1 no MFMAs, 2 no DMA after the prologue, 4 no stores);
+        // 400..: the operand's leading dimension padded by 128 bytes (row stride not a power of two)
+        int sq_variant = aux >= 1000 ? 1000 + (int)(aux / 1000) : (aux >= 300 && aux < 400 ? 128 : (aux >= 200 && aux < 300 ? 1 : 0));
+        const int64_t ldx_pad = (aux % 1000) >= 400 && (aux % 1000) < 500 ? 128 : 0;
+        if (tri) aux %= 100;
         const int bt = (int)std::min<int64_t>(std::max<int64_t>(aux, 1), 8);
         uint32_t* zflag = (uint32_t*)ctx_buf(c, "prof_zero", 64);
         if (!zflag) return SDPSR_OUT_OF_MEMORY;
         HIP_TRY(c, hipMemsetAsync(zflag, 0, 64, s));
-        void* X = ctx_buf(c, "prof_x", (size_t)ld * ld * es * bt);
+        void* X = ctx_buf(c, "prof_x", (size_t)(ld + 128) * ld * es * bt);
         void* Cc = ctx_buf(c, "prof_c", (size_t)ld * ld * os * bt);
         uint32_t* Lb = (uint32_t*)ctx_buf(c, "prof_l", (size_t)ld * ld * 4);
         if (!X || !Cc || !Lb) return SDPSR_OUT_OF_MEMORY;
@@ -58,7 +64,7 @@ extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t a
         }
         const int64_t sb = ld * ld;
         auto run = [&]() {
-            if (tri && kind == 0) launch_gemm_tn_i8_sym(s, ld, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, bt, sb, sb, zflag);
+            if (tri && kind == 0) launch_gemm_tn_i8_sym(s, ld, ld, (int8_t*)X, ld + ldx_pad, (int32_t*)Cc, ld, bt, sb + ldx_pad * ld, sb, zflag, c->num_cus, sq_variant);
             else if (tri && kind == 1) launch_gemm_tn_f32_sym(s, ld, ld, (float*)X, ld, (float*)Cc, ld, bt, sb, sb, zflag);
             else if (kind == 0) launch_gemm_tn_i8(s, ld, ld, ld, (int8_t*)X, ld, (int8_t*)X, ld, (int32_t*)Cc, ld, bt, sb, sb, sb);
             else if (kind == 1) launch_gemm_tn_f32(s, ld, ld, ld, (float*)X, ld, (float*)X, ld, (float*)Cc, ld, bt, sb, sb, sb);

@@ -103,6 +103,7 @@ void launch_gather_f32(hipStream_t s, int64_t n, int64_t ld, int T, int vmax, co
 void launch_gather_f64_padded(hipStream_t s, int64_t n, int64_t ld, const uint32_t* L,
                               uint64_t key, double* X);
 // dense copy with padding: dst[ld x ld] <- src[n x n], zero padding (templated by bytes)
+void launch_unpad_mirror_lower_i32(hipStream_t s, int64_t n, int64_t ld, const int32_t* src, int32_t* dst);
 void launch_pad_copy(hipStream_t s, int64_t n, int64_t ld, const void* src, void* dst,
                      int elem_bytes);
 void launch_unpad_copy(hipStream_t s, int64_t n, int64_t ld, const void* src, void* dst,
@@ -257,8 +258,15 @@ void launch_copy_check_symmetric(hipStream_t s, int64_t n, const uint32_t* src, 
 // Operands must be padded: k multiple of KT, m and n multiples of 128, pointers 16-B
 // aligned, lda/ldb multiples of 16 bytes.
 // ---------------------------------------------------------------------------
+// num_cus > 0: the persistent 256 x 256 launch (kernels_gemm_sym.hip) when n is a multiple of 256; variant =
+// sdpsr_opts.square_kernel (0 = by size, 1 = 128 x 128 tiles of kernels_gemm.hip, 64 / 128 = persistent forced)
 void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc,
-                           int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag);
+                           int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag, int num_cus = 0,
+                           int variant = 0);
+bool launch_i8_symsquare(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc, int batch,
+                         int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag, int num_cus, int variant);
+bool i8_symsquare_pays(int64_t n, int T, int num_cus);
+void gemm_sym_set_device_attributes();
 void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X, int64_t ldx, float* C, int64_t ldc,
                             int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag);
 void launch_unpack_symmetric_labels(hipStream_t s, int64_t n, const uint32_t* Lp, uint32_t* L);

@@ -116,6 +116,47 @@ def test_square_i8_exact(pkg, gpu_ctx, n):
     assert np.array_equal(out.reshape(n, n, order="F"), ref)
 
 
+def _sym_i8(rng, n):
+    X = rng.integers(-128, 128, size=(n, n))
+    return (np.triu(X) + np.triu(X, 1).T).astype(np.int8)
+
+
+@pytest.mark.parametrize("kernel", [64, 128, 1])
+def test_square_i8_symmetric_batch_every_kernel(pkg, gpu_ctx, kernel):
+    """mul!(X2, X, X) (src/partitions.jl:172) for the loop's symmetric channel matrices, batched as the loop launches
+    them: the persistent 256 x 256 macro-tile launch forced at sizes with 1, 2, 3 and 5 macro-tile rows (odd and even
+    numbers of diagonal tiles: the paired diagonal jobs incl. the one whose partner is missing), both ring forms, and
+    the 128 x 128 tiles: bit-exact against integer matmul."""
+    lib = pkg.load_library()
+    with pkg.Context(seed=3, square_kernel=kernel) as ctx:
+        for n, batch in ((200, 1), (256, 2), (300, 3), (700, 2), (1100, 3)):
+            rng = np.random.default_rng(1000 * n + batch)
+            Xs = [_sym_i8(rng, n) for _ in range(batch)]
+            Xf = np.concatenate([_fl(X, np.int8) for X in Xs])
+            out = np.zeros(batch * n * n, dtype=np.int32)
+            ctx.check(lib.sdpsr_square_i8_symmetric(ctx._h, n, batch, C.c_void_p(Xf.ctypes.data), C.c_void_p(out.ctypes.data), 0))
+            for b, X in enumerate(Xs):
+                ref = (X.astype(np.float64) @ X.astype(np.float64)).astype(np.int64)  # |sums| < 2^53: exact in fp64
+                got = out[b * n * n:(b + 1) * n * n].reshape(n, n, order="F")
+                assert np.array_equal(got, ref), (kernel, n, batch, b)
+
+
+def test_square_i8_symmetric_n4096_default_launch(pkg, gpu_ctx):
+    """The product launch of the bench instances (N = 4096, 2 channels: 240 full + 16 paired diagonal jobs, one per CU)
+    and the N = 4104 shape (padded to 4352: two rounds of jobs), default kernel choice."""
+    lib = pkg.load_library()
+    for n in (4096, 4104):
+        rng = np.random.default_rng(n)
+        Xs = [_sym_i8(rng, n) for _ in range(2)]
+        Xf = np.concatenate([_fl(X, np.int8) for X in Xs])
+        out = np.zeros(2 * n * n, dtype=np.int32)
+        gpu_ctx.check(lib.sdpsr_square_i8_symmetric(gpu_ctx._h, n, 2, C.c_void_p(Xf.ctypes.data), C.c_void_p(out.ctypes.data), 0))
+        for b, X in enumerate(Xs):
+            Xd = X.astype(np.float64)
+            ref = (Xd @ Xd).astype(np.int64)
+            assert np.array_equal(out[b * n * n:(b + 1) * n * n].reshape(n, n, order="F"), ref), (n, b)
+
+
 @pytest.mark.parametrize("n", [7, 130, 256])
 def test_square_f32_exact_on_small_integers(pkg, gpu_ctx, n):
     lib = pkg.load_library()

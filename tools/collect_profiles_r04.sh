@@ -1,0 +1,47 @@
+#!/bin/bash
+# Round 4, on the GPU box (through gpurun): counter passes under the two squares (int8 product launch, fp32 N = 8192),
+# kernel statistics of the bench instances at N = 4096 and N = 8192, the dense driver, the many-classes refinement.
+# Output under gpurun_out/r04/; tools/copy_profiles_r04.py turns it into profiles/r04_*.
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r04
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+WHAT=${1:-all}
+pmc_pass() {  # tag, counters, program args...
+  local tag=$1; shift; local ctr=$1; shift
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$tag -o p -- python3 "$@" > $O/pmc_$tag.log 2>&1
+}
+if [ "$WHAT" = all ] || [ "$WHAT" = pmc_squares ]; then
+  # int8 product launch (2 channels, lower-triangle tiles) and the fp32 square at N = 8192: MFMA group, LDS / stall group,
+  # HBM traffic -- every group its own pass
+  for K in "i8tri 0 4096 102" "f32n8192 1 8192 1"; do
+    set -- $K; T=$1; shift
+    pmc_pass ${T}_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA" $R/tools/pmc_probe.py "$@"
+    pmc_pass ${T}_lds "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" $R/tools/pmc_probe.py "$@"
+    pmc_pass ${T}_grbm "GRBM_GUI_ACTIVE" $R/tools/pmc_probe.py "$@"
+    pmc_pass ${T}_FETCH_SIZE "FETCH_SIZE" $R/tools/pmc_probe.py "$@"
+    pmc_pass ${T}_WRITE_SIZE "WRITE_SIZE" $R/tools/pmc_probe.py "$@"
+  done
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/squares8192 -o sq -- python3 $R/tools/pmc_probe.py 1 8192 1 > $O/squares8192.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/squares_i8tri -o sq -- python3 $R/tools/pmc_probe.py 0 4096 102 > $O/squares_i8tri.log 2>&1
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = stats ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 $R/bench.py --steps 30 --warmup 5 --skip-roofline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_theta -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --skip-roofline --workload theta_c32xk128 > $O/bench_theta_under_rocprof.json 2> /dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_er7 -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --skip-roofline --workload theta_er7xk72 > $O/bench_er7_under_rocprof.json 2> /dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/dense -o dense -- python3 $R/bench.py --steps 3 --warmup 1 --skip-roofline --eig-driver 4 --no-graph > $O/dense_under_rocprof.json 2> /dev/null
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = n8192 ]; then
+  cd $R
+  python3 bench.py --n 8192 --steps 10 --warmup 2 > $O/bench_n8192.json 2> $O/bench_n8192.err
+  ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench8192 -o bench -- python3 $R/bench.py --n 8192 --steps 10 --warmup 2 --skip-roofline > $O/bench_n8192_under_rocprof.json 2> /dev/null )
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
+  cd $R
+  python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+  python3 tools/config_times.py > $O/config_times.txt 2>&1
+  python3 tools/stedc_check.py 200 777 1024 > $O/stedc_check.txt 2>&1
+  for f in 0; do SDPSR_TOOL_FLAGS=$f python3 tools/sytrd_time.py 512 1024 2048 3072 4096 >> $O/sytrd_time.txt 2>&1; done
+  for n in 1024 2048 4096; do for drv in 0 1; do python3 tools/eig_only.py $n $drv random 2>&1 | grep "syev n=" | tail -1 >> $O/eig_drivers.txt; done; done
+fi
+ls $O | head -80
