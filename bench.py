@@ -51,6 +51,23 @@ HBM_PEAK_GBS = 8000.0
 ATOL = 1.4901161193847656e-08
 
 
+def cpu_baseline_theta(pr, n_sample):
+    """The CPU oracle on the instance that ITERATES (theta' SDP of C_32 [] K_k, 5 iterations of the loop), at a
+    reduced order n_sample = 32 k: the loop side of the path gets a measured CPU figure too."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sdpsr_oracle as O
+    k = max(1, n_sample // 32)
+    Cv, A, b, Ls, d = pr.theta_prime_product_problem(pr.cycle_adjacency(32), pr.symmetric_circulant_labels(32), k, seed=1)
+    setup = O.admissible_setup(Cv, A, b)
+    t0 = time.perf_counter()
+    P = O.admissible_subspace(Cv, A, b, rng=np.random.default_rng(0), setup=setup)
+    t1 = time.perf_counter()
+    O.block_diagonalize(P, rng=np.random.default_rng(1))
+    t2 = time.perf_counter()
+    assert np.array_equal(P.matrix, Ls)
+    return {"adm_s": t1 - t0, "bd_s": t2 - t1, "n": 32 * k, "dim": int(d)}
+
+
 def cpu_baseline(pr, n_sample, seed):
     """The CPU oracle (NumPy/SciPy restatement, NOT Julia) timed on the host cores: one full
     reduction of the headline workload's generator at order n_sample."""
@@ -75,9 +92,9 @@ def cpu_baseline(pr, n_sample, seed):
 
 def rocprof_average_us(pattern):
     """Average duration (us) of a kernel in this round's committed rocprofv3 --kernel-trace --stats
-    summary of the default bench command (profiles/r03_bench_n4096_kernel_stats.csv), or None."""
+    summary of the default bench command (profiles/r04_bench_n4096_kernel_stats.csv), or None."""
     try:
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_n4096_kernel_stats*.csv")))[-1]
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_n4096_kernel_stats*.csv")))[-1]
         for row in csv.DictReader(open(path)):
             if pattern in row["Name"]:
                 return round(float(row["AverageNs"]) / 1e3, 2)
@@ -90,8 +107,8 @@ def pmc_traffic(key):
     """HBM bytes per launch from this round's separate rocprofv3 --pmc passes (FETCH_SIZE x 2 +
     WRITE_SIZE, MI355X_MICROARCH.md HBM section), or None when the pass is not in profiles/."""
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
-        return round(pj[key]["traffic_bytes_per_launch"]), "profiles/r03_pmc.json:" + key
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+        return round(pj[key]["traffic_bytes_per_launch"]), "profiles/r04_pmc.json:" + key
     except Exception:
         return None, None
 
@@ -134,14 +151,23 @@ def launch_ranks(n_ranks, argv):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    # poll all children: the moment one exits non-zero the others are killed (a rank that died leaves its peers waiting
+    # in a collective until the backend's timeout); only fresh children were started, nothing is re-executed
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:  # one rank failed: do not leave the others waiting in a collective
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
     return rc
 
 
@@ -162,7 +188,12 @@ def main():
                     help="record the per-phase HIP events inside the timed steps (default: in a separate instrumented pass)")
     ap.add_argument("--skip-roofline", action="store_true", help="only the timed steps (clean rocprofv3 kernel statistics)")
     ap.add_argument("--workload", default="closed_scheme", choices=["closed_scheme", "theta_c32xk128", "theta_er7xk72"],
-                    help="instance run in the timed region (the other two are measured after it, rank 0)")
+                    help="instance run in the timed region (the other two are measured after it, rank 0); at --n 8192 the same "
+                         "generators give C_32 [] K_256 and ER(7) [] K_144 (N = 8208)")
+    ap.add_argument("--restarts-per-gpu", type=int, default=1,
+                    help="independent random restarts per step and GPU, run by ONE sdpsr_jordan_reduce_batch call (fibers of one host "
+                         "thread, one stream each); 1 = the headline definition (one reduction at a time)")
+    ap.add_argument("--square-kernel", type=int, default=0, help="sdpsr_opts.square_kernel (0 default, 1 = 128 x 128 tiles, 64 = persistent forced)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -193,7 +224,8 @@ def main():
     dev = torch.device(f"cuda:{local}")
     n = args.n
 
-    def build(name):
+    def build(name, nn=None):
+        n = nn or args.n
         if name == "closed_scheme":
             Ls, d = pr.synthetic_jordan_partition(n, seed=1)
             Cv, A, b = pr.partition_as_sdp(Ls, seed=1)
@@ -203,12 +235,15 @@ def main():
             Cv, A, b, Ls, d = pr.theta_prime_product_problem(pr.cycle_adjacency(32), pr.symmetric_circulant_labels(32), k, seed=1)
             return Workload(pkg, dev, name, f"theta' SDP of C_32 [] K_{k} (C = ones, A = [adjacency; I])", Cv, A, b, Ls, d, [1] * d)
         gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_partitions.npz"))["er7_P"].astype(np.int64)
-        Cv, A, b, Ls, d = pr.theta_prime_product_problem(pr.er_graph_adjacency(7), gold, 72, seed=1)
-        return Workload(pkg, dev, name, "theta' SDP of ER(7) [] K_72, N = 4104, non-commutative", Cv, A, b, Ls, d, [2, 2, 2, 2, 3] * 2)
+        ke = max(1, round(n / 57))  # 72 at n = 4096 (N = 4104), 144 at n = 8192 (N = 8208)
+        Cv, A, b, Ls, d = pr.theta_prime_product_problem(pr.er_graph_adjacency(7), gold, ke, seed=1)
+        return Workload(pkg, dev, name, f"theta' SDP of ER(7) [] K_{ke}, N = {57 * ke}, non-commutative", Cv, A, b, Ls, d, [2, 2, 2, 2, 3] * 2)
 
     mode = {"i8": L.SQUARE_I8, "f32": L.SQUARE_F32, "f64": L.SQUARE_F64}[args.mode]
     opt_flags = args.flags | (L.FLAG_NO_GRAPH if args.no_graph else 0)
-    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode, eig_driver=args.eig_driver, flags=opt_flags, channels=args.channels, insert_wgs_per_cu=args.insert_wgs)
+    ctx = pkg.Context(device=local, seed=1000 + rank, square_mode=mode, eig_driver=args.eig_driver, flags=opt_flags, channels=args.channels, insert_wgs_per_cu=args.insert_wgs,
+                      square_kernel=args.square_kernel)
+    RPG = max(1, args.restarts_per_gpu)
 
     def vp(t):
         return C.c_void_p(t.data_ptr()) if t is not None else None
@@ -218,11 +253,39 @@ def main():
             self.phase = np.zeros(L.T_COUNT)
             self.iters = 0
             self.meets = 0  # agreement steps that needed the hash-meet (ranks ended on different partitions)
+            self.bd_adopted = 0  # steps in which this rank's blockDiagonalize failed and another rank's block sizes were adopted
+            self.bd_all_failed = 0  # steps in which every rank failed and all of them drew again
 
     # test hook: SDPSR_BENCH_FORCE_DISAGREE=1 makes rank 1 report a COARSER partition in the warm-up steps (classes 1
     # and 2 merged, canonically relabelled on the device), so that the MIN/MAX all-reduce and the hash-meet with the
     # device relabel run; the agreed partition must again be the generator's closure (the `check` below)
     force_disagree = bool(os.environ.get("SDPSR_BENCH_FORCE_DISAGREE"))
+    # test hook: SDPSR_BENCH_FORCE_BD_FAIL=r makes rank r report DimensionMismatch for its blockDiagonalize in the
+    # warm-up steps: the winner selection of SURVEY 8(e)(ii) must hand it another rank's block sizes
+    force_bd_fail = int(os.environ.get("SDPSR_BENCH_FORCE_BD_FAIL", "-1"))
+
+    def batch_step(w, cx, R, check=False):
+        """R independent restarts of the reduction in ONE call (sdpsr_jordan_reduce_batch); returns the statuses"""
+        lib = cx._lib
+        if getattr(w, "bP", None) is None or len(w.bP) != R:
+            w.bP = [torch.empty(w.n * w.n, dtype=torch.int32, device=dev) for _ in range(R)]
+            w.bblk = [None] * R
+        pP = (C.c_void_p * R)(*[t.data_ptr() for t in w.bP])
+        pb = (C.c_void_p * R)(*[(t.data_ptr() if t is not None else 0) for t in w.bblk])
+        caps = (C.c_int64 * R)(*[(t.numel() if t is not None else 0) for t in w.bblk])
+        dd, it, nb = (C.c_int64 * R)(), (C.c_int32 * R)(), (C.c_int32 * R)()
+        ssq, ss, st = (C.c_int64 * R)(), (C.c_int64 * R)(), (C.c_int32 * R)()
+        if w.hint:
+            lib.sdpsr_hint_symmetric_basis(cx._h, w.hint)
+        lib.sdpsr_jordan_reduce_batch(cx._h, R, None, w.n, vp(w.tCL), vp(w.tX0), vp(w.tU), w.r, ATOL, ATOL, C.cast(pP, C.c_void_p), dd, it, nb, ssq, ss,
+                                      C.cast(pb, C.c_void_p), caps, st, L.MEM_DEVICE)
+        for i in range(R):
+            if st[i] == 0 and dd[i] * ssq[i] > caps[i]:  # first step (or a changed size): the buffer for the next one
+                w.bblk[i] = torch.empty(max(1, dd[i] * ssq[i]), dtype=torch.float64, device=dev)
+            if check and st[i] == 0:
+                assert dd[i] == w.d and bool((w.bP[i] == w.golden).all()), "partition differs from the generator's closure"
+                assert ssq[i] == sum(x * x for x in w.blocks), (ssq[i], w.blocks)
+        return [int(x) for x in st], sum(int(x) for x in it)
 
     def one_step(w, acc, cx, check=False, collective=True, timers=True):
         lib = cx._lib
@@ -277,15 +340,43 @@ def main():
                 dd.value = int(lab.max().item())
             if check:
                 assert dd.value == w.d and bool((w.tP == w.golden).all()), "partition differs from the generator's closure"
-            ms1 = (C.c_double * L.T_COUNT)()
-            cx.check(lib.sdpsr_block_diagonalize(cx._h, w.n, vp(w.tP), dd.value, ATOL, C.byref(nb), C.byref(ssq), C.byref(ss),
-                                                 tp(ms1), L.MEM_DEVICE))
-            if w.blk is None or w.blk.numel() < dd.value * ssq.value:
-                w.blk = torch.empty(max(1, dd.value * ssq.value), dtype=torch.float64, device=dev)
-            ms2 = (C.c_double * L.T_COUNT)()
-            cx.check(lib.sdpsr_block_images(cx._h, vp(w.blk), None, tp(ms2), L.MEM_DEVICE))
-            for i in range(1, L.T_COUNT):
-                acc.phase[i] += ms1[i] + ms2[i]
+            # blockDiagonalize is randomized; the reference's answer to NumericalInconsistency / DimensionMismatch is "try
+            # again" (src/eigen_decomposition.jl:264-270).  The ranks' tries have run side by side: the lowest rank
+            # whose status is OK wins and broadcasts its block sizes (parallel.agree_block_diagonalization, SURVEY
+            # 8(e)(ii)); a rank that failed adopts them (its images are the winner's to deliver); if all failed, all draw again
+            for attempt in range(5):
+                ms1 = (C.c_double * L.T_COUNT)()
+                st_bd = lib.sdpsr_block_diagonalize(cx._h, w.n, vp(w.tP), dd.value, ATOL, C.byref(nb), C.byref(ssq), C.byref(ss),
+                                                    tp(ms1), L.MEM_DEVICE)
+                if st_bd not in (0, 2, 3):
+                    cx.check(st_bd)
+                if check and force_bd_fail == rank:
+                    st_bd = 3
+                my_sizes = []
+                if st_bd == 0:
+                    sz = np.zeros(nb.value, dtype=np.int32)
+                    cx.check(lib.sdpsr_block_sizes(cx._h, sz.ctypes.data_as(C.c_void_p)))
+                    my_sizes = [int(x) for x in sz]
+                winner, agreed_sizes, _ = pkg.parallel.agree_block_diagonalization(st_bd, my_sizes, device=dev)
+                for i in range(1, L.T_COUNT):
+                    acc.phase[i] += ms1[i]
+                if winner >= 0:
+                    break
+                acc.bd_all_failed += 1
+            else:
+                raise RuntimeError("five consecutive randomized failures on every rank")
+            if st_bd == 0:
+                if w.blk is None or w.blk.numel() < dd.value * ssq.value:
+                    w.blk = torch.empty(max(1, dd.value * ssq.value), dtype=torch.float64, device=dev)
+                ms2 = (C.c_double * L.T_COUNT)()
+                cx.check(lib.sdpsr_block_images(cx._h, vp(w.blk), None, tp(ms2), L.MEM_DEVICE))
+                for i in range(1, L.T_COUNT):
+                    acc.phase[i] += ms2[i]
+            else:
+                acc.bd_adopted += 1
+            if check:
+                assert sorted(agreed_sizes) == w.blocks, (sorted(agreed_sizes), w.blocks)
+            return len(agreed_sizes)
         if check:
             sizes = np.zeros(nb.value, dtype=np.int32)
             cx.check(lib.sdpsr_block_sizes(cx._h, sizes.ctypes.data_as(C.c_void_p)))
@@ -317,16 +408,36 @@ def main():
     # ---- the timed region: K reductions of the headline instance ----
     w0 = build(args.workload)
     acc = Acc()
+
+    def batched_step(w, a, cx, check=False):
+        """RPG restarts per rank in one call; across ranks the restarts' partitions are compared by checksum and the
+        block-diagonalisation winner is agreed as in the one-restart flow"""
+        sts, its = batch_step(w, cx, RPG, check=check)
+        a.iters += its / RPG
+        bad = [s for s in sts if s != 0]
+        if world > 1:
+            ok = pkg.parallel.checksums_agree(pkg.partition_checksum(w.bP[0], ctx=cx), device=dev)
+            assert ok, "restarts on different ranks ended on different partitions"
+            win, _, _ = pkg.parallel.agree_block_diagonalization(0 if len(bad) < RPG else bad[0], w.blocks, device=dev)
+            assert win >= 0
+        return len(bad)
+
     for _ in range(args.warmup):
-        retrying(lambda: one_step(w0, acc, ctx, check=True))
+        if RPG > 1:
+            batched_step(w0, acc, ctx, check=True)
+        else:
+            retrying(lambda: one_step(w0, acc, ctx, check=True))
     acc_warm = acc
     acc = Acc()
     retries = 0
     fence(ctx)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, rt = retrying(lambda: one_step(w0, acc, ctx, timers=args.timers_in_timed_region))
-        retries += rt
+        if RPG > 1:
+            retries += batched_step(w0, acc, ctx)  # a failed restart is counted, the step's other restarts stand
+        else:
+            _, rt = retrying(lambda: one_step(w0, acc, ctx, timers=args.timers_in_timed_region))
+            retries += rt
     fence(ctx)
     dt = time.perf_counter() - t0
     if world > 1:
@@ -334,14 +445,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     acc_timed = acc
-    if not args.timers_in_timed_region:
+    if not args.timers_in_timed_region and RPG == 1:
         # the per-phase HIP events (about thirty records per reduction) stay out of the timed region: the phase
         # split comes from an instrumented pass of the same number of steps right after it
         acc_timed = Acc()
         for _ in range(args.steps):
             retrying(lambda: one_step(w0, acc_timed, ctx))
         acc_timed.iters = acc.iters
-    retrying(lambda: one_step(w0, Acc(), ctx, check=True))  # results still correct after the timed region
+    if RPG > 1:
+        batched_step(w0, Acc(), ctx, check=True)
+    else:
+        retrying(lambda: one_step(w0, Acc(), ctx, check=True))  # results still correct after the timed region
 
     def measure(w, cx, steps):
         """rank 0 only, no collectives: reductions/s of another instance / driver"""
@@ -370,7 +484,7 @@ def main():
                 "iterations_per_reduction": a.iters / steps, "randomized_retries": rts, "phase_ms_per_step": phases(a, steps),
                 "instance": w.note}
 
-    workloads = {args.workload: {"value": round(args.steps * world / dt, 3), "unit": "reductions/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+    workloads = {args.workload: {"value": round(args.steps * world * RPG / dt, 3), "unit": "reductions/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
                                  "steps": args.steps, "N": w0.n, "dim": w0.d, "blocks": f"{len(w0.blocks)} x size {w0.blocks[0]}" if len(set(w0.blocks)) == 1 else w0.blocks,
                                  "iterations_per_reduction": acc_timed.iters / max(1, args.steps), "randomized_retries": retries,
                                  "phase_ms_per_step": phases(acc_timed, args.steps), "instance": w0.note, "timed_region": True}}
@@ -379,7 +493,7 @@ def main():
     kernels = {}
     roof = None
     cpu = None
-    if rank == 0 and not args.skip_roofline and args.eig_driver == 0 and n == 4096:
+    if rank == 0 and not args.skip_roofline and args.eig_driver == 0 and n in (4096, 8192) and RPG == 1:
         for name in ("closed_scheme", "theta_c32xk128", "theta_er7xk72"):
             if name != args.workload:
                 wk = build(name)
@@ -441,6 +555,41 @@ def main():
                     cx.close()
                 del wks
                 torch.cuda.empty_cache()
+
+        if n == 4096:
+            # BASELINE configs[4]: the same generator at N = 8192 end to end (one reduction at a time, this ctx)
+            try:
+                w8 = build("closed_scheme", 8192)
+                variants["n8192_closed_scheme"] = measure(w8, ctx, 5)
+                variants["n8192_closed_scheme"]["note"] = "configs[4] scale: circulant Z_32 (x) K_256 handed over as SDP data, N = 8192; bench.py --n 8192 times all three instances"
+                del w8
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001
+                variants["n8192_closed_scheme"] = {"error": repr(exc)[:200]}
+        # the same WITHOUT host threads: R restarts in one sdpsr_jordan_reduce_batch call on one ctx (fibers of this thread)
+        for R in (2, 4):
+            try:
+                wb = build(args.workload)
+                for _ in range(3):
+                    batch_step(wb, ctx, R, check=True)
+                stepsb = max(10, args.steps)
+                ctx.synchronize()
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                failed = 0
+                for _ in range(stepsb):
+                    sts, _ = batch_step(wb, ctx, R)
+                    failed += sum(1 for x in sts if x != 0)
+                torch.cuda.synchronize()
+                elb = time.perf_counter() - tb
+                batch_step(wb, ctx, R, check=True)
+                variants["batch_%d_restarts_one_call" % R] = {"value": round(R * stepsb / elb, 3), "unit": "reductions/s", "restarts_per_call": R, "calls": stepsb,
+                                                             "randomized_failures": failed,
+                                                             "note": "sdpsr_jordan_reduce_batch: %d restarts per call, one host thread, one ctx; informational" % R}
+                del wb
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001
+                variants["batch_%d_restarts_one_call" % R] = {"error": repr(exc)[:200]}
 
     # ---- roofline leg: per-launch duration of the hot kernels, HIP events on ctx's stream ----
     lib = ctx._lib
@@ -541,23 +690,35 @@ def main():
         # of the symmetric product.  frac = EXECUTED ops / peak (hardware efficiency); the figure
         # judged against the algorithmic 2*N^3 per square is reported beside it.
         ms_tri = prof(0, n, aux=100 + TP)
-        Tt = (n + 127) // 128
-        exec_frac = (Tt + 1) / (2.0 * Tt)
+        # executed multiply-adds of that launch.  Persistent launch (kernels_gemm_sym.hip; chosen by i8_symsquare_pays,
+        # restated here): 256 x 256 macro-tiles of the lower triangle, the diagonal ones only their 36 lower 32 x 32
+        # blocks of 64; else the 128 x 128 tiles of kernels_gemm.hip: (T + 1) / (2 T) of the square
+        mt = (n + 255) // 256
+        jobs = TP * mt * (mt - 1) // 2 + (TP * mt + 1) // 2
+        rounds = -(-jobs // 256)
+        persistent = (4 * jobs >= 3 * 256) and (100 * jobs >= 85 * rounds * 256) and args.square_kernel != 1
+        if persistent or args.square_kernel == 64:
+            exec_frac = (64.0 * mt * (mt - 1) / 2 + 36.0 * mt) / (64.0 * mt * mt) * (256.0 * mt / n) ** 2
+            kname, kpat = "i8_symsquare_kernel (persistent: 256 x 256 macro-tiles of the lower triangle, diagonal tiles two per job)", "i8_symsquare_kernel"
+        else:
+            Tt = (n + 127) // 128
+            exec_frac = (Tt + 1) / (2.0 * Tt)
+            kname, kpat = "gemm_tn_dma_kernel<i8> (128 x 128 lower-triangle tiles)", "gemm_tn_dma_kernel<0,"
         alg_rate = TP * flops / (ms_tri * 1e-3) / 1e12
         tr, src = pmc_traffic(f"i8x{TP}_lower")
         ki8 = kernels["square_i8"]
-        roof = {"kernel": f"gemm_tn_dma_kernel<i8> (random squares: {TP} channels per launch, lower-triangle tiles of the symmetric product)",
+        roof = {"kernel": f"{kname}; random squares: {TP} channels per launch of the symmetric product",
                 "bound": "mfma", "achieved": round(alg_rate * exec_frac, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(alg_rate * exec_frac / I8_MFMA_PEAK_TOPS, 4), "traffic": tr, "traffic_source": src,
                 "ms_per_launch": round(ms_tri, 4), "channels_per_launch": TP, "executed_ops_per_launch": TP * flops * exec_frac,
                 "algorithmic_ops_per_launch": TP * flops, "algorithmic_rate_2N3": round(alg_rate, 2),
                 "algorithmic_frac_2N3": round(alg_rate / I8_MFMA_PEAK_TOPS, 4),
                 "algorithmic_bytes_per_launch": TP * (n * n + 4 * n * n),
-                "rocprof_avg_us": rocprof_average_us("gemm_tn_dma_kernel<0,"),
+                "rocprof_avg_us": rocprof_average_us(kpat),
                 "full_square_kernel": {"ms_per_launch": ki8["ms_per_launch"], "achieved": ki8["achieved"], "frac": ki8["frac"]},
                 "algorithmic": f"2*N^3 int8 multiply-adds (as ops) per channel and square (SURVEY 8d); one launch = {TP} channels (the "
                                f"reference does ONE square per iteration: {TP} channels + one confirm round are this build's redundancy for 8-bit draws); "
-                               "executed = (T+1)/(2T) of that (lower-triangle tiles); algorithmic bytes per launch = channels x "
+                               "executed = the lower-triangle tiles' share of that (see executed_ops_per_launch); algorithmic bytes per launch = channels x "
                                "(N^2 int8 read + N^2 int32 written)"}
         # shader clock while this launch runs (sdpsr_profile_clock: a one-wave sampler on a side
         # stream, clock64 against the 100 MHz wall clock): the int8 squares are power-limited on this
@@ -581,24 +742,44 @@ def main():
             cb = cpu_baseline(pr, cpu_n, seed=1)
             tot = cb["adm_s"] + cb["bd_s"]
             cpu = {"value": round(1.0 / tot, 6), "unit": "reductions/s", "cores": cb["threads"], "kind": "port", "n": cb["n"],
-                   "sample": f"one full oracle reduction (NumPy/SciPy restatement, not Julia) of the headline instance at N={cb['n']}, dim {cb['dim']}: "
+                   "sample": f"ONE full oracle reduction (NumPy/SciPy restatement, not Julia; one sample, no median) of the headline instance at N={cb['n']}, dim {cb['dim']}: "
                              f"admissible_subspace {cb['adm_s']:.2f} s + blockDiagonalize {cb['bd_s']:.2f} s, measured (no extrapolation)"}
-    total_red = args.steps * world
+            # like for like: the CPU leg runs the reference's algorithm (dense eigh on the N x N generic element); the
+            # GPU headline runs module compression, the commutative basis_image shortcut and the verify shortcut --
+            # algorithmic shortcuts the reference does not have.  The GPU number on the reference's own algorithm is
+            # variants.dense_eigensolver.
+            de = variants.get("dense_eigensolver", {}).get("value")
+            cpu["like_for_like"] = {"gpu_dense_eigensolver_over_cpu": round(de * tot, 1) if de else None,
+                                    "gpu_headline_over_cpu": round(args.steps * world * RPG / dt * tot, 1),
+                                    "note": "the headline path uses module compression (a w = dim(P) eigenproblem instead of the reference's dense "
+                                            "N x N eigh); the first ratio compares like with like (eig_driver = 4 against the CPU restatement)"}
+            try:  # the instance that iterates, at a reduced order: the loop side on the CPU
+                ct = cpu_baseline_theta(pr, 1024)
+                cpu["theta_c32xk32_n1024"] = {"value": round(1.0 / (ct["adm_s"] + ct["bd_s"]), 5), "unit": "reductions/s", "n": ct["n"], "dim": ct["dim"],
+                                              "sample": f"one oracle reduction of theta' of C_32 [] K_32 (N = 1024, 5 loop iterations): admissible_subspace "
+                                                        f"{ct['adm_s']:.2f} s + blockDiagonalize {ct['bd_s']:.2f} s"}
+            except Exception as exc:  # noqa: BLE001
+                cpu["theta_c32xk32_n1024"] = {"error": repr(exc)[:200]}
+    total_red = args.steps * world * RPG
     if rank == 0:
         out = {
-            "metric": "N x N SDP reductions/sec (admissible_subspace+blockDiagonalize) at N=4096",
+            "metric": f"N x N SDP reductions/sec (admissible_subspace+blockDiagonalize) at N={n}",
             "value": round(total_red / dt, 4), "unit": "reductions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"i8": "int8 square (int32 acc) + f64 eigen", "f32": "f32 square + f64 eigen", "f64": "f64"}[args.mode],
             "data": "synthetic",
             "config": {"workload": f"configs[3]: synthetic Jordan algebra N={w0.n}, {w0.d} basis matrices, instance '{args.workload}' ({w0.note}), "
-                                   f"square_mode={args.mode}, {args.channels or 2} channels" + ("" if args.channels else " + 1 confirm round"), "N": w0.n, "dim": w0.d, "restarts_per_step": world,
+                                   f"square_mode={args.mode}, {args.channels or 2} channels" + ("" if args.channels else " + 1 confirm round"), "N": w0.n, "dim": w0.d, "restarts_per_step": world * RPG, "restarts_per_gpu": RPG,
                        "iterations_per_reduction": acc_timed.iters / max(1, args.steps)},
             "phase_ms_per_step": phases(acc_timed, args.steps),
             "phase_ms_source": "HIP events inside the timed steps" if args.timers_in_timed_region else
                                "an instrumented pass of the same steps right after the timed region (the timed steps carry no phase events)",
             "partition_meets": {"warmup": meets_warmup, "timed": acc.meets,
                                 "note": "agreement steps in which the ranks' partitions differed and the hash-meet ran (rank 0's count)"},
+            "block_diagonalization_winner": {"adopted_warmup": acc_warm.bd_adopted, "adopted_timed": acc.bd_adopted,
+                                             "all_failed": acc_warm.bd_all_failed + acc.bd_all_failed,
+                                             "note": "multi-rank runs (SURVEY 8(e)(ii)): steps in which this rank's blockDiagonalize failed and it adopted the "
+                                                     "block sizes of the lowest rank that succeeded (rank 0's count) / steps in which every rank failed and all drew again"},
             "workloads": workloads, "roofline": roof, "kernels": kernels, "variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -150,7 +150,8 @@ typedef struct sdpsr_opts {
     int32_t round_mode;         /* sdpsr_round_mode */
     int32_t basis_image_kernel; /* 0 = by shape, 1 = two-stage (class sums per row), 2 = outer products per class,
                                    3 = sorted chunks with partial sums */
-    int32_t refine_path;        /* 0 = by class count, 1 = hash tables only, 2 = radix-sort relabel forced */
+    int32_t refine_path;        /* 0 = by class count (hash tables; beyond 2^18 classes the bucketed grouping), 1 = hash tables
+                                   only, 2 = hipCUB radix-sort relabel forced (comparison), 3 = bucketed grouping forced */
     int32_t label_bits;         /* 0 = no emulation; 8 / 16 / 32: width of the reference's label type T in
                                    Partition{T} (admissible_subspace defaults to UInt16, src/partitions.jl:84):
                                    SDPSR_LABEL_OVERFLOW where the reference throws InexactError (see below) */
@@ -356,6 +357,27 @@ int sdpsr_jordan_reduce(sdpsr_ctx* ctx, int64_t n, const double* CL, const doubl
                         double atol, double epsilon, uint32_t* P_out, int64_t* dim_out, int32_t* iters_out,
                         int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks, int64_t blks_capacity,
                         double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem);
+
+/* R independent random restarts of the same reduction in ONE call on ONE host thread (1 <= R <= 64): restart i runs
+   sdpsr_jordan_reduce with its own random streams (seeds[i]; seeds == NULL: the ctx's own stream for restart 0, derived
+   seeds for the others), its own HIP stream and its own workspace inside ctx.  While one restart's host side waits for a
+   verdict from the device (the reference's loop has one per refinement, src/partitions.jl:154-185), the calling thread
+   submits the other restarts' work: on one MI355X two restarts in flight finish 1.4-1.5 x the reductions per second of
+   one at a time.  These are the "independent random restarts" of the multi-GPU north-star on the per-GPU side, and the
+   reference's own answer to the randomized failures of blockDiagonalize ("try again", src/eigen_decomposition.jl:264-270,
+   src/diagonalize.jl:4-9): the caller takes the first restart whose status[i] is SDPSR_OK.
+     CL, X0L, U      shared by all restarts (same problem), in memory space `mem`;
+     P_out, blks     arrays of R pointers (each as in sdpsr_jordan_reduce; P_out or blks or single entries may be NULL),
+                     blks_capacity[R] in doubles; Q_hat is not delivered here (sdpsr_q_hat of a single-restart call);
+     dim_out .. sum_s  arrays of R entries (iters_out, nblocks, sum_sq, sum_s may be NULL);
+     status[R]       per restart, the status sdpsr_jordan_reduce would have returned.
+   Returns SDPSR_OK if every restart did, else the first restart's failure.  A hint given with
+   sdpsr_hint_symmetric_basis applies to all R restarts.  No threads are created; do not call it from two host threads
+   on one ctx. */
+int sdpsr_jordan_reduce_batch(sdpsr_ctx* ctx, int32_t R, const uint64_t* seeds, int64_t n, const double* CL, const double* X0L,
+                              const double* U, int64_t r, double atol, double epsilon, uint32_t* const* P_out, int64_t* dim_out,
+                              int32_t* iters_out, int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* const* blks,
+                              const int64_t* blks_capacity, int32_t* status, int mem);
 
 /* ---- blockDiagonalize(P; complex = true), src/compat.jl:26-32,46-68 with T = ComplexF64 ---------
    diagonalize(ComplexF64, P) = desymmetrize (src/diagonalize.jl:26-28) + Murota's decomposition

@@ -32,7 +32,7 @@ FLAG_FULL_BASIS_IMAGE = 1 << 10
 FLAG_SYTRD_PANELS = 1 << 12
 FLAG_COUPLING_ON_HOST = 1 << 13
 BASIS_IMAGE_KERNELS = {"auto": 0, "two_stage": 1, "outer": 2, "chunk": 3}
-REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2}
+REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2, "bucket": 3}
 
 STATUS = {
     0: "OK", 1: "INVALID_DECOMPOSITION_FIELD", 2: "NUMERICAL_INCONSISTENCY", 3: "DIMENSION_MISMATCH",
@@ -109,6 +109,8 @@ def load_library():
         "sdpsr_admissible_subspace": (C.c_int, [vp, i64, vp, vp, vp, i64, dbl, vp, pi64, pi32, vp, C.c_int]),
         "sdpsr_admissible_subspace_dense": (C.c_int, [vp, i64, i64, vp, vp, vp, dbl, vp, pi64, pi32, vp, C.c_int]),
         "sdpsr_jordan_reduce": (C.c_int, [vp, i64, vp, vp, vp, i64, dbl, dbl, vp, pi64, pi32, pi32, pi64, pi64, vp, i64, vp, i64, vp, C.c_int]),
+        "sdpsr_jordan_reduce_batch": (C.c_int, [vp, C.c_int32, vp, i64, vp, vp, vp, i64, dbl, dbl, vp, pi64, pi32, pi32, pi64, pi64, vp, vp, pi32,
+                                                C.c_int]),
         "sdpsr_reduce_constraints": (C.c_int, [vp, i64, vp, i64, i64, vp, vp, C.c_int]),
         "sdpsr_desymmetrize": (C.c_int, [vp, i64, vp, pi64, pi32, C.c_int]),
         "sdpsr_block_diagonalize": (C.c_int, [vp, i64, vp, i64, dbl, pi32, pi64, pi64, vp, C.c_int]),

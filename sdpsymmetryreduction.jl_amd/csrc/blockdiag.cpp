@@ -85,7 +85,7 @@ int block_diagonalize_impl(sdpsr_ctx* c, int64_t n, const uint32_t* P, int64_t d
         for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = tm.acc[i];
         phase_ms[SDPSR_T_TOTAL] = ms;
     } else if (final_sync) {
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, ctx_sync_stream(c, s));
     }
     if (final_dim != d) {
         std::string szs;
@@ -127,7 +127,7 @@ int sdpsr_q_hat(sdpsr_ctx* c, double* Q_hat, int mem) {
     if (!Qhat) return SDPSR_OUT_OF_MEMORY;
     HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, cnt * 8, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                               c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync_stream(c, c->stream));
     return SDPSR_OK;
 }
 
@@ -161,7 +161,7 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
         if (!ws || !bflag || !hv) return SDPSR_OUT_OF_MEMORY;
         (void)bflag;
         if (launch_basis_image_commutative(s, n, d, S1, L, Qrm, next_key(c), atol, 2e-10, ws, out, hv)) {  // verdict stored into pinned host memory
-            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, ctx_sync_stream(c, s));
             HIP_TRY(c, hipGetLastError());
             done = hv[0] == 0;
             if (!done && dbg_on()) fprintf(stderr, "[sdpsr] basis_image: invariance check failed, projection formula instead\n");
@@ -277,7 +277,7 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     }
     }
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(s));  // host vectors above must outlive the copies
+    HIP_TRY(c, ctx_sync_stream(c, s));  // host vectors above must outlive the copies
     st = out_finish(c, blks, out, (size_t)d * S, mem);
     if (st) return st;
     if (Q_hat) {
@@ -285,7 +285,7 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
             HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, hipMemcpyDeviceToDevice, s));
         else
             HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, ctx_sync_stream(c, s));
     }
     if (phase_ms) {
         const float ms = ev_total.stop(s);

@@ -251,7 +251,7 @@ int sdpsr_block_diagonalize_complex(sdpsr_ctx* c, int64_t n, const uint32_t* P, 
     else launch_cx_irreducible_general(s, n, Hr, Hi, Vr, Vi, ddesc, (int)S1, atol, Qhat);
     HIP_TRY(c, hipGetLastError());
     if (P_desym) HIP_TRY(c, hipMemcpyAsync(P_desym, L, len * 4, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, ctx_sync_stream(c, s));
     c->bdc_n = n;
     c->bdc_d = dd;
     c->bdc_sizes = sizes;
@@ -329,7 +329,7 @@ int sdpsr_block_images_complex(sdpsr_ctx* c, double* blks, double* Q_hat, int me
     if (st) return st;
     if (Q_hat) {
         HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)2 * n * S1 * 8, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, ctx_sync_stream(c, s));
     }
     return SDPSR_OK;
 }

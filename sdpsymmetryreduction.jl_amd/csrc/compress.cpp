@@ -163,7 +163,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         if (abs_err) return -1;
         hG.resize((size_t)ap * mp);
         if (host_filled) {
-            if (hipStreamSynchronize(s) != hipSuccess) {
+            if (ctx_sync_stream(c, s) != hipSuccess) {
                 abs_err = ctx_fail(c, SDPSR_HIP_ERROR, "hipStreamSynchronize (module growth)");
                 return -1;
             }
@@ -351,7 +351,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             return SDPSR_OK;
         };
         auto fetch = [&](double* dst) -> int {  // waits for the enqueued element, symmetrised like _symmetrize!
-            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, ctx_sync_stream(c, s));
             for (int j = 0; j < w; ++j)
                 for (int i = 0; i < w; ++i) dst[(size_t)i + (size_t)j * w] = 0.5 * (pin[(size_t)i + (size_t)j * w] + pin[(size_t)j + (size_t)i * w]);
             return SDPSR_OK;
@@ -377,7 +377,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         };
         std::vector<double> Qs;
         int st = murota_small_host(c, w, B1.data(), next_element, atol, d, sizes, S1, S, Qs);
-        if (pending) hipStreamSynchronize(s);  // never leave a copy into the pinned buffer in flight
+        if (pending) ctx_sync_stream(c, s);  // never leave a copy into the pinned buffer in flight
         tm.end();
         if (st) {
             tm.collect();
@@ -445,7 +445,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         c->main_shadow = nullptr;
         s = main_stream;
         if (e2 || !rec) {
-            hipStreamSynchronize(c->side_stream);
+            ctx_sync_stream(c, c->side_stream);
             return e2 ? e2 : SDPSR_HIP_ERROR;
         }
         return SDPSR_OK;
@@ -469,7 +469,7 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     launch_tall_times_small(s, n, ld, W, w, qs, w, (int)S1, 1.0, 0.0, Qhat, n);
     launch_clamptol(s, n * S1, Qhat, atol);
     tm.end();
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, ctx_sync_stream(c, s));
     HIP_TRY(c, hipGetLastError());
     dbg_mark(c, "compressed: lifted");
     return SDPSR_OK;

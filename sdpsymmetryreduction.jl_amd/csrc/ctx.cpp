@@ -26,7 +26,7 @@ void* ctx_buf(sdpsr_ctx* c, const char* name, size_t bytes) {
     DevBuf& b = c->bufs[name];
     if (b.bytes >= bytes) return b.p;
     if (b.p) {
-        hipStreamSynchronize(c->stream);
+        ctx_sync_stream(c, c->stream);
         hipFree(b.p);
         b.p = nullptr;
         b.bytes = 0;
@@ -52,7 +52,7 @@ namespace sdpsr {
 // to or from pageable memory costs milliseconds of host time on this stack.
 void* ctx_pinned(sdpsr_ctx* c, size_t bytes) {  // shared with eigen.cpp
     if (c->pinned_bytes >= bytes) return c->pinned;
-    hipStreamSynchronize(c->stream);
+    ctx_sync_stream(c, c->stream);
     if (c->pinned) hipHostFree(c->pinned);
     c->pinned = nullptr;
     c->pinned_bytes = 0;
@@ -95,7 +95,7 @@ int d2h_sync(sdpsr_ctx* c, void* host, const void* dev, size_t bytes) {
     void* p = ctx_pinned(c, bytes);
     if (!p) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
     HIP_TRY(c, hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync_stream(c, c->stream));
     memcpy(host, p, bytes);
     return SDPSR_OK;
 }
@@ -111,9 +111,9 @@ int h2d_sync(sdpsr_ctx* c, void* dev, const void* host, size_t bytes) {
             return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned upload ring");
         }
         if (c->h2d_ring_next == H2D_SLOTS) {  // every stream that may still read a slot
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (c->side_stream && c->side_stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->side_stream));
-            if (c->main_shadow && c->main_shadow != c->stream) HIP_TRY(c, hipStreamSynchronize(c->main_shadow));
+            HIP_TRY(c, ctx_sync_stream(c, c->stream));
+            if (c->side_stream && c->side_stream != c->stream) HIP_TRY(c, ctx_sync_stream(c, c->side_stream));
+            if (c->main_shadow && c->main_shadow != c->stream) HIP_TRY(c, ctx_sync_stream(c, c->main_shadow));
             c->h2d_ring_next = 0;
         }
         void* slot = (char*)c->h2d_ring + (size_t)c->h2d_ring_next++ * H2D_SLOT;
@@ -125,7 +125,7 @@ int h2d_sync(sdpsr_ctx* c, void* dev, const void* host, size_t bytes) {
     if (!p) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
     memcpy(p, host, bytes);
     HIP_TRY(c, hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync_stream(c, c->stream));
     return SDPSR_OK;
 }
 // carries the rounding rule into the kernels (sdpsr_hash.h: negative = truncate like the reference)
@@ -223,6 +223,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
     // per-device kernel attributes (dynamic LDS above 64 KiB); cheap and idempotent
     gemm_set_device_attributes();
     gemm_sym_set_device_attributes();
+    refine_bucket_set_device_attributes();
     blockdiag_set_device_attributes();
     module_set_device_attributes();
     partition_set_device_attributes();
@@ -250,8 +251,10 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
 
 void sdpsr_destroy(sdpsr_ctx* c) {
     if (!c) return;
+    for (sdpsr_ctx* ch : c->batch_children) sdpsr_destroy(ch);
+    c->batch_children.clear();
     DeviceGuard dg(c->device);
-    hipStreamSynchronize(c->stream);
+    ctx_sync_stream(c, c->stream);
     destroy_handle(c);
     sytrd_graph_cache_destroy(c->sytrd_graphs);
     for (auto& kv : c->bufs)
@@ -273,7 +276,7 @@ const char* sdpsr_last_error(const sdpsr_ctx* c) { return c ? c->err.c_str() : "
 
 int sdpsr_set_stream(sdpsr_ctx* c, void* hip_stream) {
     CHECK_CTX(c);
-    hipStreamSynchronize(c->stream);
+    ctx_sync_stream(c, c->stream);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
@@ -287,7 +290,7 @@ int sdpsr_set_stream(sdpsr_ctx* c, void* hip_stream) {
 
 int sdpsr_synchronize(sdpsr_ctx* c) {
     CHECK_CTX(c);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync_stream(c, c->stream));
     return SDPSR_OK;
 }
 

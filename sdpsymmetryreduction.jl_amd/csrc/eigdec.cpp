@@ -185,7 +185,7 @@ int isomorphism_classes_device(sdpsr_ctx* c, unsigned long long* dnorms, int nei
     const unsigned long long* hb = (const unsigned long long*)ctx_pinned(c, (size_t)neig * W * 8);
     if (!hb) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
     HIP_TRY(c, hipMemcpyAsync((void*)hb, dbits, (size_t)neig * W * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, ctx_sync_stream(c, s));
     DisjointSets K(neig);
     for (int i = 0; i < neig; ++i) {
         const unsigned long long* row = hb + (size_t)i * W;
@@ -252,7 +252,7 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
         else launch_check_symmetric(s, n, L, flag);
         uint32_t* hflag = (uint32_t*)c->pinned;
         HIP_TRY(c, hipMemcpyAsync(hflag, fsrc, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, ctx_sync_stream(c, s));
         if (pre ? hflag[0] == c->bd_sym_epoch : hflag[0] != 0) return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
                                       "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");
     }
@@ -306,7 +306,7 @@ int eigen_decomposition_device(sdpsr_ctx* c, int64_t n, const uint32_t* L, doubl
         launch_small_cluster_qtaq_block_norms(s, n, ld, Ap, Q, w, atol, dinfo, dpack, Tp);
         tm.end();
         HIP_TRY(c, hipMemcpyAsync(hp, dpack, pack_bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, ctx_sync_stream(c, s));
         tm.collect();
         const int hinfo = ((const int*)hp)[0];
         if (dbg_on()) fprintf(stderr, "[sdpsr] small syev n=%lld: %d sweeps\n", (long long)n, ((const int*)hp)[1]);
@@ -660,7 +660,7 @@ int sdpsr_eigen_decomposition_batched(sdpsr_ctx* c, int64_t n, const uint32_t* P
         if (!hp) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
         HIP_TRY(c, hipMemcpyAsync(hp, flag, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(hp + 16, dout, (size_t)count * 3 * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, ctx_sync_stream(c, s));
         if (hp[0])
             return ctx_fail(c, SDPSR_INVALID_DECOMPOSITION_FIELD,
                             "partition is not symmetric: decomposition over Float64 requested but the generic element has a complex spectrum");

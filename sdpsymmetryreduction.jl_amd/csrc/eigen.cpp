@@ -159,7 +159,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             sdpsr_ctx* c;
             bool armed;
             ~SideGuard() {
-                if (armed && c->side_stream) hipStreamSynchronize(c->side_stream);
+                if (armed && c->side_stream) ctx_sync_stream(c, c->side_stream);
             }
         } side_guard{c, false};
         if (!own) {
@@ -171,7 +171,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             double* ws = (double*)ctx_buf(c, "eig_sytrd_ws", sytrd_workspace_doubles(n, lda) * sizeof(double));
             if (!ws) return SDPSR_OUT_OF_MEMORY;
             launch_sytrd(c, n, A, lda, w, E, tau, ws);
-            if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: tridiagonalisation done"); }
+            if (dbg_on()) { ctx_sync_stream(c, c->stream); dbg_mark(c, "syev: tridiagonalisation done"); }
             if (hipGetLastError() != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "sytrd launch failed");
             // first half of the back-transformation on the side stream, beside the tridiagonal solver
             const bool side_ok = ctx_ensure_side(c);
@@ -185,7 +185,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
                 c->stream = main_stream;
                 c->main_shadow = nullptr;
                 if (pst || !rec) {
-                    hipStreamSynchronize(c->side_stream);
+                    ctx_sync_stream(c, c->side_stream);
                     return pst ? pst : ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation: event record failed");
                 }
                 bt_forked = true;
@@ -221,7 +221,7 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)ldz, info);
         if (rs != rocblas_status_success)
             return ctx_fail(c, SDPSR_SOLVER_ERROR, "rocsolver tridiagonal solver status " + std::to_string(rs));
-        if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: tridiagonalisation + tridiagonal solver done"); }
+        if (dbg_on()) { ctx_sync_stream(c, c->stream); dbg_mark(c, "syev: tridiagonalisation + tridiagonal solver done"); }
         if (own) {
             if (bt_forked) {
                 if (hipStreamWaitEvent(c->stream, c->ev_bt_join, 0) != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "back-transformation: join failed");
@@ -243,14 +243,14 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
                              hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             return ctx_fail(c, SDPSR_HIP_ERROR, "copy of eigenvectors failed");
     }
-    if (dbg_on()) { hipStreamSynchronize(c->stream); dbg_mark(c, "syev: back-transformation done"); }
+    if (dbg_on()) { ctx_sync_stream(c, c->stream); dbg_mark(c, "syev: back-transformation done"); }
     if (after_launch) (*after_launch)();  // everything of the eigensolver is enqueued; the caller overlaps its own launches here
     if (defer_readback) return SDPSR_OK;  // the caller reads "eig_info" (status, sweeps) and w with its own next read-back
     // read-back through the pinned scratch of the ctx (a pageable 4-byte copy costs tens of us)
     rocblas_int* hpin = (rocblas_int*)ctx_pinned(c, 64 + (host_w ? (size_t)n * sizeof(double) : 0));
     if (!hpin || hipMemcpyAsync(hpin, info, 2 * sizeof(rocblas_int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         (host_w && hipMemcpyAsync((char*)hpin + 64, w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
+        ctx_sync_stream(c, c->stream) != hipSuccess)
         return ctx_fail(c, SDPSR_HIP_ERROR, "eigensolver info read-back failed");
     if (host_w) memcpy(host_w, (char*)hpin + 64, (size_t)n * sizeof(double));
     const rocblas_int hinfo = hpin[0];

@@ -58,7 +58,7 @@ int out_finish(sdpsr_ctx* c, T* host, const T* dev, size_t count, int mem) {
     // outputs are complete on return in both memory spaces (ordering rule of sdpsr.h)
     if (mem != SDPSR_MEM_DEVICE)
         HIP_TRY(c, hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync_stream(c, c->stream));
     return SDPSR_OK;
 }
 

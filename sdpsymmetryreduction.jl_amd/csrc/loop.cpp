@@ -123,7 +123,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
     }
     tm.end();
     if (st) return st;
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, ctx_sync_stream(c, s));
     tm.collect();
     c->adm_dims.assign(1, d);
     if (label_overflows(c, (uint64_t)d)) return label_overflow_fail(c, "admissible_subspace: dim(S)", (uint64_t)d);
@@ -209,7 +209,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                     if (!vflag || !vref || !first || !hv) return SDPSR_OUT_OF_MEMORY;
                     (void)vflag;
                     if (launch_verify_no_split(s, qv, current, first, vref, hv)) {  // the verdict is stored straight into pinned host memory
-                        HIP_TRY(c, hipStreamSynchronize(s));
+                        HIP_TRY(c, ctx_sync_stream(c, s));
                         HIP_TRY(c, hipGetLastError());
                         unchanged = hv[0] == 0;
                     }

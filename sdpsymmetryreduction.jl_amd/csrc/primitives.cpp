@@ -51,28 +51,35 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
     // that large means one global atomic per entry into memory no cache holds; the radix-sort
     // relabel (kernels_refine_sort.hip) moves ~15x the algorithmic bytes but streams.  Taken when
     // the previous refinement ended above 2^18 classes, or when a table of 2^20 slots overflows.
-    const bool sort_ok = len >= (int64_t(1) << 18) && len < (int64_t(1) << 31) && c->opts.refine_path != 1;
-    bool use_sort = sort_ok && (c->table_log2_hint >= 21 || c->opts.refine_path == 2);
+    // refine_path 2 / 3 force the hipCUB sort / the bucketed grouping at any size (comparison, tests)
+    const bool forced_relabel = c->opts.refine_path == 2 || c->opts.refine_path == 3;
+    const bool sort_ok = ((len >= (int64_t(1) << 18) && c->opts.refine_path != 1) || forced_relabel) && len < (int64_t(1) << 31);
+    bool use_sort = sort_ok && (c->table_log2_hint >= 21 || forced_relabel);
     for (;;) {
         if (use_sort) {
-            const size_t wsb = refine_sorted_workspace_bytes(len);
+            // the hand-written bucketed grouping (kernels_refine_bucket.hip); hipCUB's radix sort behind refine_path = 2
+            const bool cub = c->opts.refine_path == 2;
+            const size_t wsb = cub ? refine_sorted_workspace_bytes(len) : refine_bucketed_workspace_bytes(len);
             void* wsp = ctx_buf(c, "ref_sort_ws", wsb);
             uint32_t* counters = (uint32_t*)ctx_buf(c, "ref_counters", refine_counters_bytes());
+            uint32_t* firsts = (uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
             uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
-            if (!wsp || !counters || !h) return SDPSR_OUT_OF_MEMORY;
+            if (!wsp || !counters || !firsts || !h) return SDPSR_OUT_OF_MEMORY;
             if (!materialize()) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "refine: signature source needs scratch");
-            if (!launch_refine_sorted(c->stream, len, src.sig, labels, wsp, wsb, counters))
-                return ctx_fail(c, SDPSR_HIP_ERROR, "sort-based refinement failed");
+            if (cub ? !launch_refine_sorted(c->stream, len, src.sig, labels, wsp, wsb, counters)
+                    : !launch_refine_bucketed(c->stream, len, src.sig, labels, wsp, wsb, counters, firsts, refine_first_cap()))
+                return ctx_fail(c, SDPSR_HIP_ERROR, "sorted / bucketed refinement failed");
             HIP_TRY(c, hipMemcpyAsync(h, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             if (sym_n > 0 && symflag_dev) {
                 launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);
                 HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             }
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, ctx_sync_stream(c, c->stream));
             if (sym_n > 0 && symflag_dev && sym_out) *sym_out = h[8] ? 0 : 1;
             HIP_TRY(c, hipGetLastError());
             *nparts = h[2];
             c->table_log2_hint = std::min(full, std::max(12, ceil_log2((uint64_t)h[2] * 8 + 1)));
+            if (!cub && h[2] <= refine_first_cap()) c->first_idx_labels = labels;  // "ref_first" describes these labels
             return SDPSR_OK;
         }
         const size_t cap = size_t(1) << log2cap;
@@ -100,7 +107,7 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
             launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);  // flag = 1 if NOT symmetric
             HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, ctx_sync_stream(c, c->stream));
         if (sym_fused) h[8] = h[3];
         if (sym_n > 0 && (symflag_dev || sym_fused) && sym_out) *sym_out = h[8] ? 0 : 1;
         HIP_TRY(c, hipGetLastError());

@@ -53,7 +53,17 @@ extern "C" int sdpsr_jordan_reduce(sdpsr_ctx* c, int64_t n, const double* CL, co
     }
     if (in_place) {
         // the caller's buffer stops serving phase 2 when this call returns: a later sdpsr_block_images (images not
-        // delivered here) finds the labels in the ctx buffer
+        // delivered here) finds the labels in the ctx buffer.  On every path out of this block the ctx forgets the
+        // caller's pointer; a failed hand-over also drops the pending phase 2 (it would read a buffer the caller owns).
+        struct Forget {
+            sdpsr_ctx* c;
+            bool ok = false;
+            ~Forget() {
+                c->bd_labels_ext = nullptr;
+                c->bd_trusted_symmetric = nullptr;
+                if (!ok) c->bd_valid = false;
+            }
+        } forget{c};
         if (!images_done && c->bd_valid) {
             uint32_t* keep = (uint32_t*)ctx_buf(c, "bd_labels", (size_t)len * 4);
             if (!keep) return SDPSR_OUT_OF_MEMORY;
@@ -61,11 +71,10 @@ extern "C" int sdpsr_jordan_reduce(sdpsr_ctx* c, int64_t n, const double* CL, co
         } else if (images_done) {
             c->bd_valid = false;  // nothing left for a second sdpsr_block_images to work on (sizes and Q_hat stay available)
         }
-        c->bd_labels_ext = nullptr;
-        c->bd_trusted_symmetric = nullptr;
+        forget.ok = true;
     }
     {
-        const hipError_t e = hipStreamSynchronize(s);
+        const hipError_t e = ctx_sync_stream(c, s);
         if (e != hipSuccess && st == SDPSR_OK) st = ctx_fail(c, SDPSR_HIP_ERROR, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     }
     if (phase_ms) {

@@ -69,7 +69,22 @@ struct sdpsr_ctx {
     // hash table capacity hint (log2) for the next refine
     int table_log2_hint = 12;
     hipEvent_t ev[2 * SDPSR_T_COUNT] = {};
+    // sdpsr_jordan_reduce_batch: this ctx runs one restart on a fiber of the calling thread; a host wait for one of its
+    // streams polls and hands the thread to the other restarts (ctx_sync_stream).  nullptr outside a batch call.
+    void (*yield_fn)(void*) = nullptr;
+    void* yield_arg = nullptr;
+    std::vector<sdpsr_ctx*> batch_children;  // the ctxs of restarts 1 .. R - 1 (created on demand, destroyed with this ctx)
 };
+
+// Host wait for a stream of ctx c (every wait of the library goes through here).
+inline hipError_t ctx_sync_stream(sdpsr_ctx* c, hipStream_t s) {
+    if (!c || !c->yield_fn) return hipStreamSynchronize(s);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        c->yield_fn(c->yield_arg);
+    }
+}
 
 void* ctx_buf(sdpsr_ctx* c, const char* name, size_t bytes);  // throws std::bad_alloc-like via status
 int ctx_fail(sdpsr_ctx* c, int status, const std::string& msg);
@@ -190,6 +205,10 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
                    const RefineWs& ws, int64_t sym_n = 0);
 
 // kernels_refine_sort.hip: radix-sort relabel for the many-classes regime
+size_t refine_bucketed_workspace_bytes(int64_t len);
+void refine_bucket_set_device_attributes();
+bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
+                            uint32_t* counters, uint32_t* first_idx, uint32_t first_cap);
 size_t refine_sorted_workspace_bytes(int64_t len);
 bool launch_refine_sorted(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
                           uint32_t* counters);

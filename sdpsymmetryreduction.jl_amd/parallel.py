@@ -84,6 +84,40 @@ def agree_partition(labels, relabel, group=None, checksum=None):
     return False, new_labels
 
 
+def agree_block_diagonalization(status, blk_sizes, q_hat=None, group=None, device=None):
+    """``blockDiagonalize`` is randomized and the reference's answer to ``NumericalInconsistency`` /
+    ``DimensionMismatch`` is "try again" (src/eigen_decomposition.jl:264-270, src/diagonalize.jl:4-9).  With one restart
+    per rank the tries have already run side by side: a one-integer MIN all-reduce picks the LOWEST rank whose status is
+    0, and that rank broadcasts its ``blkSizes`` (and, if given, its ``Q_hat`` tensor, which must have the same shape on
+    every rank once the sizes are known -- pass ``q_hat`` as a callable ``sizes -> tensor`` to allocate it late).
+    Returns (winner_rank, blk_sizes, q_hat); winner_rank = -1 when every rank failed (the caller retries with fresh
+    draws).  ``status``: this rank's sdpsr status (0 = ok); ``blk_sizes``: this rank's sizes (ignored unless it wins)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if device is not None and torch.device(device).type != "cpu" and dist.get_backend(group) == "gloo":
+        device = None
+    pick = torch.tensor([rank if int(status) == 0 else world], dtype=torch.int64, device=device)
+    dist.all_reduce(pick, op=dist.ReduceOp.MIN, group=group)
+    winner = int(pick.item())
+    if winner >= world:
+        return -1, None, None
+    src = dist.get_global_rank(group, winner) if group is not None else winner
+    cnt = torch.tensor([len(blk_sizes) if rank == winner else 0], dtype=torch.int64, device=device)
+    dist.broadcast(cnt, src=src, group=group)
+    sizes = torch.zeros(int(cnt.item()), dtype=torch.int64, device=device)
+    if rank == winner:
+        sizes.copy_(torch.as_tensor([int(x) for x in blk_sizes], dtype=torch.int64))
+    dist.broadcast(sizes, src=src, group=group)
+    out_sizes = [int(x) for x in sizes.cpu().tolist()]
+    q = None
+    if q_hat is not None:
+        q = q_hat(out_sizes) if callable(q_hat) else q_hat
+        dist.broadcast(q, src=src, group=group)
+    return winner, out_sizes, q
+
+
 def relabel_numpy(sig):
     """CPU canonical relabel used by the gloo tests (first occurrence order, 0 stays 0)."""
     import torch

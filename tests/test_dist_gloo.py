@@ -52,6 +52,17 @@ def _worker(rank, world, port, q):
     _, meet2 = par.agree_partition(z, par.relabel_numpy)
     res["zero_kept"] = bool((meet2[:7] == 0).all()) and bool((meet2[7:] != 0).all())
     res["seeds_differ"] = par.restart_seed(5, 0) != par.restart_seed(5, 1)
+    # 4) SURVEY 8(e)(ii): blockDiagonalize failed on rank 0 (DimensionMismatch = 3), rank 1 succeeded: the lowest rank
+    #    with status 0 wins, its block sizes and Q_hat are broadcast
+    sizes = [2, 2, 2, 2, 3] if rank == 1 else [1, 1]
+    qmine = torch.full((6, 11), float(rank + 1), dtype=torch.float64)
+    win, got_sizes, qh = par.agree_block_diagonalization(3 if rank == 0 else 0, sizes, q_hat=lambda sz: qmine if rank == 1 else torch.zeros(6, sum(sz), dtype=torch.float64))
+    res["winner_is_rank1"] = win == 1 and got_sizes == [2, 2, 2, 2, 3] and bool((qh == 2.0).all())
+    # both succeed: rank 0 wins; both fail: -1, the caller retries
+    win0, s0, _ = par.agree_block_diagonalization(0, [5 + rank], group=None)
+    res["lowest_rank_wins"] = win0 == 0 and s0 == [5]
+    winx, sx, _ = par.agree_block_diagonalization(2, [1])
+    res["all_failed"] = winx == -1 and sx is None
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()

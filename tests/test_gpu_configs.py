@@ -375,6 +375,33 @@ def test_bench_forced_disagreement_reaches_the_hash_meet():
 
 
 @pytest.mark.gpu
+def test_bench_forced_block_diagonalize_failure_adopts_the_winner():
+    """rank 0 reports DimensionMismatch for its blockDiagonalize in the warm-up steps; the one-integer
+    MIN all-reduce must pick rank 1, whose block sizes are broadcast and adopted (bench.py asserts them against the
+    instance's pinned sizes on both ranks); the timed steps, where nobody fails, have rank 0 as the winner."""
+    js = _run_bench({"SDPSR_BENCH_FORCE_BD_FAIL": "0"}, "--workload", "theta_c32xk128")
+    assert js["n_gpus"] == 2 and js["value"] > 0
+    w = js["block_diagonalization_winner"]
+    assert w["adopted_warmup"] == 2 and w["adopted_timed"] == 0 and w["all_failed"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_restarts_per_gpu_batches_in_one_call():
+    """--restarts-per-gpu 2: every step is ONE sdpsr_jordan_reduce_batch call of two restarts (fibers of one host thread);
+    bench.py checks every restart's partition against the generator's closure in the warm-up steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--skip-roofline", "--n", "1024",
+                          "--restarts-per-gpu", "2"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    js = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert js["n_gpus"] == 1 and js["config"]["restarts_per_step"] == 2 and js["config"]["restarts_per_gpu"] == 2 and js["value"] > 0
+
+
+@pytest.mark.gpu
 def test_rccl_backend_runs_the_agreement_collectives_single_rank():
     """gpurun exposes one GPU, so RCCL cannot be run with two ranks here (it refuses two ranks on one device; the two-rank
     flow is tested over gloo above).  What CAN be shown on this box is that the `nccl` (= RCCL) branch of the agreement

@@ -790,32 +790,46 @@ def test_device_inputs_from_an_async_torch_kernel(pkg, problems, golden):
 
 
 def test_sort_based_refine_matches_oracle(pkg, oracle):
-    """Radix-sort relabel (many-classes regime, kernels_refine_sort.hip) against the oracle's
-    canonical labels: forced on inputs with few, many and all-distinct classes, a zero class,
-    and through refine! (pairs of labels)."""
-    import os
+    """The relabels of the many-classes regime -- the hand-written bucketed grouping (kernels_refine_bucket.hip, the
+    default there) and hipCUB's radix sort (kernels_refine_sort.hip, comparison) -- against the oracle's canonical
+    labels: forced on inputs with few, many and all-distinct classes, a zero class, skewed class sizes (one class
+    holding half of the entries: a bucket far beyond the resolver's table), and through refine! (pairs of labels)."""
     rng = np.random.default_rng(21)
-    n = 640  # n^2 >= 2^18: the sorted path is eligible
+    n = 640  # n^2 >= 2^18: the relabel path is eligible
     cases = {
         "few": rng.integers(0, 7, size=(n, n)).astype(np.float64) * 0.25,
         "many": rng.integers(0, 150000, size=(n, n)).astype(np.float64),
         "distinct": rng.permutation(n * n).reshape(n, n).astype(np.float64) + 1.0,
+        "skewed": np.where(rng.random((n, n)) < 0.5, 7.0, rng.integers(1, 200000, size=(n, n)).astype(np.float64)),
     }
     cases["many"][rng.random((n, n)) < 0.1] = 0.0
-    for forced in (True, False):
-        with pkg.Context(seed=2, refine_path="sort" if forced else "auto") as ctx:  # sdpsr_opts.refine_path
+    for path in ("bucket", "sort", "auto"):
+        with pkg.Context(seed=2, refine_path=path) as ctx:  # sdpsr_opts.refine_path
             for name, M in cases.items():
                 P = pkg.Partition.from_matrix(M, ctx=ctx)
                 R = oracle.partition_from_values(M)
-                assert P.nparts == R.nparts, (name, forced)
-                assert np.array_equal(P.matrix, R.matrix), (name, forced)
+                assert P.nparts == R.nparts, (name, path)
+                assert np.array_equal(P.matrix, R.matrix), (name, path)
             A = rng.integers(0, 900, size=(n, n))
             B = rng.integers(0, 900, size=(n, n))
             P1 = pkg.Partition.from_matrix(A, ctx=ctx)
             P2 = pkg.Partition.from_matrix(B, ctx=ctx)
             R = oracle.refine(oracle.partition_from_labels(A), oracle.partition_from_labels(B))
             P3 = pkg.refine(P1, P2, ctx=ctx)
-            assert P3.nparts == R.nparts and np.array_equal(P3.matrix, R.matrix), forced
+            assert P3.nparts == R.nparts and np.array_equal(P3.matrix, R.matrix), path
+
+
+@pytest.mark.parametrize("n", [37, 300, 1500])
+def test_bucketed_refine_small_and_ragged_sizes(pkg, oracle, n):
+    """The bucketed grouping forced at sizes below its regime (one chunk, 16 buckets) and at a ragged size whose last
+    chunk and last rank block are partial; all-zero and all-equal inputs."""
+    rng = np.random.default_rng(n)
+    with pkg.Context(seed=4, refine_path="bucket") as ctx:
+        for M in (rng.integers(0, 5, size=(n, n)).astype(np.float64), rng.integers(0, n * n // 3, size=(n, n)).astype(np.float64),
+                  np.zeros((n, n)), np.full((n, n), 3.5)):
+            P = pkg.Partition.from_matrix(M, ctx=ctx)
+            R = oracle.partition_from_values(M)
+            assert P.nparts == R.nparts and np.array_equal(P.matrix, R.matrix), n
 
 
 # ------------------------------------------------ complex path (src/compat.jl:26-32,54-57)
@@ -1288,6 +1302,57 @@ def test_jordan_reduce_equals_the_three_calls(pkg, problems, oracle, golden, nam
             for i in range(d):
                 for k in range(len(sizes)):
                     assert np.allclose(blks[i, offs[k]:offs[k + 1]].reshape(sizes[k], sizes[k], order="F"), ref[i][k], atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["er7", "circ256"])
+def test_jordan_reduce_batch_equals_single_calls(pkg, problems, golden, name):
+    """sdpsr_jordan_reduce_batch (R restarts on fibers of one host thread, one ctx): every restart returns what a single
+    sdpsr_jordan_reduce returns -- the golden partition bit for bit, the pinned block sizes, the same iteration count --
+    and, restart by restart with the same seed, the same block images as a single call on a fresh ctx with that seed
+    (columns compared as a set: the order of the blocks follows the random generic element)."""
+    if name == "circ256":
+        Lg = golden["circ256_P"].astype(np.int64)
+        Cv, A, b = problems.partition_as_sdp(Lg, seed=1)
+    else:
+        Lg = golden[f"{name}_P"].astype(np.int64)
+        Cv, A, b = _problem(problems, name)
+    expect = list(golden[f"{name}_blk"])
+    setup = pkg.admissible_setup(Cv, A, b)
+    d = int(Lg.max())
+    S = sum(int(x) ** 2 for x in expect)
+
+    def colset(M):
+        M = np.round(np.asarray(M), 7)
+        return M[:, np.lexsort(M[::-1])]
+
+    with pkg.Context(seed=5) as ctx:
+        for R in (1, 2, 3):
+            for attempt in range(4):  # blockDiagonalize is randomized ("try again"): fresh seeds per attempt
+                seeds = [1000 * R + 10 * attempt + i for i in range(R)]
+                res = pkg.jordan_reduce_batch(Cv, A, b, restarts=R, seeds=seeds, ctx=ctx, setup=setup)
+                if all(x["status"] == 0 for x in res):
+                    break
+            assert all(x["status"] == 0 for x in res), [x["status"] for x in res]
+            its = set()
+            for x in res:
+                assert x["P"].nparts == d and np.array_equal(x["P"].matrix, Lg)
+                assert x["sum_sq"] == S and x["nblocks"] == len(expect)
+                its.add(x["iterations"])
+            assert len(its) == 1
+            if name == "circ256":  # 1 x 1 blocks: the images are the characters of the scheme, a set of d columns
+                ref = colset(res[0]["blks"])
+                for x in res[1:]:
+                    assert np.allclose(colset(x["blks"]), ref, atol=1e-6)
+        # the same seed on a fresh ctx, one restart at a time
+        single = []
+        for sd in seeds:
+            with pkg.Context(seed=sd) as c1:
+                y = pkg.jordan_reduce_batch(Cv, A, b, restarts=1, seeds=[sd], ctx=c1, setup=setup)[0]
+            single.append(y)
+        for x, y in zip(res, single):
+            assert x["status"] == y["status"] == 0
+            assert np.array_equal(x["P"].matrix, y["P"].matrix) and x["iterations"] == y["iterations"]
+            assert np.allclose(colset(x["blks"]), colset(y["blks"]), atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["circ64", "circ256", "circ1024"])
