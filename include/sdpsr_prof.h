@@ -35,6 +35,11 @@ int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int r
    The int8 squares run power-limited (the clock drops under the kernel); the roofline of
    bench.py reports the fraction of the peak both at the nominal and at this measured clock. */
 int sdpsr_profile_clock(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps, double* out);
+/* What the hipGraph cache of the tridiagonalisation (one graph per problem shape and buffer set, kept in ctx) has done
+   so far: out[0] = replays of a cached graph, out[1] = misses (a graph of ~2 n nodes built and instantiated on the
+   host), out[2] = milliseconds spent building.  A caller that alternates between a few orders pays the build once per
+   order. */
+int sdpsr_profile_sytrd_graphs(sdpsr_ctx* ctx, double* out);
 
 #ifdef __cplusplus
 }

@@ -156,15 +156,29 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     bool done = false;
     if (S == S1 && force == 0 && !(c->opts.flags & SDPSR_FLAG_FULL_BASIS_IMAGE) && d >= 1 && n >= 64) {
         double* ws = (double*)ctx_buf(c, "bi_comm_ws", basis_image_commutative_workspace_doubles(n, d) * 8);
-        uint32_t* bflag = (uint32_t*)ctx_buf(c, "bi_comm_flag", 64);
-        uint32_t* hv = (uint32_t*)ctx_pinned(c, 64);
-        if (!ws || !bflag || !hv) return SDPSR_OUT_OF_MEMORY;
-        (void)bflag;
-        if (launch_basis_image_commutative(s, n, d, S1, L, Qrm, next_key(c), atol, 2e-10, ws, out, hv)) {  // verdict stored into pinned host memory
+        // per-column verdicts, stored by the check kernel straight into pinned host memory: its own words, beside
+        // (not inside) the refinement's counters at the start of the buffer
+        uint32_t* hv = (uint32_t*)ctx_pinned(c, 256 + (size_t)(S1 + 1) * 4);
+        if (!ws || !hv) return SDPSR_OUT_OF_MEMORY;
+        hv += 64;
+        if (launch_basis_image_commutative(s, n, d, S1, L, Qrm, next_key(c), atol, 2e-10, ws, out, hv)) {
             HIP_TRY(c, ctx_sync_stream(c, s));
             HIP_TRY(c, hipGetLastError());
-            done = hv[0] == 0;
-            if (!done && dbg_on()) fprintf(stderr, "[sdpsr] basis_image: invariance check failed, projection formula instead\n");
+            const uint32_t nbad = hv[0];
+            done = nbad == 0;
+            if (!done && nbad <= 8) {
+                // a few columns failed (the eigenvectors of a pair of close eigenvalues): the projection formula for
+                // those columns only, two per extra class-sum pass
+                std::vector<int> badk;
+                for (int64_t k2 = 0; k2 < S1; ++k2)
+                    if (hv[1 + k2]) badk.push_back((int)k2);
+                done = true;
+                for (size_t q = 0; q < badk.size() && done; q += 2)
+                    done = launch_basis_image_fix_pair(s, n, d, S1, L, Qrm, badk[q], badk[q + 1 < badk.size() ? q + 1 : q], atol, ws, out);
+                if (dbg_on()) fprintf(stderr, "[sdpsr] basis_image: invariance check failed for %u column(s), projection formula for those\n", nbad);
+            } else if (!done && dbg_on()) {
+                fprintf(stderr, "[sdpsr] basis_image: invariance check failed for %u columns, projection formula instead\n", nbad);
+            }
         }
     }
     if (done) {

@@ -963,26 +963,62 @@ class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict_
 // (n^2 label reads, no gathers of Q_hat rows) instead of the class sums of all S1 columns
 // (n^2 S1 / 2 gathered 8-byte words, the L2-bound 190 us of basis_image_rows_kernel at N = 4096).
 // The identity is only as good as the invariance, so it is CHECKED, not assumed: a second vector
-// x' = sum_k sigma_k q_k with random signs goes through the same pass (double2 lanes), and
-// q_k'(A_i x) must agree with sigma_k q_k'(A_i x') -- the cross terms q_k' A_i q_k', k' != k, enter the
-// two with different signs.  Any disagreement raises a flag and the caller computes the projection
-// formula Q_k' 1[P==i] Q_k itself (two-stage kernels above), which is also what
-// sdpsr_opts.flags & SDPSR_FLAG_FULL_BASIS_IMAGE always does.
+// x' = sum_k g_k q_k with generic real weights g_k in [0.5, 1.5) goes through the same pass (double2 lanes), and
+// q_k'(A_i x) must agree with q_k'(A_i x') / g_k -- a cross term q_k' A_i q_j, j != k, enters the two with the
+// different factors 1 and g_j / g_k, so ANY non-zero cross term shows with probability 1 (round 3 used random signs:
+// a coupling of two columns with equal signs went unseen, probability 1/2 per pair).  The verdict is per COLUMN k:
+// the columns that fail (typically the two eigenvectors of a pair of close eigenvalues of the random generic element,
+// accurate to eps |A| / gap only) get their images from the projection formula q_k' 1[P==i] q_k itself, two columns per
+// extra class-sum pass (launch_basis_image_fix_pair); only when many columns fail does the caller run the projection
+// formula for all of them (two-stage kernels above), which is also what SDPSR_FLAG_FULL_BASIS_IMAGE always does.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double bi_sign(uint64_t key, int k) { return (sdpsr_fmix64(key + 0x9E3779B97F4A7C15ULL * (uint64_t)(k + 1)) >> 63) ? -1.0 : 1.0; }
+__device__ __forceinline__ double bi_weight(uint64_t key, int k) {
+    return 0.5 + (double)(sdpsr_fmix64(key + 0x9E3779B97F4A7C15ULL * (uint64_t)(k + 1)) >> 11) * (1.0 / 9007199254740992.0);
+}
 
-// X[r] = (sum_k Q[r,k], sum_k sigma_k Q[r,k]);  Qrm row-major n x S1
+// X[r] = (sum_k Q[r,k], sum_k g_k Q[r,k]);  Qrm row-major n x S1;  flag[0] = failing columns so far, flag[1 + k] = column k failed
 __global__ void bi_signed_sums_kernel(int n, int S1, const double* __restrict__ Qrm, uint64_t key, double2* __restrict__ X, uint32_t* flag) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r == 0) flag[0] = 0u;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k <= S1; k += blockDim.x) flag[k] = 0u;
     if (r >= n) return;
     double a = 0, b = 0;
     for (int k = 0; k < S1; ++k) {
         const double q = Qrm[(int64_t)r * S1 + k];
         a += q;
-        b = fma(bi_sign(key, k), q, b);
+        b = fma(bi_weight(key, k), q, b);
     }
     X[r] = make_double2(a, b);
+}
+
+// X[r] = (Q[r, k1], Q[r, k2]): the pair of columns whose images are recomputed by the projection formula
+__global__ void bi_pair_vector_kernel(int n, int S1, const double* __restrict__ Qrm, int k1, int k2, double2* __restrict__ X) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) X[r] = make_double2(Qrm[(int64_t)r * S1 + k1], Qrm[(int64_t)r * S1 + k2]);
+}
+
+// out[i * S1 + k1] = q_k1' (A_i q_k1), out[i * S1 + k2] = q_k2' (A_i q_k2) from the class sums Y of that pair; grid d
+__global__ void __launch_bounds__(256)
+bi_contract_pair_kernel(int n, int S1, const double* __restrict__ Qrm, const double2* __restrict__ Y, int k1, int k2, double atol,
+                        double* __restrict__ out) {
+    __shared__ double red[2][256];
+    const int i = blockIdx.x;
+    const double2* Yi = Y + (int64_t)i * n;
+    double a0 = 0, a1 = 0;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const double2 y = Yi[r];
+        a0 = fma(Qrm[(int64_t)r * S1 + k1], y.x, a0);
+        a1 = fma(Qrm[(int64_t)r * S1 + k2], y.y, a1);
+    }
+    red[0][threadIdx.x] = a0;
+    red[1][threadIdx.x] = a1;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double v = 0;
+        for (int g = 0; g < 256; ++g) v += red[threadIdx.x][g];
+        const int k = threadIdx.x == 0 ? k1 : k2;
+        out[(int64_t)i * S1 + k] = (fabs(v) < atol) ? 0.0 : v;
+    }
 }
 
 // Class sums of a PAIR of vectors: out[(i-1) n + r] = sum over c with L[c,r] == i of X[c]  (both halves).
@@ -1060,8 +1096,9 @@ class_sums2_kernel(int n, int d, int tstride, const uint32_t* __restrict__ L, co
     }
 }
 
-// out[i * S1 + k] = q_k' Y_i (first halves), checked against sigma_k q_k' Y_i (second halves): flag[0] = 1
-// where they differ by more than tol.  grid (d, ceil(S1 / 4)), 256 threads = 4 outputs x 64 row groups.
+// out[i * S1 + k] = q_k' Y_i (first halves), checked against q_k' Y_i (second halves) / g_k: where they differ by more
+// than tol, column k is marked (flag[1 + k] = 1, counted once in flag[0]).  grid (d, ceil(S1 / 4)), 256 threads = 4
+// outputs x 64 row groups.
 __global__ void __launch_bounds__(256)
 bi_contract_check_kernel(int n, int S1, const double* __restrict__ Qrm, const double2* __restrict__ Y, uint64_t key, double atol,
                          double tol, double* __restrict__ out, uint32_t* __restrict__ flag) {
@@ -1087,14 +1124,18 @@ bi_contract_check_kernel(int n, int S1, const double* __restrict__ Qrm, const do
             v0 += red[0][gg * 4 + threadIdx.x];
             v1 += red[1][gg * 4 + threadIdx.x];
         }
-        if (!(fabs(v0 - bi_sign(key, k) * v1) <= tol)) flag[0] = 1u;
+        if (!(fabs(v0 - v1 / bi_weight(key, k)) <= tol)) {
+            if (atomicExch(&flag[1 + k], 1u) == 0u) atomicAdd(&flag[0], 1u);
+        }
         out[(int64_t)i * S1 + k] = (fabs(v0) < atol) ? 0.0 : v0;
     }
 }
 
 size_t basis_image_commutative_workspace_doubles(int64_t n, int64_t d) { return (size_t)2 * n * (d + 1); }
 // All blocks 1 x 1 (S = S1).  ws: 2 n (d + 1) doubles.  Returns false when the shape has no instance (d > 148);
-// flag[0] = 1 after the launches <=> the check failed and `out` must be recomputed by the projection formula.
+// after the launches flag[0] = number of columns whose check failed, flag[1 + k] = 1 for those columns (flag: 1 + S1
+// words the device can write, e.g. pinned host memory): their entries of `out` must be recomputed by the projection
+// formula (launch_basis_image_fix_pair, or everything by the caller).
 bool launch_basis_image_commutative(hipStream_t s, int64_t n, int64_t d, int64_t S1, const uint32_t* L, const double* Qrm, uint64_t key,
                                     double atol, double tol, double* ws, double* out, uint32_t* flag) {
     const int tstride = (int)((d + 1) | 1);
@@ -1113,6 +1154,28 @@ bool launch_basis_image_commutative(hipStream_t s, int64_t n, int64_t d, int64_t
     else class_sums2_kernel<1><<<g, 64, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
     dim3 gc((unsigned)d, (unsigned)((S1 + 3) / 4));
     bi_contract_check_kernel<<<gc, 256, 0, s>>>((int)n, (int)S1, Qrm, Y, key, atol, tol, out, flag);
+    return true;
+}
+
+// The projection formula for two columns k1, k2 of a commutative Q_hat (k2 = k1 allowed): one more class-sum pass of
+// the pair (q_k1, q_k2) and its contraction, overwriting out[i * S1 + k1], out[i * S1 + k2] for every class i.
+bool launch_basis_image_fix_pair(hipStream_t s, int64_t n, int64_t d, int64_t S1, const uint32_t* L, const double* Qrm, int k1, int k2,
+                                 double atol, double* ws, double* out) {
+    const int tstride = (int)((d + 1) | 1);
+    const size_t per_wave = (size_t)64 * tstride * sizeof(double2);
+    int W = 4;
+    while (W > 1 && per_wave * W > 150 * 1024) W >>= 1;
+    if (per_wave * W > 150 * 1024 || n < 1 || n > 0x7FFFFFFF / 2) return false;
+    double2* X = reinterpret_cast<double2*>(ws);
+    double2* Y = X + n;
+    bi_pair_vector_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((int)n, (int)S1, Qrm, k1, k2, X);
+    int g = (int)((n + W - 1) / W);
+    if (g > 256) g = 256;
+    const size_t lds = per_wave * W;
+    if (W == 4) class_sums2_kernel<4><<<g, 256, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+    else if (W == 2) class_sums2_kernel<2><<<g, 128, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+    else class_sums2_kernel<1><<<g, 64, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+    bi_contract_pair_kernel<<<(unsigned)d, 256, 0, s>>>((int)n, (int)S1, Qrm, Y, k1, k2, atol, out);
     return true;
 }
 

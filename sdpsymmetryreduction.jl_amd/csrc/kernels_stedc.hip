@@ -827,4 +827,26 @@ bool launch_stedc(hipStream_t s, int64_t n, int64_t ld, const double* d, const d
     return hipGetLastError() == hipSuccess;
 }
 
+// info[0] = 1 if an eigenvalue is not finite or the values are not ascending (NaN / Inf in the tridiagonal input
+// pass through the secular bisection as "below" and would come out as garbage eigenpairs with a clean status: the
+// library solvers behind eig_driver 1 / 2 / 3 / 5 report SOLVER_ERROR there), else 0; info[1] = 0.
+__global__ void __launch_bounds__(256) dc_check_kernel(int n, const double* __restrict__ w, int* __restrict__ info) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int b = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double v = w[i];
+        if (!(fabs(v) <= 1.79769313486231570e308)) b = 1;         // NaN or Inf
+        if (i + 1 < n && !(v <= w[i + 1])) b = 1;                  // not ascending (or NaN)
+    }
+    if (b) bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[0] = bad;
+        info[1] = 0;
+    }
+}
+void launch_stedc_check(hipStream_t s, int64_t n, const double* w, int* info) { dc_check_kernel<<<1, 256, 0, s>>>((int)n, w, info); }
+
 }  // namespace sdpsr

@@ -28,6 +28,10 @@
 // Output is LAPACK-compatible (d, e, tau, reflectors below the subdiagonal of A), so the
 // tridiagonal solve (rocSOLVER stedc) and the back-transformation plug in unchanged.
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "sdpsr_internal.h"
 #include "jacobi64.h"
 
@@ -1129,7 +1133,17 @@ struct SytrdGraph {
 struct SytrdGraphCache {
     SytrdGraph slots[6];
     uint64_t clock = 0;
+    // what the cache did (sytrd_graph_cache_stats; traced under SDPSR_DEBUG): a miss builds and instantiates a graph of
+    // ~2 n nodes on the host, several times the cost of the solve it then replays
+    uint64_t hits = 0, misses = 0;
+    double instantiate_ms = 0;
 };
+bool dbg_on();  // ctx.cpp (SDPSR_DEBUG)
+void sytrd_graph_cache_stats(const SytrdGraphCache* g, uint64_t* hits, uint64_t* misses, double* instantiate_ms) {
+    if (hits) *hits = g ? g->hits : 0;
+    if (misses) *misses = g ? g->misses : 0;
+    if (instantiate_ms) *instantiate_ms = g ? g->instantiate_ms : 0.0;
+}
 void sytrd_graph_cache_destroy(SytrdGraphCache* g) {
     if (!g) return;
     for (auto& sl : g->slots)
@@ -1151,7 +1165,10 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
     SytrdGraph* slot = nullptr;
     for (auto& g : gc.slots)
         if (g.exec && g.n == n64 && g.ld == ld && g.rows == rows && g.A == A && g.d == d && g.e == e && g.tau == tau && g.ws == ws) slot = &g;
+    if (slot) ++gc.hits;
     if (!slot) {
+        ++gc.misses;
+        const auto t_build = std::chrono::steady_clock::now();
         SytrdGraph* victim = &gc.slots[0];
         for (auto& g : gc.slots)
             if (!g.exec) {
@@ -1186,6 +1203,11 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
         victim->tau = tau;
         victim->ws = ws;
         slot = victim;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
+        gc.instantiate_ms += ms;
+        if (dbg_on())
+            fprintf(stderr, "[sdpsr] sytrd graph cache MISS: n=%lld ld=%lld rows=%d built + instantiated in %.2f ms (hits %llu, misses %llu)\n",
+                    (long long)n64, (long long)ld, (int)rows, ms, (unsigned long long)gc.hits, (unsigned long long)gc.misses);
     }
     slot->last_use = gc.clock;
     if (hipGraphLaunch(slot->exec, s) != hipSuccess) {

@@ -202,12 +202,12 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                     !(c->opts.flags & SDPSR_FLAG_NO_VERIFY_SHORTCUT)) {
                     SigSource qv = qj;
                     if (confirming) qv.kind = SIG_CHAN_I32;
-                    uint32_t* vflag = (uint32_t*)ctx_buf(c, "adm_vflag", 64);
                     void* vref = ctx_buf(c, "adm_vref", verify_ref_bytes(current));
                     const uint32_t* first = (const uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
-                    uint32_t* hv = (uint32_t*)ctx_pinned(c, 64);
-                    if (!vflag || !vref || !first || !hv) return SDPSR_OUT_OF_MEMORY;
-                    (void)vflag;
+                    // the verdict has its own pinned words (the refinement's counters live at the start of the buffer)
+                    uint32_t* hv = (uint32_t*)ctx_pinned(c, 1024);
+                    if (!vref || !first || !hv) return SDPSR_OUT_OF_MEMORY;
+                    hv += 128;
                     if (launch_verify_no_split(s, qv, current, first, vref, hv)) {  // the verdict is stored straight into pinned host memory
                         HIP_TRY(c, ctx_sync_stream(c, s));
                         HIP_TRY(c, hipGetLastError());

@@ -22,6 +22,18 @@ void launch_clock_sampler(hipStream_t s, long long* buf, int ns, const unsigned*
 void launch_wall_marker(hipStream_t s, long long* out);
 }
 
+extern "C" int sdpsr_profile_sytrd_graphs(sdpsr_ctx* c, double* out) {
+    CHECK_CTX(c);
+    if (!out) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    uint64_t h = 0, m = 0;
+    double ms = 0;
+    sytrd_graph_cache_stats(c->sytrd_graphs, &h, &m, &ms);
+    out[0] = (double)h;
+    out[1] = (double)m;
+    out[2] = ms;
+    return SDPSR_OK;
+}
+
 extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t aux, int reps,
                                     double* ms_per_launch) {
     CHECK_CTX(c);

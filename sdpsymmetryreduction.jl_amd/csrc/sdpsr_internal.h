@@ -267,6 +267,7 @@ void launch_eigdec_batched64(hipStream_t s, int64_t n, int64_t d, int64_t count,
                              uint64_t seed, uint64_t stream_base, double atol, int32_t* status, int32_t* neig,
                              int32_t* nclasses, int num_cus);
 void sytrd_graph_cache_destroy(SytrdGraphCache* g);
+void sytrd_graph_cache_stats(const SytrdGraphCache* g, uint64_t* hits, uint64_t* misses, double* instantiate_ms);
 
 // symmetric-labels check: flag[0] = 1 if some L[i,j] != L[j,i]
 void launch_check_symmetric(hipStream_t s, int64_t n, const uint32_t* L, uint32_t* flag);
@@ -356,6 +357,8 @@ void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S
                                   const uint32_t* L, const double* Qrm, double* T, const int32_t* colA,
                                   const int32_t* colB, double atol, double* out);
 size_t basis_image_commutative_workspace_doubles(int64_t n, int64_t d);
+bool launch_basis_image_fix_pair(hipStream_t s, int64_t n, int64_t d, int64_t S1, const uint32_t* L, const double* Qrm, int k1, int k2,
+                                 double atol, double* ws, double* out);
 bool launch_basis_image_commutative(hipStream_t s, int64_t n, int64_t d, int64_t S1, const uint32_t* L, const double* Qrm, uint64_t key,
                                     double atol, double tol, double* ws, double* out, uint32_t* flag);
 void launch_transpose_to_rowmajor(hipStream_t s, int64_t n, int64_t S1, const double* Qcm,

@@ -332,6 +332,37 @@ def test_config4_n8192_block_diagonalize_full_size(pkg, problems):
     assert sizes == [1] * d
 
 
+def test_generic_partition_failure_rate_matches_the_oracle(pkg, problems):
+    """configs[1]'s kind of partition (no symmetry: every unordered pair its own class) makes the randomized
+    eigen_decomposition fail with NumericalInconsistency in a two-digit percentage of the draws -- the reference's own
+    behaviour ("try again", src/eigen_decomposition.jl:264-270).  CPU oracle, reference-literal, 300 runs each
+    (tools/bd_failure_compare.py generic-oracle; profiles/r04_bd_failure_rates_generic.txt): 30 / 300 at n = 200,
+    35 / 300 at n = 320, 30 / 300 at n = 512.  The device's dense driver with the reference's single coupling element
+    (SDPSR_FLAG_SINGLE_COUPLING_ELEMENT) must fail at the SAME rate (binomial band of 4 sigma around 35 / 300), and the
+    default driver (extra coupling elements on demand) must not fail more often than that."""
+    n, runs, p_oracle = 320, 300, 35.0 / 300.0
+    iu = np.triu_indices(n)
+    L = np.zeros((n, n), dtype=np.int64)
+    L[iu] = np.arange(1, len(iu[0]) + 1)
+    L = np.maximum(L, L.T)
+    L, d = problems.canonical_labels(L)
+    P = pkg.Partition(d, L.astype(np.uint32))
+    sigma = (runs * p_oracle * (1 - p_oracle)) ** 0.5
+    rates = {}
+    for flags in (pkg._lib.FLAG_SINGLE_COUPLING_ELEMENT, 0):
+        fails = 0
+        with pkg.Context(seed=77, flags=flags) as ctx:
+            for _ in range(runs):
+                try:
+                    pkg.eigen_decomposition(P, ctx=ctx)
+                except pkg.NumericalInconsistency:
+                    fails += 1
+        rates[flags] = fails
+    lit = rates[pkg._lib.FLAG_SINGLE_COUPLING_ELEMENT]
+    assert abs(lit - runs * p_oracle) <= 4 * sigma, (rates, runs * p_oracle, sigma)
+    assert rates[0] <= runs * p_oracle + 4 * sigma, rates
+
+
 # ------------------------------------------------ bench.py --gpus N: the launcher and the agreement step on device tensors
 def _run_bench(extra_env, *flags):
     import json

@@ -266,6 +266,62 @@ def test_tridiagonal_divide_and_conquer_hard_cases(pkg):
                     assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12, (drv, n, name)
 
 
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_tridiagonal_divide_and_conquer_hard_cases_large(pkg, n):
+    """The same hard tridiagonal matrices at the orders where the deflation runs and the 64-terms-per-lane secular
+    kernels of kernels_stedc.hip are at their limits (merges of 4096 poles; 8192 is the embedded order of the complex
+    path at n = 4096): Wilkinson, glued Wilkinson, graded, and a spectrum of six eigenvalues with multiplicities of
+    hundreds (at 8192: two such blocks of order 4096 glued by 1e-9).  Same bounds as at the small orders: eigenvalues to
+    2e-13 |T| against LAPACK's tridiagonal solver, residual 1e-12 |T|, orthogonality 1e-12 (products on the device)."""
+    import scipy.linalg as sl
+    import torch
+    lib = pkg.load_library()
+    rng = np.random.default_rng(n)
+
+    def six(m):
+        Q0, _ = np.linalg.qr(rng.standard_normal((m, m)))
+        Dg = np.repeat(rng.standard_normal(6) * 3, m // 6 + 1)[:m]
+        A = (Q0 * Dg) @ Q0.T
+        H = sl.hessenberg((A + A.T) / 2)
+        return np.diag(H).copy(), np.diag(H, -1).copy()
+
+    d6, e6 = six(4096)
+    if n == 8192:
+        d6, e6 = np.concatenate([d6, d6]), np.concatenate([e6, [1e-9], e6])
+    cases = [("wilkinson", np.abs(np.arange(n) - n // 2).astype(float), np.ones(n - 1)),
+             ("glued wilkinson", np.tile(np.abs(np.arange(21) - 10.0), n // 21 + 1)[:n], np.where((np.arange(n - 1) + 1) % 21 == 0, 1e-8, 1.0)),
+             ("graded", 10.0 ** (-np.arange(n) * 12.0 / n), 10.0 ** (-np.arange(n - 1) * 12.0 / n)),
+             ("six eigenvalues", d6, e6)]
+    T = torch.zeros(n * n, dtype=torch.float64, device="cuda")
+    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    V = torch.empty(n * n, dtype=torch.float64, device="cuda")
+    with pkg.Context(seed=1) as ctx:
+        for name, d, e in cases:
+            T.zero_()
+            Tm = T.view(n, n)  # symmetric: row- and column-major views coincide
+            td, te = torch.from_numpy(d).cuda(), torch.from_numpy(e).cuda()
+            idx = torch.arange(n, device="cuda")
+            Tm[idx, idx] = td
+            Tm[idx[:-1], idx[:-1] + 1] = te
+            Tm[idx[:-1] + 1, idx[:-1]] = te
+            ctx.check(lib.sdpsr_syev_f64(ctx._h, n, C.c_void_p(T.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(V.data_ptr()), 1))
+            wl = sl.eigh_tridiagonal(d, e, eigvals_only=True)
+            sc = np.abs(wl).max()
+            wh = w.cpu().numpy()
+            assert np.all(np.diff(wh) >= 0), (n, name)
+            assert np.abs(wh - wl).max() <= 2e-13 * sc, (n, name, np.abs(wh - wl).max() / sc)
+            Vm = V.view(n, n).t()  # column-major n x n
+            R = td[:, None] * Vm
+            R[:-1] += te[:, None] * Vm[1:]
+            R[1:] += te[:, None] * Vm[:-1]
+            R -= Vm * w[None, :]
+            assert float(R.abs().max()) <= 1e-12 * sc, (n, name, float(R.abs().max()) / sc)
+            G = Vm.t() @ Vm
+            G -= torch.eye(n, dtype=torch.float64, device="cuda")
+            assert float(G.abs().max()) < 1e-12, (n, name, float(G.abs().max()))
+            del R, G
+
+
 def test_syev_degenerate_spectrum_residual(pkg, problems, gpu_ctx):
     """Generic elements of symmetric algebras have a handful of eigenvalues with huge
     multiplicities: the tridiagonalisation deflates after ~dim columns and then works on
@@ -830,6 +886,71 @@ def test_bucketed_refine_small_and_ragged_sizes(pkg, oracle, n):
             P = pkg.Partition.from_matrix(M, ctx=ctx)
             R = oracle.partition_from_values(M)
             assert P.nparts == R.nparts and np.array_equal(P.matrix, R.matrix), n
+
+
+def test_syev_alternating_orders_replay_their_graphs(pkg):
+    """A caller that alternates between a few orders (the dense driver on problems of different size) must pay the
+    construction of the tridiagonalisation's hipGraph once per order (twice where the ctx's grow-only buffers were still
+    growing): from the third round on every call is a replay (hit / miss counters of the ctx's cache), and no
+    device-resident call takes more than twice the median of its order.  (The 75-95 ms calls of
+    profiles/r03_stedc_check.txt are not graph rebuilds -- that run built 3 graphs in 24 calls, 4 ms each; they come and go
+    with the host's BLAS thread pool, which tools/stedc_check.py used for its LAPACK comparison between the calls with
+    128 threads on the box's 16-core share.)"""
+    import time
+    import torch
+    lib = pkg.load_library()
+    prof = pkg._lib.load_prof_library()
+    orders = (640, 900, 1152)
+    rng = np.random.default_rng(5)
+    with pkg.Context(seed=1) as ctx:
+        mats = {}
+        for n in orders:
+            A = rng.standard_normal((n, n))
+            mats[n] = torch.from_numpy(np.asfortranarray((A + A.T) / 2).ravel(order="F").copy()).cuda()
+        w = {n: torch.empty(n, dtype=torch.float64, device="cuda") for n in orders}
+        V = {n: torch.empty(n * n, dtype=torch.float64, device="cuda") for n in orders}
+        times = {n: [] for n in orders}
+        st = (C.c_double * 3)()
+        for rnd in range(6):
+            for n in orders:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.check(lib.sdpsr_syev_f64(ctx._h, n, C.c_void_p(mats[n].data_ptr()), C.c_void_p(w[n].data_ptr()), C.c_void_p(V[n].data_ptr()), 1))
+                times[n].append((time.perf_counter() - t0) * 1e3)
+            if rnd == 1:
+                ctx.check(prof.sdpsr_profile_sytrd_graphs(ctx._h, st))
+                misses_settled = st[1]
+        ctx.check(prof.sdpsr_profile_sytrd_graphs(ctx._h, st))
+        # one build per order, plus one more for every order whose graph was built before the ctx's grow-only padded
+        # buffers reached their final size (the first round visits the orders in increasing size): settled after round 2
+        assert st[1] == misses_settled <= 2 * len(orders), (st[0], st[1], misses_settled)
+        assert st[0] >= 4 * len(orders)
+        for n in orders:
+            rest = sorted(times[n][2:])
+            med = rest[len(rest) // 2]
+            assert max(rest) <= 2.0 * med + 0.5, (n, times[n])
+        # spectrum still right after the replays
+        for n in orders:
+            ref = np.linalg.eigvalsh(mats[n].cpu().numpy().reshape(n, n, order="F"))
+            assert np.abs(w[n].cpu().numpy() - ref).max() <= 1e-12 * n
+
+
+def test_syev_nonfinite_input_is_reported(pkg):
+    """NaN / Inf in the matrix: the own divide and conquer must not return garbage eigenpairs with a clean status
+    (rocSOLVER's drivers report SOLVER_ERROR there; so does the own path now, through its eigenvalue check)."""
+    lib = pkg.load_library()
+    n = 300
+    A = np.random.default_rng(1).standard_normal((n, n))
+    A = (A + A.T) / 2
+    for bad in (np.nan, np.inf):
+        B = A.copy()
+        B[17, 17] = bad
+        Bf = np.asfortranarray(B)
+        w = np.zeros(n)
+        V = np.zeros((n, n), order="F")
+        with pkg.Context(seed=1) as ctx:
+            st = lib.sdpsr_syev_f64(ctx._h, n, C.c_void_p(Bf.ctypes.data), C.c_void_p(w.ctypes.data), C.c_void_p(V.ctypes.data), 0)
+        assert st == 7, st  # SDPSR_SOLVER_ERROR
 
 
 # ------------------------------------------------ complex path (src/compat.jl:26-32,54-57)
