@@ -29,7 +29,7 @@ size_t stedc_descriptors(int64_t ld, std::vector<int>& out);
 void* stedc_descriptor_slot(void* ws, int64_t ld);
 bool launch_stedc(hipStream_t s, int64_t n, int64_t ld, const double* d, const double* e, double* w, double* Z, double* W1, double* W2,
                   void* ws);
-void launch_stedc_check(hipStream_t s, int64_t n, const double* w, int* info);
+void launch_stedc_check(hipStream_t s, int64_t n, const double* a, const double* b, int pre, int* info);
 
 // C (m x n, dense: ldc == m) = A' B with the K range split over workgroups when the output alone
 // would leave most CUs idle; partial tiles are summed in fixed order.
@@ -220,11 +220,12 @@ int syev_device(sdpsr_ctx* c, int64_t n, double* A, int64_t lda, double* w, doub
             int hst = h2d_sync(c, stedc_descriptor_slot(dws, ldz), desc.data(), db);
             if (hst) return hst;
             // (d = w and the output eigenvalues share the caller's array: the solver reads d, e in its first launch only)
+            launch_stedc_check(c->stream, n, w, E, 1, (int*)info);  // info = 1 on NaN / Inf in the tridiagonal matrix
             if (!launch_stedc(c->stream, n, ldz, w, E, wtmp, Z, W1, W2, dws))
                 return ctx_fail(c, SDPSR_HIP_ERROR, "tridiagonal divide and conquer: launch failed");
             if (hipMemcpyAsync(w, wtmp, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
                 return ctx_fail(c, SDPSR_HIP_ERROR, "tridiagonal divide and conquer: copy failed");
-            launch_stedc_check(c->stream, n, wtmp, (int*)info);  // info = 1 on non-finite / unordered eigenvalues (NaN / Inf input)
+            launch_stedc_check(c->stream, n, wtmp, nullptr, 0, (int*)info);  // ... or non-finite / unordered eigenvalues
             rs = rocblas_status_success;
         } else if (c->opts.eig_driver == 3)
             rs = rocsolver_dsteqr(h, rocblas_evect_tridiagonal, (rocblas_int)n, w, E, Z, (rocblas_int)ldz, info);

@@ -827,26 +827,34 @@ bool launch_stedc(hipStream_t s, int64_t n, int64_t ld, const double* d, const d
     return hipGetLastError() == hipSuccess;
 }
 
-// info[0] = 1 if an eigenvalue is not finite or the values are not ascending (NaN / Inf in the tridiagonal input
-// pass through the secular bisection as "below" and would come out as garbage eigenpairs with a clean status: the
-// library solvers behind eig_driver 1 / 2 / 3 / 5 report SOLVER_ERROR there), else 0; info[1] = 0.
-__global__ void __launch_bounds__(256) dc_check_kernel(int n, const double* __restrict__ w, int* __restrict__ info) {
+// Status of the own tridiagonal solver.  NaN / Inf in the tridiagonal input pass through the Jacobi leaves and the secular
+// bisection ("below") and can come out as finite garbage eigenpairs with a clean status; the library solvers behind
+// eig_driver 1 / 2 / 3 / 5 report SOLVER_ERROR there.  pre = 1 (before the solve): info[0] = 1 if d or e holds a
+// non-finite value, else 0; info[1] = 0.  pre = 0 (after it): info[0] |= 1 if an eigenvalue is not finite or the
+// values are not ascending.
+__global__ void __launch_bounds__(256) dc_check_kernel(int n, const double* __restrict__ a, const double* __restrict__ b, int pre, int* __restrict__ info) {
     __shared__ int bad;
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
-    int b = 0;
+    int f = 0;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const double v = w[i];
-        if (!(fabs(v) <= 1.79769313486231570e308)) b = 1;         // NaN or Inf
-        if (i + 1 < n && !(v <= w[i + 1])) b = 1;                  // not ascending (or NaN)
+        const double v = a[i];
+        if (!(fabs(v) <= 1.79769313486231570e308)) f = 1;                 // NaN or Inf
+        if (pre) {
+            if (i + 1 < n && !(fabs(b[i]) <= 1.79769313486231570e308)) f = 1;
+        } else if (i + 1 < n && !(v <= a[i + 1])) {
+            f = 1;                                                         // not ascending (or NaN)
+        }
     }
-    if (b) bad = 1;
+    if (f) bad = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
-        info[0] = bad;
+        info[0] = pre ? bad : (info[0] | bad);
         info[1] = 0;
     }
 }
-void launch_stedc_check(hipStream_t s, int64_t n, const double* w, int* info) { dc_check_kernel<<<1, 256, 0, s>>>((int)n, w, info); }
+void launch_stedc_check(hipStream_t s, int64_t n, const double* a, const double* b, int pre, int* info) {
+    dc_check_kernel<<<1, 256, 0, s>>>((int)n, a, b, pre, info);
+}
 
 }  // namespace sdpsr
