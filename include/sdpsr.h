@@ -158,8 +158,8 @@ typedef struct sdpsr_opts {
     int32_t insert_wgs_per_cu;  /* measurement knob: resident workgroups per CU of the refinement's insert pass (0 = default) */
     int32_t square_kernel;      /* int8 square of symmetric labels (src/partitions.jl:172): 0 = default (one persistent launch
                                    of 256 x 256 macro-tiles once they fill the chip, 128 x 128 tiles below that), 1 = always
-                                   128 x 128 tiles (the launch of ABI 0.3), 64 / 128 = always the persistent launch, with
-                                   64-byte K stages in a ring of four / two 128-byte stages.  Same integers every way. */
+                                   128 x 128 tiles (the launch of ABI 0.3), 64 = always the persistent launch (64-byte K
+                                   stages in a ring of four).  Same integers every way. */
     int32_t reserved[3];
 } sdpsr_opts;
 

@@ -65,7 +65,8 @@ struct SymSquareArgs {
     int32_t* C;
     int64_t ldx, ldc, strideX, strideC;
     int k;  // rows of X (bytes of K per operand row), a multiple of the stage width
-    int m;  // macro-tile rows: ld / 256
+    int m;  // whole macro-tile rows: ld / 256 (rounded down)
+    int rem;  // 1: ld is an odd multiple of 128 (a last unit row / column of quarter tiles)
     int T;  // channels
     const uint32_t* nonsym_flag;
 };
@@ -89,14 +90,18 @@ struct SymLane {
     int wave, lane_off, r32, h;
 };
 
-// One job of one wave: ROLE < 0 = its 128 x 64 part of a full macro-tile (rows from panel A, columns from panel B),
+// One job of one wave: ROLE -1 = its 128 x 64 part of a full macro-tile (rows from panel A, columns from panel B),
+// ROLE -2 = its 64 x 32 part of a 128 x 128 "quarter" tile (the ragged last 128 rows / columns of a matrix whose order
+// is an odd multiple of 128: panels of 128 rows, half the DMA instructions),
 // ROLE 0..3 = nine blocks of a diagonal macro-tile (waves 0-3: the tile of panel A, waves 4-7: that of panel B).
 // Every wave of the workgroup passes the same nk + 1 barriers whatever its role.
 template <int KB, int ROLE, bool LATE>
 __device__ __forceinline__ void sym_job(const SymLane& L, const char* smem, const int8_t* pA, const int8_t* pB, int32_t* Cout, int64_t ldc,
-                                        int nk, const int (&soff)[SymCfg<KB>::IPW], const int (&coff)[SymCfg<KB>::NQ]) {
+                                        int nk, const int (&soff)[ROLE == -2 ? 1 : SymCfg<KB>::IPW], const int (&coff)[SymCfg<KB>::NQ]) {
     typedef SymCfg<KB> CF;
-    constexpr int NACC = ROLE < 0 ? 8 : 9;
+    constexpr bool QUARTER = ROLE == -2;
+    constexpr int NACC = QUARTER ? 2 : (ROLE < 0 ? 8 : 9);
+    constexpr int NIS = QUARTER ? 1 : CF::IPW;  // DMA instructions per wave, panel and stage
     const int wave = L.wave;
     const int wi = wave & 1, wj = wave >> 1;
     v16i acc[NACC];
@@ -106,11 +111,11 @@ __device__ __forceinline__ void sym_job(const SymLane& L, const char* smem, cons
         for (int r = 0; r < 16; ++r) acc[t][r] = 0;
 
     auto issue = [&](int slot, int kt) {
-        const unsigned dst = L.lds0 + (unsigned)(slot * CF::STAGE + wave * CF::IPW * 1024);
+        const unsigned dst = L.lds0 + (unsigned)(slot * CF::STAGE + wave * NIS * 1024);
         const char* ga = reinterpret_cast<const char*>(pA) + (int64_t)kt * KB;
         const char* gb = reinterpret_cast<const char*>(pB) + (int64_t)kt * KB;
 #pragma unroll
-        for (int s = 0; s < CF::IPW; ++s) {
+        for (int s = 0; s < NIS; ++s) {
             glds16_u(ga + soff[s], dst + s * 1024);
             glds16_u(gb + soff[s], dst + CF::OPB + s * 1024);
         }
@@ -120,9 +125,13 @@ __device__ __forceinline__ void sym_job(const SymLane& L, const char* smem, cons
         if (st < nk) issue(st, st);
 
     // fragments of one 32-byte K-group and the MFMAs on them, by role
-    constexpr int NFR = ROLE < 0 ? 6 : kDiagRoles[ROLE < 0 ? 0 : ROLE].nf;
+    constexpr int NFR = QUARTER ? 3 : (ROLE < 0 ? 6 : kDiagRoles[ROLE < 0 ? 0 : ROLE].nf);
     auto load = [&](uint4 (&F)[NFR], const char* sA, const char* sB, int q) {
-        if constexpr (ROLE < 0) {
+        if constexpr (QUARTER) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) F[t] = *reinterpret_cast<const uint4*>(sA + (wi * 64 + t * 32) * KB + L.lane_off + coff[q]);
+            F[2] = *reinterpret_cast<const uint4*>(sB + (wj * 32) * KB + L.lane_off + coff[q]);
+        } else if constexpr (ROLE < 0) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) F[t] = *reinterpret_cast<const uint4*>(sA + (wi * 128 + t * 32) * KB + L.lane_off + coff[q]);
 #pragma unroll
@@ -135,7 +144,14 @@ __device__ __forceinline__ void sym_job(const SymLane& L, const char* smem, cons
         }
     };
     auto mma = [&](const uint4 (&F)[NFR]) {
-        if constexpr (ROLE < 0) {
+        if constexpr (QUARTER) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                v4i av = {(int)F[2].x, (int)F[2].y, (int)F[2].z, (int)F[2].w};
+                v4i bv = {(int)F[ti].x, (int)F[ti].y, (int)F[ti].z, (int)F[ti].w};
+                acc[ti] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc[ti], 0, 0, 0);
+            }
+        } else if constexpr (ROLE < 0) {
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
@@ -163,8 +179,12 @@ __device__ __forceinline__ void sym_job(const SymLane& L, const char* smem, cons
     uint4 Fc[NFR];  // the late group's carried fragments
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt has landed once at most the D - 1 younger stages of this wave are outstanding
-        if (kt + CF::D - 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (D - 1) * 2 * IPW
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + CF::D - 1 < nk) {
+            if constexpr (QUARTER) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (D - 1) * 2 * NIS
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if constexpr (late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the carried fragments are out of the ring
         __syncthreads();  // everybody's part of stage kt is in; nobody reads stage kt - 1 any more
         if (kt + CF::D < nk) issue((kt + CF::D) % CF::NS, kt + CF::D);
@@ -195,7 +215,14 @@ __device__ __forceinline__ void sym_job(const SymLane& L, const char* smem, cons
 
     // ---- results: D[jj][ii], ii = lane & 31, jj = (reg & 3) + 8 (reg >> 2) + 4 h ----
     if (!Cout) return;
-    if constexpr (ROLE < 0) {
+    if constexpr (QUARTER) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            int32_t* Ct = Cout + (wi * 64 + ti * 32 + L.r32) + (int64_t)(wj * 32 + 4 * L.h) * ldc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ct[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[ti][r];
+        }
+    } else if constexpr (ROLE < 0) {
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
@@ -230,12 +257,14 @@ __global__ void __launch_bounds__(SYM_NT) i8_symsquare_kernel(SymSquareArgs a) {
     const int wave = L.wave;
 
     const bool sym = a.nonsym_flag && *a.nonsym_flag == 0u;  // uniform
-    const int m = a.m, T = a.T;
+    const int m = a.m, T = a.T;                 // m whole macro-tile rows; a.rem = 1: 128 more rows / columns
     const int tri = m * (m - 1) / 2;
     const int ndt = sym ? T * m : 0;            // diagonal macro-tiles ...
     const int ND = (ndt + 1) >> 1;              // ... two per job
     const int NF = sym ? T * tri : T * m * m;   // full macro-tiles
-    const int NJ = NF + ND;
+    const int nqc = a.rem ? (sym ? 2 * m + 1 : 4 * m + 1) : 0;  // quarter tiles per channel: the last unit row (+ column)
+    const int NQ4 = T * nqc;
+    const int NJ = NF + ND + NQ4;
     const int nk = a.k / KB;
 
     // DMA sources of this lane inside a panel (K offset excluded)
@@ -245,6 +274,11 @@ __global__ void __launch_bounds__(SYM_NT) i8_symsquare_kernel(SymSquareArgs a) {
         const int r = (wave * CF::IPW + s) * CF::RPI + lane / CF::CH;
         const int c = (lane % CF::CH) ^ sym_swz<KB>(r);
         soff[s] = r * (int)a.ldx + c * 16;
+    }
+    int soffq[1];  // quarter tiles: this wave's 16 rows of a 128-row panel
+    {
+        const int r = wave * CF::RPI + lane / CF::CH;
+        soffq[0] = r * (int)a.ldx + ((lane % CF::CH) ^ sym_swz<KB>(r)) * 16;
     }
     // fragment reads: row r32 of a 32-row block, chunk 2 q + h, un-swizzled
     int coff[CF::NQ];
@@ -276,6 +310,17 @@ __global__ void __launch_bounds__(SYM_NT) i8_symsquare_kernel(SymSquareArgs a) {
             int32_t* cA = a.C + (int64_t)c * a.strideC + (int64_t)I * 256 + (int64_t)J * 256 * a.ldc;
             if (wave < 4) sym_job<KB, -1, false>(L, smem, pA, pB, cA, a.ldc, nk, soff, coff);
             else sym_job<KB, -1, true>(L, smem, pA, pB, cA, a.ldc, nk, soff, coff);
+        } else if (job >= NF + ND) {
+            // quarter tile of the ragged border: unit row 2 m x unit column u (u <= 2 m), or -- full squares only --
+            // unit row u - (2 m + 1) x unit column 2 m
+            const int q = job - NF - ND;
+            const int c = q / nqc, u = q - c * nqc;
+            const int ur = u <= 2 * m ? 2 * m : u - (2 * m + 1), uc = u <= 2 * m ? u : 2 * m;
+            const int8_t* pA = a.X + (int64_t)c * a.strideX + (int64_t)ur * 128 * a.ldx;
+            const int8_t* pB = a.X + (int64_t)c * a.strideX + (int64_t)uc * 128 * a.ldx;
+            int32_t* cQ = a.C + (int64_t)c * a.strideC + (int64_t)ur * 128 + (int64_t)uc * 128 * a.ldc;
+            if (wave < 4) sym_job<KB, -2, false>(L, smem, pA, pB, cQ, a.ldc, nk, soffq, coff);
+            else sym_job<KB, -2, true>(L, smem, pA, pB, cQ, a.ldc, nk, soffq, coff);
         } else {
             const int d1 = 2 * (job - NF), d2 = d1 + 1;
             const int c1 = d1 / m, I1 = d1 - c1 * m;
@@ -307,15 +352,15 @@ void gemm_sym_set_device_attributes() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&i8_symsquare_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
-// Does the persistent launch pay for an n x n problem with T channels?  Its jobs (lower-triangle macro-tiles of the
-// 256-padded matrix, the diagonal ones two per job) come in rounds of one per CU, and a job is 35 - 40 us of work at
-// N = 4096: the launch pays when the rounds are well filled (N = 4096, 2 channels: 256 jobs on 256 CUs; N = 8192:
-// 1024).  A sparsely filled last round (N = 4104 -> 4352: 289 jobs, 33 of them alone in a second round: 135 us against
-// 106 us for the 128 x 128 tiles) or a small problem keeps the 128 x 128 tiles, which spread over more CUs.  loop.cpp
-// pads the channel matrices accordingly.
+// Does the persistent launch pay for an n x n problem with T channels?  Its big jobs (lower-triangle macro-tiles of
+// the whole 256-row part of the matrix, the diagonal ones two per job) come in rounds of one per CU, and a job is
+// 35 - 40 us of work at N = 4096: the launch pays when the rounds are well filled (N = 4096, 2 channels: 256 jobs on 256
+// CUs; N = 8192: 1024; N = 4104 -> ld 4224: the same 256 jobs plus 66 quarter tiles of the last 128 rows, a short
+// second round).  A sparsely filled last round of big jobs or a small problem keeps the 128 x 128 tiles of
+// kernels_gemm.hip, which spread over more CUs.
 bool i8_symsquare_pays(int64_t n, int T, int num_cus) {
     if (num_cus < 1) return false;
-    const int64_t m = (n + 255) / 256;
+    const int64_t m = ((n + 127) / 128 * 128) / 256;
     const int64_t jobs = (int64_t)T * m * (m - 1) / 2 + ((int64_t)T * m + 1) / 2;
     const int64_t rounds = (jobs + num_cus - 1) / num_cus;
     return 4 * jobs >= 3 * (int64_t)num_cus && 100 * jobs >= 85 * rounds * num_cus;
@@ -325,7 +370,7 @@ bool i8_symsquare_pays(int64_t n, int T, int num_cus) {
 bool launch_i8_symsquare(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc, int batch,
                          int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag, int num_cus, int variant) {
     const bool forced = variant == 64;  // tests / measurements: the persistent launch at any size
-    if (num_cus < 1 || !(forced || i8_symsquare_pays(n, batch, num_cus)) || n < 256 || (n % 256) != 0 || (k % 128) != 0 || (ldx % 16) != 0 || (strideX % 16) != 0 ||
+    if (num_cus < 1 || !(forced || i8_symsquare_pays(n, batch, num_cus)) || n < 256 || (n % 128) != 0 || (k % 128) != 0 || (ldx % 16) != 0 || (strideX % 16) != 0 ||
         (reinterpret_cast<uintptr_t>(X) % 16) != 0 || n > 65536 || ldx > 65536)
         return false;
     SymSquareArgs a;
@@ -337,9 +382,10 @@ bool launch_i8_symsquare(hipStream_t s, int64_t n, int64_t k, const int8_t* X, i
     a.strideC = strideC;
     a.k = (int)k;
     a.m = (int)(n / 256);
+    a.rem = (n % 256) != 0 ? 1 : 0;
     a.T = batch;
     a.nonsym_flag = nonsym_flag;
-    const int64_t jobs = (int64_t)batch * a.m * a.m;  // upper bound (the full squares)
+    const int64_t jobs = (int64_t)batch * (a.m * a.m + (a.rem ? 4 * a.m + 1 : 0));  // upper bound (the full squares)
     const unsigned grid = (unsigned)std::min<int64_t>(jobs, num_cus);
     i8_symsquare_kernel<64><<<grid, SYM_NT, 128 * 1024, s>>>(a);
     return true;

@@ -53,10 +53,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
 
     const int mode = c->opts.square_mode;
     const int T = (mode == SDPSR_SQUARE_F64) ? 1 : c->opts.channels;
-    // int8 channels: padded to whole 256 x 256 macro-tiles of the persistent square (kernels_gemm_sym.hip)
-    const bool sq256 = mode == SDPSR_SQUARE_I8 && (c->opts.square_kernel == 64 || c->opts.square_kernel == 128 ||
-                                                   (c->opts.square_kernel == 0 && i8_symsquare_pays(n, T, c->num_cus)));
-    const int64_t ld = round_up(n, sq256 ? 256 : 128);
+    const int64_t ld = round_up(n, 128);
     void* Xp = nullptr;
     void* Cp = nullptr;
     double* Y = nullptr;

@@ -354,8 +354,7 @@ int sdpsr_square_i8_symmetric(sdpsr_ctx* c, int64_t n, int64_t batch, const int8
     if (!X || !X2 || n < 1 || batch < 1 || batch > 8) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
     int st = SDPSR_OK;
     const int sk = c->opts.square_kernel;
-    const bool sq256 = sk == 64 || sk == 128 || (sk == 0 && i8_symsquare_pays(n, (int)batch, c->num_cus));
-    const int64_t ld = round_up(n, sq256 ? 256 : 128);
+    const int64_t ld = round_up(n, 128);
     const int8_t* dX = in_dev(c, "sq_in", X, (size_t)batch * n * n, mem, &st);
     int8_t* Xp = (int8_t*)ctx_buf(c, "sq_xpad", (size_t)batch * ld * ld);
     int32_t* Cp = (int32_t*)ctx_buf(c, "sq_cpad", (size_t)batch * ld * ld * 4);

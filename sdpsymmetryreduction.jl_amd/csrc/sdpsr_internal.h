@@ -279,7 +279,7 @@ void launch_copy_check_symmetric(hipStream_t s, int64_t n, const uint32_t* src, 
 // aligned, lda/ldb multiples of 16 bytes.
 // ---------------------------------------------------------------------------
 // num_cus > 0: the persistent 256 x 256 launch (kernels_gemm_sym.hip) when n is a multiple of 256; variant =
-// sdpsr_opts.square_kernel (0 = by size, 1 = 128 x 128 tiles of kernels_gemm.hip, 64 / 128 = persistent forced)
+// sdpsr_opts.square_kernel (0 = by size, 1 = 128 x 128 tiles of kernels_gemm.hip, 64 = persistent forced)
 void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc,
                            int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag, int num_cus = 0,
                            int variant = 0);

@@ -34,7 +34,7 @@ struct Opts
     refine_path::Int32
     label_bits::Int32        # 8 * sizeof(T) of Partition{T}: InexactError where the reference throws it; 0 = never
     insert_wgs_per_cu::Int32 # measurement knob, 0 = default
-    square_kernel::Int32     # 0 = by size, 1 = 128 x 128 tiles, 64 / 128 = persistent 256 x 256 launch forced
+    square_kernel::Int32     # 0 = by size, 1 = 128 x 128 tiles, 64 = persistent 256 x 256 launch forced
     reserved::NTuple{3,Int32}
 end
 Opts(; flags=0, round_mode=0, label_bits=0, square_mode=0, channels=0) =

@@ -121,12 +121,13 @@ def _sym_i8(rng, n):
     return (np.triu(X) + np.triu(X, 1).T).astype(np.int8)
 
 
-@pytest.mark.parametrize("kernel", [64, 128, 1])
+@pytest.mark.parametrize("kernel", [64, 1, 0])
 def test_square_i8_symmetric_batch_every_kernel(pkg, gpu_ctx, kernel):
     """mul!(X2, X, X) (src/partitions.jl:172) for the loop's symmetric channel matrices, batched as the loop launches
-    them: the persistent 256 x 256 macro-tile launch forced at sizes with 1, 2, 3 and 5 macro-tile rows (odd and even
-    numbers of diagonal tiles: the paired diagonal jobs incl. the one whose partner is missing), both ring forms, and
-    the 128 x 128 tiles: bit-exact against integer matmul."""
+    them: the persistent 256 x 256 macro-tile launch forced at sizes with 1, 3 and 4 whole macro-tile rows, with and
+    without a ragged last 128 rows (the quarter-tile jobs), odd and even numbers of diagonal tiles (the paired diagonal
+    jobs incl. the one whose partner is missing); the 128 x 128 tiles; the default choice: bit-exact against integer
+    matmul."""
     lib = pkg.load_library()
     with pkg.Context(seed=3, square_kernel=kernel) as ctx:
         for n, batch in ((200, 1), (256, 2), (300, 3), (700, 2), (1100, 3)):
