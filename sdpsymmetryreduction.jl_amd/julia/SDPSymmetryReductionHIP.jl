@@ -240,6 +240,35 @@ function SR.blockDiagonalize(::Type{ComplexF64}, P::HIPPartition, verbose=true;
     return (blkSizes=Int.(sizes), blks=blks)
 end
 
+# ---- R independent random restarts of the reduction in ONE call on this task's thread (sdpsr_jordan_reduce_batch):
+# the reference's "try again" after NumericalInconsistency / DimensionMismatch (eigen_decomposition.jl:264-270,
+# diagonalize.jl:4-9) run side by side; returns the restarts' partitions, statuses and block-size sums, first the sizes
+# (images: call jordan_reduce / blockDiagonalize on the partition of the first restart whose status is 0) ----
+function jordan_reduce_batch(C::AbstractVector{Float64}, A::AbstractMatrix{Float64}, b::AbstractVector{Float64}, R::Integer;
+                             seeds::Union{Nothing,Vector{UInt64}}=nothing, atol=Base.rtoldefault(Float64),
+                             epsilon=Base.rtoldefault(Float64))
+    n = isqrt(length(C)); @assert n^2 == length(C)
+    F = qr(A'); U = Matrix(F.Q)[:, 1:rank(A)]; proj(v) = U * (U' * v)
+    c = Vector(C); c .-= proj(c); SR._clamp_round!(c, atol=atol); SR._symmetrize!(c, n)
+    x0, _ = SR.Krylov.craig(A, b); SR._symmetrize!(x0, n); x0 = proj(x0); SR._clamp_round!(x0, atol=atol)
+    cx = ctx()
+    Ps = [Matrix{UInt32}(undef, n, n) for _ in 1:R]
+    pP = [pointer(P) for P in Ps]
+    d = zeros(Int64, R); it = zeros(Int32, R); nb = zeros(Int32, R); ssq = zeros(Int64, R); ss = zeros(Int64, R); st = zeros(Int32, R)
+    hint = 2 | (all(k -> (M = reshape(view(U, :, k), n, n); isapprox(M, M'; atol=1e-12, rtol=0)), 1:size(U, 2)) ? 1 : 0)
+    ccall((:sdpsr_hint_symmetric_basis, libsdpsr), Cint, (Ptr{Cvoid}, Cint), cx.handle, hint)
+    GC.@preserve Ps begin
+        ccall((:sdpsr_jordan_reduce_batch, libsdpsr), Cint,
+              (Ptr{Cvoid}, Int32, Ptr{UInt64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Float64,
+               Ptr{Ptr{UInt32}}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64},
+               Ptr{Int32}, Cint),
+              cx.handle, R, seeds === nothing ? C_NULL : seeds, n, c, x0, U, size(U, 2), atol, epsilon, pP, d, it, nb, ssq, ss,
+              C_NULL, C_NULL, st, MEM_HOST)
+    end
+    return [(status=Int(st[i]), P=HIPPartition(Int(d[i]), Ps[i]), iterations=Int(it[i]), nblocks=Int(nb[i]),
+             sum_sq=Int(ssq[i]), sum_s=Int(ss[i])) for i in 1:R]
+end
+
 # ---- test/numerical_issues.jl:85-94 in one call: `count` runs of eigen_decomposition on all CUs ----
 function eigen_decomposition_batched(P::HIPPartition, count::Integer; atol=1e-12 * size(P, 1))
     n = size(P, 1); cx = ctx()
