@@ -3,7 +3,6 @@
 The directory name is not an importable dotted name; load it with
 ``__graft_entry__.load_package()`` (imports it as ``sdpsr_amd``).
 """
-from . import problems  # noqa: F401
 from . import parallel  # noqa: F401
 from . import _lib  # noqa: F401
 from . import api  # noqa: F401

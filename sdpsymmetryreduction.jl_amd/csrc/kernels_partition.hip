@@ -1032,19 +1032,26 @@ constexpr int LDS_MAX_PROBES = 24;
 // SRC: where the signatures come from (see the Src* functors); INSERT_PER_THREAD entries per
 // thread and chunk (16 for the plain array, 8 for the computed sources: their loads and hashes
 // of one chunk are all live before the first probe)
-template <class SRC, int INSERT_PER_THREAD, int LDS_SLOTS>
-__global__ void __launch_bounds__(REFINE_THREADS)
+// THREADS: 256, or 1024 with a table of 8192 slots in dynamic LDS (128 KiB, one workgroup per CU, 16 waves): the mid regime of
+// 1024 .. 4096 classes, whose signatures all stay resident in the workgroup's table (with 2048 slots they thrash it and
+// every entry goes to the global table: 0.5 ms at 3000 classes, N = 4096)
+template <class SRC, int INSERT_PER_THREAD, int LDS_SLOTS, int THREADS = REFINE_THREADS>
+__global__ void __launch_bounds__(THREADS)
 refine_insert_kernel(int64_t len, const SRC src,
                      uint32_t* __restrict__ slot_out, unsigned long long* __restrict__ tab_sig,
                      uint32_t* __restrict__ tab_min, uint32_t mask, uint32_t* counters) {
-    constexpr int INSERT_CHUNK = REFINE_THREADS * INSERT_PER_THREAD;
+    constexpr int INSERT_CHUNK = THREADS * INSERT_PER_THREAD;
     // The LDS table lives across the chunks of a workgroup: a signature is published to the
     // global table only the first time the workgroup meets it (its chunks come in increasing
     // index order, so that chunk also holds the workgroup's smallest index of the class); later
     // chunks reuse the resolved global slot.  The table is reset when it gets half full.
-    __shared__ unsigned long long l_sig[LDS_SLOTS];
-    __shared__ uint32_t l_min[LDS_SLOTS];
-    __shared__ uint32_t l_gslot[LDS_SLOTS];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long ri_dyn[];
+    __shared__ unsigned long long l_sig_st[LDS_SLOTS <= 2048 ? LDS_SLOTS : 1];
+    __shared__ uint32_t l_min_st[LDS_SLOTS <= 2048 ? LDS_SLOTS : 1];
+    __shared__ uint32_t l_gslot_st[LDS_SLOTS <= 2048 ? LDS_SLOTS : 1];
+    unsigned long long* l_sig = LDS_SLOTS <= 2048 ? l_sig_st : ri_dyn;
+    uint32_t* l_min = LDS_SLOTS <= 2048 ? l_min_st : reinterpret_cast<uint32_t*>(ri_dyn + LDS_SLOTS);
+    uint32_t* l_gslot = LDS_SLOTS <= 2048 ? l_gslot_st : reinterpret_cast<uint32_t*>(ri_dyn + LDS_SLOTS) + LDS_SLOTS;
     __shared__ uint32_t l_count, l_overflow, l_new;
     constexpr uint32_t PENDING = 0xFFFFFFFEu;
     const int64_t nchunk = (len + INSERT_CHUNK - 1) / INSERT_CHUNK;
@@ -1061,7 +1068,7 @@ refine_insert_kernel(int64_t len, const SRC src,
     // word, one barrier per chunk instead of three -- 80.3 us against 79.6: the barriers are not what the waves wait for.)
     for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x) {
         if (need_clear) {
-            for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
+            for (int i = threadIdx.x; i < LDS_SLOTS; i += THREADS) {
                 l_sig[i] = 0ull;
                 l_min[i] = 0xFFFFFFFFu;
             }
@@ -1079,7 +1086,7 @@ refine_insert_kernel(int64_t len, const SRC src,
             // level only costs probes, every entry goes to the global table directly
 #pragma unroll 4
             for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+                const int64_t e = base + q * THREADS + threadIdx.x;
                 if (e < len) {
                     const uint64_t sg = src(e);
                     uint32_t out = NO_SLOT;
@@ -1104,20 +1111,20 @@ refine_insert_kernel(int64_t len, const SRC src,
             if (base + threadIdx.x < len) IjWalk::locate(nn, low, base + threadIdx.x, wi, wj);
 #pragma unroll
             for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+                const int64_t e = base + q * THREADS + threadIdx.x;
                 sgs[q] = (e < len) ? src.at(wi, wj, e) : 0ull;
-                IjWalk::step(nn, low, wi, wj, REFINE_THREADS);
+                IjWalk::step(nn, low, wi, wj, THREADS);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-                const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+                const int64_t e = base + q * THREADS + threadIdx.x;
                 sgs[q] = (e < len) ? src(e) : 0ull;
             }
         }
 #pragma unroll
         for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-            const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+            const int64_t e = base + q * THREADS + threadIdx.x;
             const uint64_t sg = sgs[q];
             myslot[q] = -1;
             if (sg) {
@@ -1168,7 +1175,7 @@ refine_insert_kernel(int64_t len, const SRC src,
         // publish the signatures this workgroup has not resolved yet (few classes: nothing new after the first chunks,
         // the scan of the table and its barrier are skipped; l_new is uniform after the barrier above)
         if (l_new) {
-        for (int i = threadIdx.x; i < LDS_SLOTS; i += REFINE_THREADS) {
+        for (int i = threadIdx.x; i < LDS_SLOTS; i += THREADS) {
             if (l_sig[i] != 0ull && l_gslot[i] == PENDING) {
                 const uint32_t g = global_find_or_insert(l_sig[i], tab_sig, mask, counters);
                 // tab_min only ever decreases, so a (possibly stale) plain read that is already
@@ -1184,7 +1191,7 @@ refine_insert_kernel(int64_t len, const SRC src,
         }
 #pragma unroll
         for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-            const int64_t e = base + q * REFINE_THREADS + threadIdx.x;
+            const int64_t e = base + q * THREADS + threadIdx.x;
             if (e < len) {
                 uint32_t out = NO_SLOT;
                 if (myslot[q] >= 0) out = l_gslot[myslot[q]];
@@ -1714,7 +1721,16 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
         }
         case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;
         case SIG_CHAN_F32: launch_insert_chan<float>(s, gcap, len, q, slot, ws, cap); break;
-        default: launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap); break;
+        default:
+            if (ws.log2cap >= 14 && ws.log2cap <= 15) {  // 1024 < classes <= 4096 expected: the whole partition fits the big LDS table
+                const int64_t nchunk = (len + 1024 * 4 - 1) / (1024 * 4);
+                const int g = (int)(nchunk < 256 ? nchunk : 256);
+                refine_insert_kernel<SrcArray, 4, 8192, 1024><<<g, 1024, 8192 * 16, s>>>(len, SrcArray{q.sig}, slot, (unsigned long long*)ws.tab_sig,
+                                                                                       ws.tab_min, (uint32_t)(cap - 1), ws.counters);
+            } else {
+                launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap);
+            }
+            break;
     }
     const int g2 = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
     // ws.expect_small: the host predicts <= SMALL_K classes (from the previous refinement) and
@@ -1955,6 +1971,7 @@ __global__ void reduce_columns_final_kernel(int64_t nchunks, int m, int d, const
 }
 // per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes)
 void partition_set_device_attributes() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_kernel<SrcArray, 4, 8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
