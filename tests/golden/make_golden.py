@@ -22,7 +22,7 @@ ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "oracle"))
 import sdpsr_oracle as O  # noqa: E402
 
-spec = importlib.util.spec_from_file_location("problems", ROOT / "sdpsymmetryreduction.jl_amd" / "problems.py")
+spec = importlib.util.spec_from_file_location("problems", ROOT / "tests" / "problems.py")
 pr = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(pr)
 
