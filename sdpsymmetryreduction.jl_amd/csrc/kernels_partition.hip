@@ -1032,9 +1032,10 @@ constexpr int LDS_MAX_PROBES = 24;
 // SRC: where the signatures come from (see the Src* functors); INSERT_PER_THREAD entries per
 // thread and chunk (16 for the plain array, 8 for the computed sources: their loads and hashes
 // of one chunk are all live before the first probe)
-// THREADS: 256, or 1024 with a table of 8192 slots in dynamic LDS (128 KiB, one workgroup per CU, 16 waves): the mid regime of
-// 1024 .. 4096 classes, whose signatures all stay resident in the workgroup's table (with 2048 slots they thrash it and
-// every entry goes to the global table: 0.5 ms at 3000 classes, N = 4096)
+// (Round 4 measured a 1024-thread instance with an 8192-slot table in dynamic LDS for the mid regime of 1024 .. 4096
+// classes, where the 2048-slot table thrashes and every entry goes to the L2-resident global table: 306 us against 316 us
+// for the insert pass at 3000 classes, N = 4096 -- with thousands of distinct signatures the lookups are random LDS
+// accesses, 4-5 lanes per bank, and cost what the L2 lookups cost; removed.  THREADS stays a parameter.)
 template <class SRC, int INSERT_PER_THREAD, int LDS_SLOTS, int THREADS = REFINE_THREADS>
 __global__ void __launch_bounds__(THREADS)
 refine_insert_kernel(int64_t len, const SRC src,
@@ -1721,16 +1722,7 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
         }
         case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;
         case SIG_CHAN_F32: launch_insert_chan<float>(s, gcap, len, q, slot, ws, cap); break;
-        default:
-            if (ws.log2cap >= 14 && ws.log2cap <= 15) {  // 1024 < classes <= 4096 expected: the whole partition fits the big LDS table
-                const int64_t nchunk = (len + 1024 * 4 - 1) / (1024 * 4);
-                const int g = (int)(nchunk < 256 ? nchunk : 256);
-                refine_insert_kernel<SrcArray, 4, 8192, 1024><<<g, 1024, 8192 * 16, s>>>(len, SrcArray{q.sig}, slot, (unsigned long long*)ws.tab_sig,
-                                                                                       ws.tab_min, (uint32_t)(cap - 1), ws.counters);
-            } else {
-                launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap);
-            }
-            break;
+        default: launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap); break;
     }
     const int g2 = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
     // ws.expect_small: the host predicts <= SMALL_K classes (from the previous refinement) and
@@ -1971,7 +1963,6 @@ __global__ void reduce_columns_final_kernel(int64_t nchunks, int m, int d, const
 }
 // per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes)
 void partition_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_kernel<SrcArray, 4, 8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }

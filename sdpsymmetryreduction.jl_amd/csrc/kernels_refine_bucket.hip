@@ -287,9 +287,11 @@ bk_resolve_kernel(int NB, const uint32_t* __restrict__ bstart, const uint64_t* _
             }
         }
         if (done) continue;
-        // ---- large or crowded bucket: sub-passes over its entries by further hash bits, two sweeps each ----
+        // ---- large or crowded bucket: sub-passes over its entries by further hash bits, two sweeps each.  The number of
+        // sub-passes follows the DISTINCT signatures, not the entries (a bucket of 260 000 entries of one class -- a
+        // refinement that ends with few classes on a ctx whose previous one ended with many -- is one sub-pass): start
+        // with one, double whenever a sub-pass overfills the table ----
         uint32_t npass = 1;
-        while (npass < 256 && (uint64_t)npass * (BK_TS / 2) < n) npass <<= 1;
         for (uint32_t sp = 0; sp < npass;) {
             __syncthreads();
             for (int i = threadIdx.x; i < BK_TS; i += BK_RTHREADS) {
@@ -301,13 +303,25 @@ bk_resolve_kernel(int NB, const uint32_t* __restrict__ bstart, const uint64_t* _
                 t_ovf = 0u;
             }
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += BK_RTHREADS) {
-                const uint64_t sg = bsig[s0 + i];
-                const uint64_t hh = bk_hash(sg);
-                if (((uint32_t)(hh >> 44) & (npass - 1)) != sp) continue;
-                const uint32_t idx = bidx[s0 + i];
-                const int sl = bk_table_insert(t_sig, &t_cnt, &t_ovf, sg, hh);
-                if (sl >= 0 && t_min[sl] > idx) atomicMin(&t_min[sl], idx);
+            for (uint32_t i0 = 0; i0 < n; i0 += 8 * BK_RTHREADS) {  // chunks of 2048 entries; an overfull table stops the sweep
+                uint64_t sgs[8];
+                uint32_t ixs[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {  // all of the chunk's loads in flight before the first probe
+                    const uint32_t i = i0 + q * BK_RTHREADS + threadIdx.x;
+                    sgs[q] = i < n ? bsig[s0 + i] : 0ull;
+                    ixs[q] = i < n ? bidx[s0 + i] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (!sgs[q]) continue;
+                    const uint64_t hh = bk_hash(sgs[q]);
+                    if (((uint32_t)(hh >> 44) & (npass - 1)) != sp) continue;
+                    const int sl = bk_table_insert(t_sig, &t_cnt, &t_ovf, sgs[q], hh);
+                    if (sl >= 0 && t_min[sl] > ixs[q]) atomicMin(&t_min[sl], ixs[q]);
+                }
+                __syncthreads();
+                if (t_ovf) break;  // uniform
             }
             __syncthreads();
             if (t_ovf) {  // uniform: more distinct signatures in this sub-pass than the table takes: split finer, start over
@@ -316,15 +330,25 @@ bk_resolve_kernel(int NB, const uint32_t* __restrict__ bstart, const uint64_t* _
                 sp = 0;
                 continue;
             }
-            for (uint32_t i = threadIdx.x; i < n; i += BK_RTHREADS) {
-                const uint64_t sg = bsig[s0 + i];
-                const uint64_t hh = bk_hash(sg);
-                if (((uint32_t)(hh >> 44) & (npass - 1)) != sp) continue;
-                const uint32_t idx = bidx[s0 + i];
-                uint32_t sl = (uint32_t)(hh >> 32) & (BK_TS - 1);
-                while (t_sig[sl] != sg) sl = (sl + 1) & (BK_TS - 1);
-                const uint32_t m = t_min[sl];
-                if (m != idx) first[idx] = m;
+            for (uint32_t i0 = 0; i0 < n; i0 += 8 * BK_RTHREADS) {
+                uint64_t sgs[8];
+                uint32_t ixs[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t i = i0 + q * BK_RTHREADS + threadIdx.x;
+                    sgs[q] = i < n ? bsig[s0 + i] : 0ull;
+                    ixs[q] = i < n ? bidx[s0 + i] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (!sgs[q]) continue;
+                    const uint64_t hh = bk_hash(sgs[q]);
+                    if (((uint32_t)(hh >> 44) & (npass - 1)) != sp) continue;
+                    uint32_t sl = (uint32_t)(hh >> 32) & (BK_TS - 1);
+                    while (t_sig[sl] != sgs[q]) sl = (sl + 1) & (BK_TS - 1);
+                    const uint32_t m = t_min[sl];
+                    if (m != ixs[q]) first[ixs[q]] = m;
+                }
             }
             ++sp;
         }

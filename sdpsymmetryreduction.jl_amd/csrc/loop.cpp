@@ -37,6 +37,9 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
     PhaseTimer tm(c, phase_ms != nullptr);
     TotalEvents ev_total(phase_ms != nullptr, s);
 
+    // the table-size hint left by the previous call describes ITS final partition; this call starts from the few classes
+    // of (C_L, X0) again (a stale "many classes" hint would send the first refinements down the bucketed path)
+    c->table_log2_hint = 12;
     const double* dCL = in_dev(c, "adm_cl", CL, len, mem, &st);
     const double* dX0 = in_dev(c, "adm_x0", X0L, len, mem, &st);
     const double* dU = in_dev(c, "adm_u", U, (size_t)len * std::max<int64_t>(r, 1), mem, &st);
