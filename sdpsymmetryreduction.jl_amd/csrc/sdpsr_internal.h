@@ -79,9 +79,15 @@ struct sdpsr_ctx {
 // Host wait for a stream of ctx c (every wait of the library goes through here).
 inline hipError_t ctx_sync_stream(sdpsr_ctx* c, hipStream_t s) {
     if (!c || !c->yield_fn) return hipStreamSynchronize(s);
+    bool waited = false;
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
-        if (e != hipErrorNotReady) return e;
+        if (e != hipErrorNotReady) {
+            // "not ready" is an answer, not a failure: it must not be what a later hipGetLastError() of this thread reports
+            if (waited && e == hipSuccess) (void)hipGetLastError();
+            return e;
+        }
+        waited = true;
         c->yield_fn(c->yield_arg);
     }
 }

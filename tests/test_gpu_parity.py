@@ -791,6 +791,38 @@ def test_error_paths(pkg, problems, golden):
         assert sorted(bd.blkSizes) == list(golden["er3_blk"])
 
 
+def test_batch_error_paths(pkg, problems):
+    """sdpsr_jordan_reduce_batch: bad restart counts are BAD_ARGUMENT; a restart that fails reports ITS status (here
+    NOT_CONVERGED under an iteration cap of 1 on ER(7), which needs 5 iterations) in status[i] and as the call's return
+    value (or, as sdpsr_jordan_reduce does, the failure of blockDiagonalize on the unconverged partition), and the ctx (and the restarts' ctxs inside it) stay usable:
+    the same call without the cap succeeds afterwards on a fresh ctx sharing nothing; sdpsr_square_i8_symmetric rejects
+    null pointers and batch sizes outside 1..8."""
+    Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(7))
+    setup = pkg.admissible_setup(Cv, A, b)
+    n, CL, X0L, U = setup
+    Uf = np.asfortranarray(U)
+    with pkg.Context(seed=3) as ctx:
+        lib = ctx._lib
+        dd, st = (C.c_int64 * 2)(), (C.c_int32 * 2)()
+        args = (C.c_void_p(CL.ctypes.data), C.c_void_p(X0L.ctypes.data), C.c_void_p(Uf.ctypes.data), U.shape[1], 1.5e-8, 1.5e-8)
+        for R in (0, 65):
+            assert lib.sdpsr_jordan_reduce_batch(ctx._h, R, None, n, *args, None, dd, None, None, None, None, None, None, st, 0) == 5
+        assert lib.sdpsr_jordan_reduce_batch(ctx._h, 2, None, n, *args, None, None, None, None, None, None, None, None, st, 0) == 5
+        x = np.zeros(16, dtype=np.int8)
+        o = np.zeros(16, dtype=np.int32)
+        assert lib.sdpsr_square_i8_symmetric(ctx._h, 4, 0, C.c_void_p(x.ctypes.data), C.c_void_p(o.ctypes.data), 0) == 5
+        assert lib.sdpsr_square_i8_symmetric(ctx._h, 4, 9, C.c_void_p(x.ctypes.data), C.c_void_p(o.ctypes.data), 0) == 5
+        assert lib.sdpsr_square_i8_symmetric(ctx._h, 4, 1, None, C.c_void_p(o.ctypes.data), 0) == 5
+    with pkg.Context(seed=3, max_iters=1) as ctx:
+        res = pkg.jordan_reduce_batch(Cv, A, b, restarts=2, seeds=[1, 2], ctx=ctx, setup=setup)
+        # the loop stops unconverged; blockDiagonalize then runs on a partition that is not an algebra: its own failure
+        # (DimensionMismatch / NumericalInconsistency) or, had it passed, NOT_CONVERGED -- per restart, never OK
+        assert all(x["status"] in (2, 3, 9) for x in res), [x["status"] for x in res]
+    with pkg.Context(seed=3) as ctx:
+        res = pkg.jordan_reduce_batch(Cv, A, b, restarts=2, seeds=[1, 2], ctx=ctx, setup=setup)
+        assert [x["status"] for x in res] == [0, 0] and all(x["P"].nparts == 18 for x in res)
+
+
 # ------------------------------------------------ ctx contract (include/sdpsr.h:20-25)
 def test_two_contexts_from_two_threads(pkg, golden):
     """Distinct ctxs may be driven from distinct host threads (no process-global state: kernel
