@@ -77,16 +77,18 @@ extern "C" int sdpsr_jordan_reduce_batch(sdpsr_ctx* c, int32_t R, const uint64_t
     Sched sched;
     sched.fibers.resize(R);
     std::vector<sdpsr_ctx*> ctxs(R);
+    for (int i = 0; i < R; ++i) {  // everything that can fail first: no ctx is switched to fiber waits before all stacks exist
+        ctxs[i] = i == 0 ? c : c->batch_children[i - 1];
+        sched.fibers[i].stack.reset(new (std::nothrow) char[kFiberStack]);
+        if (!sched.fibers[i].stack) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "fiber stack");
+    }
     for (int i = 0; i < R; ++i) {
-        sdpsr_ctx* ci = i == 0 ? c : c->batch_children[i - 1];
-        ctxs[i] = ci;
+        sdpsr_ctx* ci = ctxs[i];
         if (seeds) sdpsr_set_seed(ci, seeds[i]);
         ci->hint_symmetric_basis = hint;
         status[i] = SDPSR_OK;
         Fiber& f = sched.fibers[i];
         f.sched = &sched;
-        f.stack.reset(new (std::nothrow) char[kFiberStack]);
-        if (!f.stack) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "fiber stack");
         f.body = [=]() {
             return sdpsr_jordan_reduce(ci, n, CL, X0L, U, r, atol, epsilon, P_out ? P_out[i] : nullptr, dim_out + i,
                                        iters_out ? iters_out + i : nullptr, nblocks ? nblocks + i : nullptr, sum_sq ? sum_sq + i : nullptr,

@@ -238,7 +238,7 @@ __device__ __forceinline__ int bk_table_insert(unsigned long long* t_sig, uint32
 constexpr int BK_RPER = 12;  // entries per thread of the one-sweep form (<= 3072 per bucket: the table's 75 %)
 __global__ void __launch_bounds__(BK_RTHREADS)
 bk_resolve_kernel(int NB, const uint32_t* __restrict__ bstart, const uint64_t* __restrict__ bsig, const uint32_t* __restrict__ bidx,
-                  uint32_t* __restrict__ first) {
+                  uint32_t* __restrict__ first, uint32_t* __restrict__ fail) {
     __shared__ unsigned long long t_sig[BK_TS];
     __shared__ uint32_t t_min[BK_TS];
     __shared__ uint32_t t_cnt, t_ovf;
@@ -325,7 +325,10 @@ bk_resolve_kernel(int NB, const uint32_t* __restrict__ bstart, const uint64_t* _
             }
             __syncthreads();
             if (t_ovf) {  // uniform: more distinct signatures in this sub-pass than the table takes: split finer, start over
-                if (npass >= 256) return;  // (2^8 sub-passes of 3072 distinct signatures each: beyond any bucket of < 2^31 / 2^4 entries)
+                if (npass >= 256) {  // 2^8 sub-passes of 3072 distinct signatures each in ONE bucket: the hash bits do not spread
+                    if (threadIdx.x == 0) *fail = 1u;  // these signatures; reported (counters[1]), never a silently wrong partition
+                    return;
+                }
                 npass <<= 1;
                 sp = 0;
                 continue;
@@ -431,9 +434,9 @@ bk_label_first_kernel(int64_t len, const uint32_t* __restrict__ first, const uin
 __global__ void __launch_bounds__(256)
 bk_label_rest_kernel(int64_t len, const uint32_t* __restrict__ first, uint32_t* labels, const uint32_t* __restrict__ total, uint32_t* __restrict__ counters) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t d = *total;
+        const uint32_t d = total[0];
         counters[0] = d;
-        counters[1] = 0u;
+        counters[1] = total[1];  // the resolver's failure word
         counters[2] = d;
     }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -470,7 +473,8 @@ size_t refine_bucketed_workspace_bytes(int64_t len) {
     return (size_t)len * 28 + (size_t)((1 << BK_MAX_LGT) + 1) * 4 * 3 + (size_t)(nrb + 1) * 4 + 1024 + 12 * 256;
 }
 
-// labels_out: canonical labels; counters[0] = counters[2] = number of classes, counters[1] = 0; first_idx (may be null):
+// labels_out: canonical labels; counters[0] = counters[2] = number of classes, counters[1] = 0 (1: a bucket could not be resolved,
+// labels_out is then not a partition of the input and the caller must fail); first_idx (may be null):
 // first-occurrence index of class l at [l - 1] for l <= first_cap
 bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
                             uint32_t* counters, uint32_t* first_idx, uint32_t first_cap) {
@@ -501,7 +505,7 @@ bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uin
     uint32_t* blk_cnt = (uint32_t*)p;
     p = align(p + (size_t)(nrb + 1) * 4);
     uint32_t* total = (uint32_t*)p;
-    if (hipMemsetAsync(start, 0, (size_t)(nbt + 1) * 4, s) != hipSuccess) return false;
+    if (hipMemsetAsync(start, 0, (size_t)(nbt + 1) * 4, s) != hipSuccess || hipMemsetAsync(total, 0, 8, s) != hipSuccess) return false;
     const int cgrid = (int)std::min<int64_t>((len + 1023) / 1024, 512);
     bk_count_kernel<<<cgrid, 1024, (size_t)nbt * 4, s>>>(len, sig, lgt, start, first);
     bk_scan_kernel<<<1, 1024, 0, s>>>(nbt, start, start + nbt);
@@ -517,7 +521,7 @@ bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uin
         bidx = idxB;
     }
     const int rgrid = (int)std::min<int64_t>(nbt, 256 * 3);
-    bk_resolve_kernel<<<rgrid, BK_RTHREADS, 0, s>>>((int)nbt, start, bsig, bidx, first);
+    bk_resolve_kernel<<<rgrid, BK_RTHREADS, 0, s>>>((int)nbt, start, bsig, bidx, first, total + 1);
     bk_first_count_kernel<<<(unsigned)nrb, 256, 0, s>>>(len, first, blk_cnt);
     bk_scan_kernel<<<1, 1024, 0, s>>>(nrb, blk_cnt, total);
     bk_label_first_kernel<<<(unsigned)nrb, 256, 0, s>>>(len, first, blk_cnt, labels_out, first_idx, first_cap);

@@ -77,6 +77,7 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
             HIP_TRY(c, ctx_sync_stream(c, c->stream));
             if (sym_n > 0 && symflag_dev && sym_out) *sym_out = h[8] ? 0 : 1;
             HIP_TRY(c, hipGetLastError());
+            if (h[1]) return ctx_fail(c, SDPSR_HIP_ERROR, "bucketed refinement: a hash bucket could not be resolved (signatures that do not spread)");
             *nparts = h[2];
             c->table_log2_hint = std::min(full, std::max(12, ceil_log2((uint64_t)h[2] * 8 + 1)));
             if (!cub && h[2] <= refine_first_cap()) c->first_idx_labels = labels;  // "ref_first" describes these labels

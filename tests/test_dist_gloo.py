@@ -63,6 +63,13 @@ def _worker(rank, world, port, q):
     res["lowest_rank_wins"] = win0 == 0 and s0 == [5]
     winx, sx, _ = par.agree_block_diagonalization(2, [1])
     res["all_failed"] = winx == -1 and sx is None
+    # more block sizes than the one-collective record holds (QAP-type partitions have a few dozen blocks; 100 here): every
+    # rank must fall through to the all-reduce + broadcast form together, also the rank whose own list is short / failed
+    big = list(range(1, 101))
+    winb, sb, _ = par.agree_block_diagonalization(0 if rank == 1 else 3, big if rank == 1 else [7])
+    res["long_form"] = winb == 1 and sb == big
+    winc, sc, _ = par.agree_block_diagonalization(0, big if rank == 0 else [7, 7])
+    res["long_form_rank0_wins"] = winc == 0 and sc == big
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
