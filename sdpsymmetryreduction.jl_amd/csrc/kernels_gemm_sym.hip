@@ -2,8 +2,8 @@
 // the refinement loop:   mul!(X2, X, X)   src/partitions.jl:172
 //
 // One PERSISTENT launch: at most one workgroup per CU (8 waves, 128 KiB of LDS), every workgroup walks a static list of
-// jobs.  Why not the 128 x 128 tiles of kernels_gemm.hip (round 3's product launch, 92 us at N = 4096, 2 channels):
-// its counters (profiles/r04_pmc.json, i8x2_lower_counters) say a tile takes 62.7 k clocks where its 512 MFMAs per wave
+// jobs.  Why not the 128 x 128 tiles of kernels_gemm.hip (round 3's product launch, 92 - 98 us at N = 4096, 2 channels):
+// its counters (profiles/r04_pmc.json, i8x2_lower_128tiles_counters) say a tile takes 62.7 k clocks where its 512 MFMAs per wave
 // need 32.8 k (two workgroups per CU), because the global -> LDS feed is at its per-CU limit -- 64 KiB per K-tile of
 // 128 bytes and CU in 1960 clocks = 33 B/clk/CU = 70 GB/s per CU, the rate MI355X_MICROARCH.md gives for LDS gathers
 // served by the L2 -- and that the 1056 tiles take three rounds on the 512 resident slots although they are 2.06 rounds
@@ -11,8 +11,14 @@
 //   * 256 x 256 macro-tiles (a wave owns 128 x 64): half the feed bytes per MFMA, 32 B/clk/CU at the full MFMA rate;
 //   * the diagonal macro-tiles two per job, their 2 x 36 lower 32 x 32 blocks dealt 9 to a wave (a "full" wave has 8), so
 //     that N = 4096, 2 channels is 240 + 16 = 256 jobs of 1.0 / 1.125 tile times: ONE round on 256 CUs, no tail;
-//   * the K walk in a ring of LDS stages filled by LDS-DMA with counted waits (vmcnt(N), never a drain inside the
-//     loop), so the feed does not idle between a stage's arrival and the next issue.
+//   * quarter tiles (128 x 128, 8 waves of 64 x 32) for the ragged last 128 rows of an order that is an odd multiple of
+//     128 (N = 4104 -> 4224: 256 big jobs + 66 quarter tiles in a short second round);
+//   * the K walk in a ring of four 64-byte LDS stages filled by LDS-DMA with counted waits (vmcnt(N), never a drain
+//     inside the loop), so the feed does not idle between a stage's arrival and the next issue.
+// 76 - 78 us at N = 4096, 2 channels (0.36 of the nominal int8 peak, MfmaUtil 0.40, 193 MB moved for 168 MB algorithmic).
+// Where the rest goes, from ablation builds (profiles/r04_i8sym_ablation.txt): the MFMAs alone take 46 us (the matrix
+// pipe under random int8 operands runs at ~1.6 GHz under the board's power cap), fragment reads + barriers add 7, the
+// DMA 14, the 69 MB of results 9.5 -- the stages add up instead of overlapping, which is what a power budget does.
 // The device flag decides as before: *nonsym_flag != 0 => every macro-tile of the full squares (no diagonal jobs).
 //
 // Exact integers (int32 accumulation of int8 products, |sum| <= 2^14 ld): the order in which K is consumed is free.

@@ -33,6 +33,8 @@ def test_opts_struct_layout(pkg):
     L = pkg._lib
     assert C.sizeof(L.Opts) == 64
     assert L.Opts.flags.offset == 24 and L.Opts.round_mode.offset == 28 and L.Opts.label_bits.offset == 40
+    assert L.Opts.square_kernel.offset == 48 and L.Opts.reserved.offset == 52  # ABI 0.4: one more reserved word named
+    assert "bucket" in L.REFINE_PATHS and L.REFINE_PATHS["bucket"] == 3
     hdr = open(L.HEADER_PATH).read()
     for name, val in (("SEPARATE_REFINEMENTS", L.FLAG_SEPARATE_REFINEMENTS), ("FRESH_IRREDUCIBLE_ELEMENT", L.FLAG_FRESH_IRREDUCIBLE_ELEMENT),
                       ("ALWAYS_REORTHOGONALIZE", L.FLAG_ALWAYS_REORTHOGONALIZE), ("REFINE_NO_FUSE", L.FLAG_REFINE_NO_FUSE),
