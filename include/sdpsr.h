@@ -372,7 +372,8 @@ int sdpsr_jordan_reduce(sdpsr_ctx* ctx, int64_t n, const double* CL, const doubl
      dim_out .. sum_s  arrays of R entries (iters_out, nblocks, sum_sq, sum_s may be NULL);
      status[R]       per restart, the status sdpsr_jordan_reduce would have returned.
    Returns SDPSR_OK if every restart did, else the first restart's failure.  A hint given with
-   sdpsr_hint_symmetric_basis applies to all R restarts.  No threads are created; do not call it from two host threads
+   sdpsr_hint_symmetric_basis applies to all R restarts, and so does the ordering of ctx's stream (sdpsr_wait_stream,
+   sdpsr_set_stream): every restart's stream starts behind what ctx's stream has been ordered behind.  No threads are created; do not call it from two host threads
    on one ctx. */
 int sdpsr_jordan_reduce_batch(sdpsr_ctx* ctx, int32_t R, const uint64_t* seeds, int64_t n, const double* CL, const double* X0L,
                               const double* U, int64_t r, double atol, double epsilon, uint32_t* const* P_out, int64_t* dim_out,

@@ -82,6 +82,12 @@ extern "C" int sdpsr_jordan_reduce_batch(sdpsr_ctx* c, int32_t R, const uint64_t
         sched.fibers[i].stack.reset(new (std::nothrow) char[kFiberStack]);
         if (!sched.fibers[i].stack) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "fiber stack");
     }
+    // the restarts' streams inherit what the caller has ordered before ctx's stream (sdpsr_wait_stream / a shared stream):
+    // device-resident inputs produced by the caller's own kernels are complete for every restart, not only for restart 0
+    for (int i = 1; i < R; ++i) {
+        const int st = sdpsr_wait_stream(ctxs[i], c->stream);
+        if (st) return ctx_fail(c, st, "sdpsr_jordan_reduce_batch: could not order a restart's stream behind the ctx's");
+    }
     for (int i = 0; i < R; ++i) {
         sdpsr_ctx* ci = ctxs[i];
         if (seeds) sdpsr_set_seed(ci, seeds[i]);

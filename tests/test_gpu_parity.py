@@ -878,6 +878,36 @@ def test_device_inputs_from_an_async_torch_kernel(pkg, problems, golden):
             del junk
 
 
+def test_batch_device_inputs_from_an_async_torch_kernel(pkg, problems, golden):
+    """The same ordering rule for sdpsr_jordan_reduce_batch: the inputs are produced by torch kernels queued behind a long
+    GEMM; ctx's stream is ordered behind torch's (sdpsr_wait_stream) and EVERY restart's stream must inherit that -- a
+    restart that started early would read unfinished inputs and end on another partition."""
+    import torch
+    Cv, A, b = problems.theta_prime_problem(problems.er_graph_adjacency(7))
+    n, CL, X0L, U = pkg.admissible_setup(Cv, A, b)
+    dev = torch.device("cuda:0")
+    big = torch.randn(6144, 6144, device=dev)
+    R = 3
+    gold = torch.from_numpy(np.ascontiguousarray(golden["er7_P"].ravel(order="F")).astype(np.int32)).to(dev)
+    with pkg.Context(seed=5) as ctx:
+        lib = ctx._lib
+        for rep in range(3):
+            junk = big @ big
+            tCL = torch.from_numpy(CL).to(dev) + junk[0, 0] * 0.0  # queued behind the GEMM
+            tX0 = torch.from_numpy(X0L).to(dev) * 1.0
+            tU = (torch.from_numpy(np.ascontiguousarray(U.T)).to(dev) + junk[1, 1] * 0.0).contiguous()
+            tPs = [torch.zeros(n * n, dtype=torch.int32, device=dev) for _ in range(R)]
+            ctx.check(lib.sdpsr_wait_stream(ctx._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            pP = (C.c_void_p * R)(*[t.data_ptr() for t in tPs])
+            dd, st = (C.c_int64 * R)(), (C.c_int32 * R)()
+            lib.sdpsr_jordan_reduce_batch(ctx._h, R, None, n, C.c_void_p(tCL.data_ptr()), C.c_void_p(tX0.data_ptr()), C.c_void_p(tU.data_ptr()), U.shape[1],
+                                          1.5e-8, 1.5e-8, C.cast(pP, C.c_void_p), dd, None, None, None, None, None, None, st, 1)
+            for i in range(R):
+                assert st[i] in (0, 2, 3), st[i]  # blockDiagonalize may fail at random; the partition must be right
+                assert dd[i] == 18 and bool((tPs[i] == gold).all()), (rep, i)
+            del junk
+
+
 def test_sort_based_refine_matches_oracle(pkg, oracle):
     """The relabels of the many-classes regime -- the hand-written bucketed grouping (kernels_refine_bucket.hip, the
     default there) and hipCUB's radix sort (kernels_refine_sort.hip, comparison) -- against the oracle's canonical
