@@ -121,7 +121,11 @@ enum {
        block is 1 x 1, the images are read off as eigenvalues, blks[i][k] = q_k'(1[P==i] x) with x = sum_k q_k, under
        a randomized self-check that falls back to the projection formula (see sdpsr_block_images) */
     SDPSR_FLAG_FULL_BASIS_IMAGE = 1u << 10,
-    /* (1u << 11: unused) */
+    /* admissible_subspace: run the projection half of every iteration (src/partitions.jl:159-164).  By default, once every
+       basis matrix U_k is found constant on the classes of S (checked on the device after a refinement), that half is
+       skipped for the rest of the call: x - U U'x of a class-constant x is then class-constant for every x, it cannot
+       refine S any more (see sdpsr_admissible_subspace) */
+    SDPSR_FLAG_ALWAYS_PROJECT = 1u << 11,
     /* dense driver: the panel form of the tridiagonalisation (two launches per column, rank-64 trailing updates on
        the matrix cores) at every order; by default orders <= 2048 take the one-launch-per-column row form */
     SDPSR_FLAG_SYTRD_PANELS = 1u << 12,
@@ -290,7 +294,13 @@ int sdpsr_gemm_tn_f64(sdpsr_ctx* ctx, int64_t m, int64_t n, int64_t k, const dou
    partition (the smallest partition subspace containing C_L and X0 that is closed under the
    projection and under squaring; P_out is canonical, so it is the same matrix); *iters_out counts
    joint steps (equal to the reference-structured count on every test problem).
-   sdpsr_opts.flags & SDPSR_FLAG_SEPARATE_REFINEMENTS restores two refinements per iteration. */
+   sdpsr_opts.flags & SDPSR_FLAG_SEPARATE_REFINEMENTS restores two refinements per iteration.
+   In that joint form the projection half of an iteration is SKIPPED once it can no longer refine anything: when every
+   basis matrix U_k is constant on every class of the current partition S (compared on the device through the rounding of
+   _clamp_round!, :159-164), x - U U'x of any x that is constant on the classes of S is constant on them too -- U_k in
+   span(S) implies U U'x in span(S) -- and every finer partition inherits that; generically it holds right after the first
+   projection refinement.  The partition returned is the same; SDPSR_FLAG_ALWAYS_PROJECT keeps the projection in every
+   iteration. */
 int sdpsr_admissible_subspace(sdpsr_ctx* ctx, int64_t n, const double* CL, const double* X0L,
                               const double* U, int64_t r, double atol, uint32_t* P_out,
                               int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem);

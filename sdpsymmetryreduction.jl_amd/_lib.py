@@ -29,6 +29,7 @@ FLAG_SMALL_EIGEN_ON_DEVICE = 1 << 7
 FLAG_NO_GRAPH = 1 << 8
 FLAG_NO_VERIFY_SHORTCUT = 1 << 9
 FLAG_FULL_BASIS_IMAGE = 1 << 10
+FLAG_ALWAYS_PROJECT = 1 << 11
 FLAG_SYTRD_PANELS = 1 << 12
 FLAG_COUPLING_ON_HOST = 1 << 13
 BASIS_IMAGE_KERNELS = {"auto": 0, "two_stage": 1, "outer": 2, "chunk": 3}

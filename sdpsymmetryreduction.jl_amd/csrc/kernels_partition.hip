@@ -1613,6 +1613,70 @@ static void launch_verify_rt(hipStream_t s, const SigSource& q, int64_t d, const
                                                       (const VerifyRef*)ref, flag);
 }
 size_t verify_ref_bytes(int64_t d) { return (size_t)(d > 0 ? d : 1) * sizeof(VerifyRef); }
+
+// "Can the projection step still split a class?"  x - U U'x of an x that is constant on the classes of S is constant on
+// them for EVERY x exactly when every basis matrix U_k is (U_k in span(S) => U U'x in span(S)), and a finer S keeps the
+// property: once it holds, the projection half of the loop (src/partitions.jl:159-164) cannot refine S any more.  The
+// check compares the rounded codes of U_k (the rounding of the projection's own signatures, sdpsr_round_key) at every
+// entry of the packed lower triangle with those at the class representative (first_idx, as the verify pass); label 0
+// (structural zeros) needs U_k = 0.  flag[0] = 1 <=> some U_k is NOT constant on some class.
+template <int R>
+__global__ void uconst_ref_kernel(int n, int d, const uint32_t* __restrict__ first_idx, const double* __restrict__ U, double atol, double scale,
+                                  uint64_t* __restrict__ ref, uint32_t* __restrict__ flag) {
+    const int cls = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cls == 0) flag[0] = 0u;
+    if (cls >= d) return;
+    uint32_t i, j;
+    packed_lower_ij(n, (int64_t)first_idx[cls], i, j);
+    const int64_t ef = (int64_t)i + (int64_t)j * n;
+#pragma unroll
+    for (int k = 0; k < R; ++k) ref[(int64_t)cls * R + k] = sdpsr_round_key(U[(int64_t)k * n * n + ef], atol, scale);
+}
+template <int R>
+__global__ void __launch_bounds__(256)
+uconst_check_kernel(int n, const uint32_t* __restrict__ Lp, const double* __restrict__ U, double atol, double scale,
+                    const uint64_t* __restrict__ ref, uint32_t* __restrict__ flag) {
+    bool bad = false;
+    const int64_t nn = (int64_t)n * n;
+    const uint64_t zero_code = sdpsr_round_key(0.0, atol, scale);
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        const int64_t poff = (int64_t)j * n - (int64_t)j * (j - 1) / 2 - j;
+        const uint32_t* Lj = Lp + poff;
+        const double* Uj = U + (int64_t)j * n;
+#pragma unroll 2
+        for (int i = j + threadIdx.x; i < n; i += 256) {
+            const uint32_t l = __builtin_nontemporal_load(&Lj[i]);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const uint64_t code = sdpsr_round_key(__builtin_nontemporal_load(&Uj[(int64_t)k * nn + i]), atol, scale);
+                bad = bad || code != (l ? ref[(int64_t)(l - 1) * R + k] : zero_code);
+            }
+        }
+    }
+    if (bad) flag[0] = 1u;
+}
+size_t uconst_ref_bytes(int64_t d, int64_t r) { return (size_t)(d > 0 ? d : 1) * (size_t)(r > 0 ? r : 1) * 8; }
+// symmetric basis matrices U_k (n x n, column-major, r <= 4 of them), packed labels Lp of d <= REFINE_FIRST_CAP classes
+// with their representatives first_idx; flag: a word the device can write (pinned host memory)
+bool launch_basis_constant_on_classes(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* Lp, int64_t d,
+                                      const uint32_t* first_idx, double atol, double scale, void* ref, uint32_t* flag) {
+    if (r < 1 || r > 4 || d < 1 || d > (int64_t)REFINE_FIRST_CAP) return false;
+    const unsigned gr = (unsigned)((d + 255) / 256);
+    const int g = n < 256 * 8 ? (int)n : 256 * 8;
+#define SDPSR_UCONST_CASE(RR)                                                                                          \
+    case RR:                                                                                                           \
+        uconst_ref_kernel<RR><<<gr, 256, 0, s>>>((int)n, (int)d, first_idx, U, atol, scale, (uint64_t*)ref, flag);      \
+        uconst_check_kernel<RR><<<g, 256, 0, s>>>((int)n, Lp, U, atol, scale, (const uint64_t*)ref, flag);              \
+        break;
+    switch (r) {
+        SDPSR_UCONST_CASE(1)
+        SDPSR_UCONST_CASE(2)
+        SDPSR_UCONST_CASE(3)
+        SDPSR_UCONST_CASE(4)
+    }
+#undef SDPSR_UCONST_CASE
+    return true;
+}
 // q: SIG_JOINT_I32 or SIG_CHAN_I32 on the packed lower triangle with packed labels (q.L = Lp); flag[0] = verdict.
 // Returns false when there is no instance for the shape (the caller runs the refinement).
 bool launch_verify_no_split(hipStream_t s, const SigSource& q, int64_t d, const uint32_t* first_idx, void* ref, uint32_t* flag) {

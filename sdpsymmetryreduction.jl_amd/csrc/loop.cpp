@@ -138,6 +138,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
     const int64_t maximal = (len + n) / 2;  // :148
     int64_t current = d;
     int it = 0;
+    bool proj_dead = false;  // every U_k constant on the classes of S: the projection half cannot refine S any more
     int confirm_left = c->opts.confirm_rounds;
     bool converged = current >= maximal;
     while (current < maximal) {  // :154
@@ -160,10 +161,29 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
         if (!separate && packed_proj && keep_packed && (T == 2 || T == 4) && c->table_log2_hint < 21) {
             const bool jl = packed_valid;
             if (!jl) need_full();
+            // Is the projection half still able to split a class?  Not once every U_k is constant on the classes of S
+            // (kernels_partition.hip, launch_basis_constant_on_classes): x - U U'x of a class-constant x is then
+            // class-constant for every x, and a finer S keeps that.  Generically this holds after the first projection
+            // refinement (entries of a class with different U_k get different projected values); it is CHECKED, once per
+            // iteration until it holds, on the labels the last refinement made, and from then on the iteration is the
+            // square alone: no dot-product pass over U, signatures from the channel values only.
+            if (!proj_dead && it >= 2 && r >= 1 && jl && c->first_idx_labels == Lp && current >= 1 && current <= (int64_t)refine_first_cap() &&
+                !(c->opts.flags & SDPSR_FLAG_ALWAYS_PROJECT)) {
+                void* uref = ctx_buf(c, "adm_uref", uconst_ref_bytes(current, r));
+                const uint32_t* first = (const uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
+                uint32_t* hv = (uint32_t*)ctx_pinned(c, 1024);
+                if (!uref || !first || !hv) return SDPSR_OUT_OF_MEMORY;
+                hv += 192;  // its own pinned word (refinement counters at 0, verify verdict at 128)
+                if (launch_basis_constant_on_classes(s, n, r, dU, Lp, current, first, atol, scale, uref, hv)) {
+                    HIP_TRY(c, ctx_sync_stream(c, s));
+                    HIP_TRY(c, hipGetLastError());
+                    proj_dead = hv[0] == 0;
+                }
+            }
             // (Round 3 measured this dot-product pass on the side stream BESIDE the channel gather and the int8 square -- two
             // independent readers of the same labels: theta_c32xk128 477 against 480 reductions/s in sequence, closed_scheme
             // 1016 against 1028.  The square slows by what the overlapped pass takes from it; kept in sequence.)
-            launch_proj_coef_lower(s, n, r, dU, jl ? Lp : L, jl ? 1 : 0, key, partial, nblk, coef);
+            if (!proj_dead) launch_proj_coef_lower(s, n, r, dU, jl ? Lp : L, jl ? 1 : 0, key, partial, nblk, coef);
             tm.end();
             int64_t dj = current;
             bool confirming = false;  // this round repeats the square after a round that did not refine
@@ -177,7 +197,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                 tm.end();
                 tm.begin(SDPSR_T_REFINE);
                 SigSource qj;
-                qj.kind = SIG_JOINT_I32;
+                qj.kind = proj_dead ? SIG_CHAN_I32 : SIG_JOINT_I32;  // projection dead: the square's channel values alone
                 qj.sig = sig;
                 qj.U = dU;
                 qj.coef = coef;
@@ -192,6 +212,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                 qj.packed = 1;
                 qj.L = jl2 ? Lp : L;
                 qj.lab_packed = jl2 ? 1 : 0;
+                qj.zero_flag = zero_flag;  // (the stand-alone channel signatures of a materialised source read it)
                 // Rounds that are expected NOT to refine -- a confirm round, and the first iteration (an
                 // input that is closed already) -- first ask the cheap question "does any entry differ
                 // from the representative of its class?" (one streaming compare pass, kernels_partition.hip

@@ -203,6 +203,9 @@ struct SigSource {
 bool sig_source_fusable(const SigSource& q);
 uint32_t refine_first_cap();
 size_t verify_ref_bytes(int64_t d);
+size_t uconst_ref_bytes(int64_t d, int64_t r);
+bool launch_basis_constant_on_classes(hipStream_t s, int64_t n, int64_t r, const double* U, const uint32_t* Lp, int64_t d,
+                                      const uint32_t* first_idx, double atol, double scale, void* ref, uint32_t* flag);
 bool launch_verify_no_split(hipStream_t s, const SigSource& q, int64_t d, const uint32_t* first_idx, void* ref, uint32_t* flag);
 void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint64_t* sig);
 // slot: len entries of scratch; labels_out may alias q.L (it is written only by a pass that succeeded)

@@ -24,6 +24,15 @@ def load_package():
 
 @pytest.fixture(scope="session")
 def pkg():
+    # torch initialises its HIP side lazily, and on this image it reports "no ROCm-capable device" when it does so AFTER
+    # another library of the process has created streams on the device: let torch look at the GPU first, whatever subset
+    # of the tests runs (harmless on a CPU-only box: is_available() is False there)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # noqa: BLE001
+        pass
     return load_package()
 
 

@@ -791,6 +791,26 @@ def test_error_paths(pkg, problems, golden):
         assert sorted(bd.blkSizes) == list(golden["er3_blk"])
 
 
+@pytest.mark.parametrize("name", ["petersen", "er3", "er5", "er7", "esc16j"])
+def test_projection_skipped_once_the_basis_is_class_constant(pkg, problems, golden, name):
+    """Once every U_k is constant on the classes of S the projection half of the loop cannot refine S (x - U U'x stays in
+    span(S)); the loop checks that on the device and then iterates on the square alone.  Same canonical partition, same
+    iteration count and same dimension trajectory as with SDPSR_FLAG_ALWAYS_PROJECT (the projection in every iteration,
+    src/partitions.jl:159-164), over several seeds; both against the golden matrix."""
+    Cv, A, b = _problem(problems, name)
+    Lg = golden[f"{name}_P"].astype(np.int64)
+    setup = pkg.admissible_setup(Cv, A, b)
+    outs = {}
+    for flags in (0, pkg._lib.FLAG_ALWAYS_PROJECT):
+        outs[flags] = []
+        for seed in (1, 2, 3, 4):
+            with pkg.Context(seed=seed, flags=flags) as ctx:
+                P = pkg.admissible_subspace(Cv, A, b, ctx=ctx, setup=setup)
+                assert np.array_equal(P.matrix, Lg), (name, flags, seed)
+                outs[flags].append((P.iterations, tuple(P.dims)))
+    assert outs[0] == outs[pkg._lib.FLAG_ALWAYS_PROJECT], outs
+
+
 def test_batch_error_paths(pkg, problems):
     """sdpsr_jordan_reduce_batch: bad restart counts are BAD_ARGUMENT; a restart that fails reports ITS status (here
     NOT_CONVERGED under an iteration cap of 1 on ER(7), which needs 5 iterations) in status[i] and as the call's return
