@@ -132,7 +132,12 @@ enum {
     /* eigen_decomposition: the coupling matrix of the eigenspaces (block norms, src/eigen_decomposition.jl:177-217) is
        always read back and thresholded on the host; by default, from 256 eigenspaces on, its extrema, the histogram
        counts of the Otsu threshold and one bit per pair are formed on the device (same classes) */
-    SDPSR_FLAG_COUPLING_ON_HOST = 1u << 13
+    SDPSR_FLAG_COUPLING_ON_HOST = 1u << 13,
+    /* dense driver, orders in (2048, 8192]: the panel columns of the tridiagonalisation with ONE launch per column -- the
+       product is taken with the unnormalised column, the reflector is finished by the next launch, redundantly in every
+       tile (csrc/kernels_sytrd_look.hip).  Same results to rounding; measured slower than the two-launch form on MI355X
+       (DESIGN.md 4.1), kept for comparison */
+    SDPSR_FLAG_SYTRD_ONE_LAUNCH = 1u << 14
 };
 
 typedef struct sdpsr_opts {

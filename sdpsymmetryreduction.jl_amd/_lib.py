@@ -32,6 +32,7 @@ FLAG_FULL_BASIS_IMAGE = 1 << 10
 FLAG_ALWAYS_PROJECT = 1 << 11
 FLAG_SYTRD_PANELS = 1 << 12
 FLAG_COUPLING_ON_HOST = 1 << 13
+FLAG_SYTRD_ONE_LAUNCH = 1 << 14
 BASIS_IMAGE_KERNELS = {"auto": 0, "two_stage": 1, "outer": 2, "chunk": 3}
 REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2, "bucket": 3}
 

@@ -30,12 +30,27 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstdio>
+#include <vector>
 #include <cstdlib>
 
 #include "sdpsr_internal.h"
 #include "jacobi64.h"
 
 namespace sdpsr {
+
+// development aid (-DLK_TIMING): wall-clock stamps (100 MHz) of the phases of the form kernel's first / middle / last workgroup
+#ifdef LK_TIMING
+__device__ long long* sy_dbg = nullptr;
+#define SY_STAMP(i)                                                                                                   \
+    do {                                                                                                               \
+        if (sy_dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.x == gridDim.x / 2)) { \
+            const int which = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1);                            \
+            sy_dbg[((int64_t)j * 3 + which) * 16 + (i)] = wall_clock64();                                              \
+        }                                                                                                              \
+    } while (0)
+#else
+#define SY_STAMP(i)
+#endif
 
 constexpr int SY_NB = 32;            // panel width
 constexpr int SY_PW = 2 * SY_NB;     // doubles per panel row: [V(r, 0..NB) | W(r, 0..NB)]
@@ -44,13 +59,33 @@ constexpr int SY_TR = 128;           // tile rows of the symmetric product
 constexpr int SY_TC = 64;            // strip width (tile columns)
 constexpr int SY_FROWS = 64;         // rows per workgroup of the form kernel
 constexpr int SY_MAXSEG = 40;        // segments of a strip (rows of the transposed-partials buffer)
-constexpr int SY_MAXVAV = 4096;      // slots of per-workgroup v'Av partials
+constexpr int SY_MAXVAV = 8704;      // slots of per-workgroup v'Av partials (one-launch form: 2 parities x 2 per tile, 64 blocks)
+
+// wave-wide sum on the DPP path (no LDS round trips): every lane ends with the same bits
+template <int CTRL>
+__device__ __forceinline__ double sr_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sr_readlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double sr_wave_sum(double x) {
+    x += sr_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += sr_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += sr_dpp<0x124>(x);  // row_ror:4
+    x += sr_dpp<0x128>(x);  // row_ror:8: every lane holds the sum of its row of 16
+    return (sr_readlane(x, 0) + sr_readlane(x, 16)) + (sr_readlane(x, 32) + sr_readlane(x, 48));
+}
 
 struct SytrdArgs {
     double* A;          // n x n, leading dimension ld (multiple of 128), lower triangle referenced
     int64_t ld;
     int n;
     double* PT;         // ld x SY_PW, row-major panel
+    double* PTc;        // SY_PW x ld: the same panel column-major (what a row's owner thread of the form kernel reads)
     double* Pdir;       // (ld / 64) x ld: direct partial products, one row per strip
     double* Ptr;        // SY_MAXSEG x ld: transposed partial products, one row per segment
     double* Gpart;      // (ld / 64 + 1) x SY_PW: partial panel dots [V'v | W'v], one row per 64 matrix rows
@@ -103,11 +138,11 @@ static SymvGeom symv_geometry(int n, int j, int cf) {
 __global__ void __launch_bounds__(SY_THREADS)
 sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_vav, int S0, int SEG, int G) {
     __shared__ double s_raw[SY_PW], s_Gf[SY_PW], s_Mf[SY_PW], s_graw[4][SY_PW];
-    __shared__ double s_psum[4][SY_FROWS], s_sf[SY_FROWS], s_sm[SY_FROWS];
+    __shared__ double s_psum[4][SY_FROWS], s_sf[4][SY_FROWS], s_sm[4][SY_FROWS];
     __shared__ double s_scal[4];  // tau, alpha2, p0[j], sf of row j
     __shared__ double s_vavw[4];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, q = tid >> 6;
+    const int lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar bases, 32-bit lane offsets
     const int64_t ld = a.ld;
     const int n = a.n;
     const int jf = j - 1;
@@ -115,122 +150,120 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
     const int r = rbase + lane;
     const int nt128 = (n + SY_TR - 1) / SY_TR;
 
-    // ---- independent loads first (every global load of this kernel is issued before the first
-    // barrier: a dependent load costs a memory round trip on the critical path of the column)
+    SY_STAMP(0);
+    // ---- loads first, ALL of them, into registers, in batches of a static shape: a value that is consumed (or a loop whose
+    // trip count the compiler does not know) between two loads makes the later load wait for a memory round trip of its
+    // own, and a round trip is ~1 us on the critical path of the column (round 4: this kernel had seven of them in a row
+    // before its first barrier, 8.3 us per launch).  Orders beyond 4096 finish the longer sums in loops behind the batch.
     const double pre_tau = do_finish ? a.scal[0] : 0.0, pre_scale = do_finish ? a.scal[2] : 0.0;
-    double pre_raw = 0, pre_x = 0;
-    if (q == 0 && r < n) {
-        if (do_finish) pre_raw = a.A[r + (int64_t)jf * ld];
-        if (do_form) pre_x = a.A[r + (int64_t)j * ld];
+    const bool rok = r < n;
+    const int rr = rok ? r : j;  // (an address that exists)
+    double pre_raw = 0, pre_x = 0, mf = 0, pjk = 0, x1 = 0, x2 = 0;
+    double tvd[16], tvt[4], tvg[16], tvv[8], pcv[8], pcw[8];
+    const int Sr = rr / SY_TC;
+    const int cnt = (do_finish && rok && Sr >= S0 + q) ? (Sr - S0 - q) / 4 + 1 : 0;   // slots of direct partial products of this wave
+    const int nseg = (nt128 - (Sr >> 1) + SEG - 1) / SEG;
+    const int cnt2 = (do_finish && rok && nseg > q) ? (nseg - 1 - q) / 4 + 1 : 0;      // ... of transposed ones
+    const int gk = lane, gpart = q;
+    if (q == 0) {
+        if (do_finish) pre_raw = a.A[rr + (int64_t)jf * ld];
+        if (do_form) pre_x = a.A[rr + (int64_t)j * ld];
     }
     if (do_finish) {
-        // partial products of row r (and, by wave 3 afterwards, of row j): wave q takes every
-        // fourth slot; loads are coalesced along the rows and issued in predicated batches of 8
-        // (a loop with one load per trip serialises the memory latency)
-        double ps = 0;
-        if (r < n) {
-            const int Sr = r / SY_TC;
-            const int cnt = (Sr >= S0 + q) ? (Sr - S0 - q) / 4 + 1 : 0;
-            for (int b0 = 0; b0 < cnt; b0 += 16) {
-                double tv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const bool ok = b0 + u < cnt;
-                    const int S = S0 + q + 4 * (ok ? b0 + u : 0);
-                    const double x = a.Pdir[(int64_t)S * ld + r];
-                    tv[u] = ok ? x : 0.0;
-                }
-                ps += (((tv[0] + tv[1]) + (tv[2] + tv[3])) + ((tv[4] + tv[5]) + (tv[6] + tv[7]))) +
-                      (((tv[8] + tv[9]) + (tv[10] + tv[11])) + ((tv[12] + tv[13]) + (tv[14] + tv[15])));
-            }
-            const int nseg = (nt128 - (Sr >> 1) + SEG - 1) / SEG;
-            const int cnt2 = (nseg > q) ? (nseg - 1 - q) / 4 + 1 : 0;
-            for (int b0 = 0; b0 < cnt2; b0 += 4) {
-                double tv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool ok = b0 + u < cnt2;
-                    const int sg = q + 4 * (ok ? b0 + u : 0);
-                    const double x = a.Ptr[(int64_t)sg * ld + r];
-                    tv[u] = ok ? x : 0.0;
-                }
-                ps += (tv[0] + tv[1]) + (tv[2] + tv[3]);
-            }
-        }
-        s_psum[q][lane] = ps;
-        // panel dots [V'v | W'v]: 256 threads sum the G partial vectors, four slots per panel entry
+        // (slots past the last one are read too, and dropped: the addresses stay inside the workspace -- Pdir, Ptr and the
+        // records are followed by the 64 ld doubles of the column-major panel -- and plain strides cost no address arithmetic)
         {
-            const int k = tid & (SY_PW - 1), part = tid >> 6;
-            double g = 0;
-            for (int b0 = part; b0 < G; b0 += 16) {
-                double tv[4];
+            const double* pd = a.Pdir + (int64_t)(S0 + q) * ld + rr;
+            const double* pt = a.Ptr + (int64_t)q * ld + rr;
+            const int64_t st = 4 * ld;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int b = b0 + 4 * u;
-                    const double x = a.Gpart[(b < G ? b : 0) * SY_PW + k];
-                    tv[u] = (b < G) ? x : 0.0;
-                }
-                g += (tv[0] + tv[1]) + (tv[2] + tv[3]);
-            }
-            s_graw[part][k] = g;
+            for (int u = 0; u < 16; ++u) tvd[u] = pd[u * st];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tvt[u] = pt[u * st];
+        }
+        {
+            // (64 rows: Gpart has ld / 64 + 1; at smaller orders the rows past G run into the records behind it)
+            const double* pg = a.Gpart + gpart * SY_PW + gk;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tvg[u] = pg[u * 4 * SY_PW];
+        }
+        // v'Av partials: all 256 threads
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tvv[u] = a.part_vav[64 * q + SY_THREADS * u + lane];  // (SY_MAXVAV >= 2048 slots exist)
+        if (q == 3) {  // row j: product partials
+            const int Sj = j / SY_TC;
+            const int nsegj = (nt128 - (Sj >> 1) + SEG - 1) / SEG;
+            x1 = a.Pdir[(int64_t)(S0 + lane) * ld + j];
+            x2 = a.Ptr[(int64_t)lane * ld + j];
         }
     }
     if (do_form && tid < SY_PW)  // row j of the panel with the halves swapped: [W(j,:) | V(j,:)]
-        s_Mf[tid] = ((tid & (SY_NB - 1)) < cf) ? a.PT[(int64_t)j * SY_PW + (tid ^ SY_NB)] : 0.0;
-    // v'Av partials: all 256 threads, independent loads issued before the first barrier
-    double vav = 0;
-    if (do_finish) {
-        for (int b0 = tid; b0 < n_vav; b0 += SY_THREADS * 8) {
-            double tv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int b = b0 + SY_THREADS * u;
-                const double x = a.part_vav[b < n_vav ? b : 0];
-                tv[u] = (b < n_vav) ? x : 0.0;
-            }
-            vav += ((tv[0] + tv[1]) + (tv[2] + tv[3])) + ((tv[4] + tv[5]) + (tv[6] + tv[7]));
-        }
-    }
-    // row j: product partials (wave 3) -- also independent of everything above
-    double psj = 0;
-    if (do_finish && q == 3) {
-        const int Sj = j / SY_TC;
-        const int nsegj = (nt128 - (Sj >> 1) + SEG - 1) / SEG;
-        const bool ok1 = S0 + lane <= Sj, ok2 = lane < nsegj;
-        const double x1 = a.Pdir[(int64_t)(ok1 ? S0 + lane : S0) * ld + j];
-        const double x2 = a.Ptr[(int64_t)(ok2 ? lane : 0) * ld + j];
-        psj = (ok1 ? x1 : 0.0) + (ok2 ? x2 : 0.0);
-    }
-    // the 16 panel rows of this wave: 4 lanes per row, 16 consecutive panel entries per lane (128
-    // bytes); the wave reads 8 KiB contiguous.  Row j (needed by all rows) goes to wave 2's lanes.
-    const int prow = lane >> 2, pq = lane & 3;  // row within the wave's 16, quarter of the panel row
-    double2 ptv[8], ptj[8];
+        mf = a.PT[(int64_t)j * SY_PW + (tid ^ SY_NB)];
+    // the panel entries of row r from the column-major copy: a thread owns a row (coalesced loads, no reduction across
+    // lanes), wave q takes the panel columns 8q .. 8q+7 of V and of W
     if (cf > 0) {
-        const int rr = rbase + q * (SY_FROWS / 4) + prow;
-        const double2* src = reinterpret_cast<const double2*>(a.PT + (int64_t)(rr < n ? rr : j) * SY_PW + 16 * pq);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ptv[u] = src[u];
-        if (q == 2 && do_finish) {
-            const double2* sj = reinterpret_cast<const double2*>(a.PT + (int64_t)j * SY_PW + 16 * pq);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) ptj[u] = sj[u];
+        for (int u = 0; u < 8; ++u) {
+            const int k = 8 * q + u;
+            const bool need = k < cf;
+            pcv[u] = need ? a.PTc[(int64_t)k * ld + rr] : 0.0;
+            pcw[u] = need ? a.PTc[(int64_t)(SY_NB + k) * ld + rr] : 0.0;
         }
+        if (q == 2 && do_finish) pjk = a.PT[(int64_t)j * SY_PW + lane];  // row j, lane = panel entry
     }
+    SY_STAMP(1);
+    // ---- consumption
+    double vav = 0, psj = 0;
     if (do_finish) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vav += __shfl_down(vav, o, 64);
+        for (int u = 0; u < 16; ++u) tvd[u] = u < cnt ? tvd[u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tvt[u] = u < cnt2 ? tvt[u] : 0.0;
+        double ps = ((((tvd[0] + tvd[1]) + (tvd[2] + tvd[3])) + ((tvd[4] + tvd[5]) + (tvd[6] + tvd[7]))) +
+                     (((tvd[8] + tvd[9]) + (tvd[10] + tvd[11])) + ((tvd[12] + tvd[13]) + (tvd[14] + tvd[15])))) +
+                    ((tvt[0] + tvt[1]) + (tvt[2] + tvt[3]));
+        for (int b0 = 16; b0 < cnt; ++b0) ps += a.Pdir[(int64_t)(S0 + q + 4 * b0) * ld + rr];   // (orders beyond 4096)
+        for (int b0 = 4; b0 < cnt2; ++b0) ps += a.Ptr[(int64_t)(q + 4 * b0) * ld + rr];
+        s_psum[q][lane] = ps;
+        double g = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tvg[u] = gpart + 4 * u < G ? tvg[u] : 0.0;
+        g = (((tvg[0] + tvg[1]) + (tvg[2] + tvg[3])) + ((tvg[4] + tvg[5]) + (tvg[6] + tvg[7]))) +
+            (((tvg[8] + tvg[9]) + (tvg[10] + tvg[11])) + ((tvg[12] + tvg[13]) + (tvg[14] + tvg[15])));
+        for (int b = gpart + 64; b < G; b += 4) g += a.Gpart[b * SY_PW + gk];
+        s_graw[gpart][gk] = g;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tvv[u] = tid + SY_THREADS * u < n_vav ? tvv[u] : 0.0;
+        vav = ((tvv[0] + tvv[1]) + (tvv[2] + tvv[3])) + ((tvv[4] + tvv[5]) + (tvv[6] + tvv[7]));
+        for (int b = tid + SY_THREADS * 8; b < n_vav; b += SY_THREADS) vav += a.part_vav[b];
+        if (q == 3) {
+            const int Sj = j / SY_TC;
+            const int nsegj = (nt128 - (Sj >> 1) + SEG - 1) / SEG;
+            psj = (S0 + lane <= Sj ? x1 : 0.0) + (lane < nsegj ? x2 : 0.0);
+        }
+    }
+    if (do_form && tid < SY_PW) s_Mf[tid] = ((tid & (SY_NB - 1)) < cf) ? mf : 0.0;
+    if (!rok) {
+        pre_raw = 0.0;
+        pre_x = 0.0;
+    }
+    if (do_finish) {
+        vav = sr_wave_sum(vav);
         if (lane == 0) s_vavw[q] = vav;
     }
+    SY_STAMP(2);
     __syncthreads();
+    SY_STAMP(3);
     if (do_finish && tid < SY_PW) s_raw[tid] = (s_graw[0][tid] + s_graw[1][tid]) + (s_graw[2][tid] + s_graw[3][tid]);
+    SY_STAMP(4);
     __syncthreads();
+    SY_STAMP(5);
     if (do_finish) {
         // multiplier of PT[r][k] in  V(r,:) (W'v) + W(r,:) (V'v):  the other half's dot
         if (tid < SY_PW) s_Gf[tid] = ((tid & (SY_NB - 1)) < cf) ? s_raw[tid ^ SY_NB] : 0.0;
         if (q == 1) {  // fixed-shape tree reductions (bitwise reproducible)
             double gg = (lane < cf) ? s_raw[lane] * s_raw[lane + SY_NB] : 0.0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) gg += __shfl_down(gg, o, 64);
+            gg = sr_wave_sum(gg);
             if (lane == 0) {
                 const double vav = (s_vavw[0] + s_vavw[1]) + (s_vavw[2] + s_vavw[3]);
                 const double tau = pre_tau;
@@ -240,55 +273,51 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
             }
         }
         if (q == 3) {  // row j: needed by every row of the form part
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) psj += __shfl_down(psj, o, 64);
+            psj = sr_wave_sum(psj);
             if (lane == 0) s_scal[2] = psj;
         }
     }
+    SY_STAMP(6);
     __syncthreads();
+    SY_STAMP(7);
     // ---- panel dots of the 64 rows
-    if (cf > 0) {
-        const int rr = rbase + q * (SY_FROWS / 4) + prow;
-        double sf = 0, sm = 0, sfj = 0;
+    {
+        double sf = 0, sm = 0;
+        if (cf > 0) {
+            // the 32 multipliers of this wave in one batch of LDS reads, then two independent chains per sum (round 4: one LDS
+            // round trip per fma pair, behind a branch on do_finish / do_form each, was 0.9 us of the 6.3 us of a launch)
+            double gf[16], gm[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k0 = 16 * pq + 2 * u;
-            if (do_finish) {
-                sf = fma(ptv[u].x, s_Gf[k0], sf);
-                sf = fma(ptv[u].y, s_Gf[k0 + 1], sf);
+            for (int u = 0; u < 8; ++u) {
+                gf[u] = s_Gf[8 * q + u];
+                gf[8 + u] = s_Gf[SY_NB + 8 * q + u];
+                gm[u] = s_Mf[8 * q + u];
+                gm[8 + u] = s_Mf[SY_NB + 8 * q + u];
             }
-            if (do_form) {
-                sm = fma(ptv[u].x, s_Mf[k0], sm);
-                sm = fma(ptv[u].y, s_Mf[k0 + 1], sm);
+            double sf2 = 0, sm2 = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sf = fma(pcv[u], gf[u], sf);
+                sf2 = fma(pcw[u], gf[8 + u], sf2);
+                sm = fma(pcv[u], gm[u], sm);
+                sm2 = fma(pcw[u], gm[8 + u], sm2);
             }
+            sf += sf2;
+            sm += sm2;
             if (q == 2 && do_finish) {
-                sfj = fma(ptj[u].x, s_Gf[k0], sfj);
-                sfj = fma(ptj[u].y, s_Gf[k0 + 1], sfj);
+                double sfj = pjk * s_Gf[lane];
+                sfj = sr_wave_sum(sfj);
+                if (lane == 0) s_scal[3] = sfj;
             }
+        } else if (tid == 0) {
+            s_scal[3] = 0.0;
         }
-        if (rr >= n) {
-            sf = 0;
-            sm = 0;
-        }
-        sf += __shfl_xor(sf, 1, 64);
-        sm += __shfl_xor(sm, 1, 64);
-        sfj += __shfl_xor(sfj, 1, 64);
-        sf += __shfl_xor(sf, 2, 64);
-        sm += __shfl_xor(sm, 2, 64);
-        sfj += __shfl_xor(sfj, 2, 64);
-        if (pq == 0) {
-            s_sf[q * (SY_FROWS / 4) + prow] = sf;
-            s_sm[q * (SY_FROWS / 4) + prow] = sm;
-        }
-        if (q == 2 && do_finish && lane == 0) s_scal[3] = sfj;
-    } else {
-        if (tid < SY_FROWS) {
-            s_sf[tid] = 0.0;
-            s_sm[tid] = 0.0;
-        }
-        if (tid == 0) s_scal[3] = 0.0;
+        s_sf[q][lane] = (r < n) ? sf : 0.0;
+        s_sm[q][lane] = (r < n) ? sm : 0.0;
     }
+    SY_STAMP(8);
     __syncthreads();
+    SY_STAMP(9);
     if (q != 0) return;
     double sq = 0;
     if (r < n) {
@@ -297,15 +326,17 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
             const double tau = s_scal[0], alpha2 = s_scal[1], scale = pre_scale;
             v = (r == jf + 1) ? 1.0 : pre_raw * scale;
             const double p0 = s_psum[0][lane] + s_psum[1][lane] + s_psum[2][lane] + s_psum[3][lane];
-            wnew = tau * (p0 - s_sf[lane]) + alpha2 * v;
+            wnew = tau * (p0 - ((s_sf[0][lane] + s_sf[1][lane]) + (s_sf[2][lane] + s_sf[3][lane]))) + alpha2 * v;
             a.PT[(int64_t)r * SY_PW + cf] = v;
             a.PT[(int64_t)r * SY_PW + SY_NB + cf] = wnew;
+            a.PTc[(int64_t)cf * ld + r] = v;
+            a.PTc[(int64_t)(SY_NB + cf) * ld + r] = wnew;
             // LAPACK storage of the finished reflector: v below the subdiagonal of column jf
             if (r >= jf + 2) a.A[r + (int64_t)jf * ld] = v;
         }
         if (do_form) {
             double x = pre_x;
-            double sm = s_sm[lane];
+            double sm = (s_sm[0][lane] + s_sm[1][lane]) + (s_sm[2][lane] + s_sm[3][lane]);
             if (do_finish) {
                 // row j of the column that this launch finishes: V(j, cf) = v_jf[jf+1] = 1
                 const double wj = s_scal[0] * (s_scal[2] - s_scal[3]) + s_scal[1];
@@ -318,10 +349,10 @@ sytrd_form_kernel(SytrdArgs a, int j, int cf, int do_finish, int do_form, int n_
         }
     }
     if (do_form) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+        sq = sr_wave_sum(sq);
         if (lane == 0) a.part_norm[blockIdx.x] = sq;
     }
+    SY_STAMP(10);
 }
 
 // ---------------------------------------------------------------------------
@@ -379,11 +410,11 @@ sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm, int S0, int SEG, int n
     // tree: bitwise the same result in every wave and workgroup) -- no LDS broadcast, no barrier
     double scale;
     {
-        double xn2 = 0;
-        for (int b = lane; b < n_norm; b += 64) xn2 += a.part_norm[b];
+        double xn2 = a.part_norm[lane];  // (64 slots are there at every order: part_vav follows part_norm)
         const double alpha = colj[j + 1];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) xn2 += __shfl_xor(xn2, o, 64);
+        xn2 = lane < n_norm ? xn2 : 0.0;
+        for (int b = lane + 64; b < n_norm; b += 64) xn2 += a.part_norm[b];  // (orders beyond 4096)
+        xn2 = sr_wave_sum(xn2);
         double beta, tau;
         if (xn2 == 0.0) {  // dlarfg: H = I
             tau = 0.0;
@@ -515,8 +546,7 @@ sytrd_symv_kernel(SytrdArgs a, int j, int cf, int n_norm, int S0, int SEG, int n
         if (tid < SY_PW)
             a.Gpart[sx * SY_PW + tid] = (s_y[0][0][tid] + s_y[0][1][tid]) + (s_y[0][2][tid] + s_y[0][3][tid]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vav += __shfl_down(vav, o, 64);
+    vav = sr_wave_sum(vav);
     if (lane == 0) s_red[w] = vav;
     __syncthreads();
     if (tid == 0) a.part_vav[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
@@ -712,23 +742,6 @@ struct SytrdRowArgs {
 // Wave-wide sum on the DPP path (quad permutes, row rotations, four read-lanes) instead of six ds_bpermute round
 // trips of a 64-bit value: the kernel below is one dependent chain with three of these in it.  All 64 lanes must be
 // active.  The result is uniform.
-template <int CTRL>
-__device__ __forceinline__ double sr_dpp(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double sr_readlane(double x, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-}
-__device__ __forceinline__ double sr_wave_sum(double x) {
-    x += sr_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
-    x += sr_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
-    x += sr_dpp<0x124>(x);  // row_ror:4
-    x += sr_dpp<0x128>(x);  // row_ror:8: every lane holds the sum of its row of 16
-    return (sr_readlane(x, 0) + sr_readlane(x, 16)) + (sr_readlane(x, 32) + sr_readlane(x, 48));
-}
 
 // NCH: 128-column chunks of a row that can be active (ceil(ld / 128) at most)
 template <int NCH>
@@ -911,7 +924,7 @@ sytrd_row_mirror_kernel(int n, int64_t ld, double* __restrict__ A) {
 size_t sytrd_workspace_doubles(int64_t n, int64_t ld) {
     (void)n;
     return (size_t)ld * SY_PW + (size_t)(ld / SY_TC + 1) * ld + (size_t)SY_MAXSEG * ld + (size_t)(ld / 64 + 1) * SY_PW +
-           (size_t)(ld / SY_FROWS + 8) + SY_MAXVAV + 64;
+           (size_t)(ld / SY_FROWS + 8) + SY_MAXVAV + 64 + (size_t)ld * SY_PW;  // (+ the one-launch form's column-major panel)
 }
 
 static SytrdArgs sytrd_args(int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
@@ -926,6 +939,7 @@ static SytrdArgs sytrd_args(int64_t n, double* A, int64_t ld, double* d, double*
     a.part_norm = a.Gpart + (ld / 64 + 1) * SY_PW;
     a.part_vav = a.part_norm + (ld / SY_FROWS + 8);
     a.scal = a.part_vav + SY_MAXVAV;
+    a.PTc = a.scal + 64;
     a.d = d;
     a.e = e;
     a.tau = tau;
@@ -1009,6 +1023,35 @@ static void emit_form(SytrdEmitter& em, unsigned grid, const SytrdArgs& a, int j
 static bool emit_sytrd(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws,
                        int stop = -1) {
     const int n = (int)n64;
+#ifdef LK_TIMING
+    long long* dbg = nullptr;
+    struct DbgDump {
+        long long*& dbg; hipStream_t s; int n;
+        ~DbgDump() {
+            if (!dbg) return;
+            hipStreamSynchronize(s);
+            std::vector<long long> h((size_t)(n + 64) * 3 * 16);
+            hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+            for (int j : {5, 20, 31, 33, 1029, 1950}) {
+                if (j >= n) continue;
+                for (int wch = 0; wch < 3; ++wch) {
+                    const long long* t = &h[((size_t)j * 3 + wch) * 16];
+                    fprintf(stderr, "[form timing] j=%d wg=%d:", j, wch);
+                    for (int i = 1; i < 11; ++i) fprintf(stderr, " %6.2f", t[i] ? (t[i] - t[0]) * 0.01 : -1.0);
+                    fprintf(stderr, "  (t0 rel. to wg0 %.2f)\n", (t[0] - h[(size_t)j * 3 * 16]) * 0.01);
+                }
+            }
+            long long* z = nullptr;
+            hipMemcpyToSymbol(HIP_SYMBOL(sy_dbg), &z, sizeof(z));
+            hipFree(dbg);
+        }
+    } dump{dbg, em.s, n};
+    if (!em.graph && getenv("SDPSR_LOOK_TIMING")) {
+        hipMalloc(&dbg, (size_t)(n + 64) * 3 * 16 * 8);
+        hipMemset(dbg, 0, (size_t)(n + 64) * 3 * 16 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(sy_dbg), &dbg, sizeof(dbg));
+    }
+#endif
     SytrdArgs a = sytrd_args(n64, A, ld, d, e, tau, ws);
     em.zero(ws, sytrd_workspace_doubles(n, ld) * sizeof(double));
     if (n == 1) {
@@ -1079,24 +1122,98 @@ static bool emit_sytrd_rows(SytrdEmitter& em, int64_t n64, double* A, int64_t ld
     em.copy8(d + (n - 1), A + (int64_t)(n - 1) * ld + (n - 1));  // tau(n-2) = 0: the last diagonal entry is final
     return em.ok;
 }
-// the default: row form up to SR_NMAX; beyond, the panel form until the trailing matrix has come down to SR_NMAX
-// (there a column of the panel form is two launch latencies, 13-14 us, against one latency + 16 m^2 bytes of the row form)
-static bool sytrd_use_rows(const sdpsr_ctx* c, int64_t n, int64_t ld) {
-    return ld >= n && !(c && (c->opts.flags & SDPSR_FLAG_SYTRD_PANELS));
+// The panel columns with ONE launch per column (kernels_sytrd_look.hip): columns 0 .. stop-1, stop a multiple of 128 below n;
+// the trailing matrix A(stop:, stop:) is left updated (lower triangle) for the row form.  The buffers of the two-launch form
+// are reused: the partial products take Pdir, the column Ptr, the records Gpart / part_norm / part_vav.
+#ifdef LK_TIMING
+void sytrd_look_debug_buffer(long long* p);
+#endif
+static bool emit_sytrd_look(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws, int stop) {
+    const int n = (int)n64;
+    SytrdArgs a = sytrd_args(n64, A, ld, d, e, tau, ws);
+    em.zero(ws, sytrd_workspace_doubles(n, ld) * sizeof(double));
+    SytrdLookArgs la;
+    la.A = A;
+    la.ld = ld;
+    la.n = n;
+    la.PT = a.PT;
+    la.PTc = a.PTc;
+    la.P = a.Pdir;
+    la.acol = a.Ptr;
+    la.rec_norm = a.part_norm;
+    la.rec_dots = a.Gpart;
+    la.rec_vaz = a.part_vav;
+    la.vaz_cap = SY_MAXVAV / 2;
+    la.d = d;
+    la.e = e;
+    la.tau = tau;
+    const int nb = (n + 127) / 128;
+    auto tiles = [&](int j) {
+        const int t = nb - j / 128;
+        return t * (t + 1) / 2;
+    };
+#ifdef LK_TIMING
+    long long* dbg = nullptr;
+    if (!em.graph && getenv("SDPSR_LOOK_TIMING")) {
+        hipMalloc(&dbg, (size_t)(stop + 64) * 3 * 16 * 8);
+        hipMemset(dbg, 0, (size_t)(stop + 64) * 3 * 16 * 8);
+        sytrd_look_debug_buffer(dbg);
+    }
+#endif
+    for (int j0 = 0; j0 < stop; j0 += SY_NB) {
+        for (int cf = 0; cf < SY_NB; ++cf) {
+            const int j = j0 + cf;
+            em.kernel(sytrd_look_kernel_fn(cf == 0 ? 0 : 1, ld), (unsigned)tiles(j), SY_THREADS, 0, la, j, cf, cf == 0 ? 0 : 2 * tiles(j - 1));
+        }
+        const int j1 = j0 + SY_NB;
+        em.kernel(sytrd_look_kernel_fn(2, ld), (unsigned)(nb - j1 / 128), SY_THREADS, 0, la, j1, SY_NB, 2 * tiles(j1 - 1));
+        const int T0 = j1 / 128;
+        const int nt = nb - T0;
+        em.kernel(reinterpret_cast<const void*>(&sytrd_syr2k_mfma_kernel), (unsigned)(nt * (nt + 1) / 2), SY_THREADS, 128 * 1024, a, j1, T0);
+    }
+#ifdef LK_TIMING
+    if (dbg) {
+        hipStreamSynchronize(em.s);
+        std::vector<long long> h((size_t)(stop + 64) * 3 * 16);
+        hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        for (int j : {5, 20, 31, 32, 33, 1029, 1055, 1056, 1950, 1983, 1984}) {
+            if (j >= stop + 1) continue;
+            for (int wch = 0; wch < 3; ++wch) {
+                const long long* t = &h[((size_t)j * 3 + wch) * 16];
+                fprintf(stderr, "[look timing] j=%d wg=%d:", j, wch);
+                for (int i = 1; i < 10; ++i) fprintf(stderr, " %6.2f", t[i] ? (t[i] - t[0]) * 0.01 : -1.0);
+                fprintf(stderr, "  (us since the first stamp; t0 rel. to wg0 %.2f)\n", (t[0] - h[(size_t)j * 3 * 16]) * 0.01);
+            }
+        }
+        sytrd_look_debug_buffer(nullptr);
+        hipFree(dbg);
+    }
+#endif
+    return em.ok;
 }
-static bool emit_sytrd_default(SytrdEmitter& em, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
+
+// the default: row form up to SR_NMAX; beyond, the panel form until the trailing matrix has come down to SR_NMAX
+// (there a column of the two-launch panel form is two launch latencies, 13-14 us, against one latency + 16 m^2 bytes of the row form)
+// form: 0 = panels (two launches per column) at every order, 1 = row form + two-launch panels above SR_NMAX (default),
+//       2 = row form + one-launch panels above SR_NMAX (SDPSR_FLAG_SYTRD_ONE_LAUNCH; measured slower)
+static int sytrd_form(const sdpsr_ctx* c, int64_t n, int64_t ld) {
+    if (ld < n || (c && (c->opts.flags & SDPSR_FLAG_SYTRD_PANELS))) return 0;
+    if (ld <= 8192 && c && (c->opts.flags & SDPSR_FLAG_SYTRD_ONE_LAUNCH)) return 2;
+    return 1;
+}
+static bool emit_sytrd_default(SytrdEmitter& em, int64_t n, double* A, int64_t ld, double* d, double* e, double* tau, double* ws, int form) {
+    if (form == 0) return emit_sytrd(em, n, A, ld, d, e, tau, ws);
     if (n <= SR_NMAX) return emit_sytrd_rows(em, n, A, ld, d, e, tau, ws);
     const int64_t j0 = (n - SR_NMAX + 127) / 128 * 128;
-    if (!emit_sytrd(em, n, A, ld, d, e, tau, ws, (int)j0)) return false;
+    if (form == 2 ? !emit_sytrd_look(em, n, A, ld, d, e, tau, ws, (int)j0) : !emit_sytrd(em, n, A, ld, d, e, tau, ws, (int)j0)) return false;
     return emit_sytrd_rows(em, n - j0, A + j0 * ld + j0, ld, d + j0, e + j0, tau + j0, ws);
 }
 
 static void launch_sytrd_direct(hipStream_t s, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau,
-                                double* ws, bool rows) {
+                                double* ws, int form) {
     SytrdEmitter em;
     em.s = s;
-    if (rows) emit_sytrd_default(em, n64, A, ld, d, e, tau, ws);
-    else emit_sytrd(em, n64, A, ld, d, e, tau, ws);
+    emit_sytrd_default(em, n64, A, ld, d, e, tau, ws, form);
 }
 
 // measurement hook: only the symv launches of a full tridiagonalisation (same grid shapes and
@@ -1125,7 +1242,7 @@ void launch_sytrd_symv_sweep(hipStream_t s, int64_t n64, double* A, int64_t ld, 
 // one ctx are serialised by contract, so no lock is needed.
 struct SytrdGraph {
     int64_t n = 0, ld = 0;
-    bool rows = false;
+    int form = 0;
     const void *A = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr, *ws = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t last_use = 0;
@@ -1154,9 +1271,9 @@ void sytrd_graph_cache_destroy(SytrdGraphCache* g) {
 void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, double* e, double* tau, double* ws) {
     hipStream_t s = c->stream;
     const bool no_graph = (c->opts.flags & SDPSR_FLAG_NO_GRAPH) != 0;  // profiling: per-kernel statistics of the launches
-    const bool rows = sytrd_use_rows(c, n64, ld);
+    const int form = sytrd_form(c, n64, ld);
     if (no_graph || n64 < 64) {
-        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, rows);
+        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, form);
         return;
     }
     if (!c->sytrd_graphs) c->sytrd_graphs = new SytrdGraphCache();
@@ -1164,7 +1281,7 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
     ++gc.clock;
     SytrdGraph* slot = nullptr;
     for (auto& g : gc.slots)
-        if (g.exec && g.n == n64 && g.ld == ld && g.rows == rows && g.A == A && g.d == d && g.e == e && g.tau == tau && g.ws == ws) slot = &g;
+        if (g.exec && g.n == n64 && g.ld == ld && g.form == form && g.A == A && g.d == d && g.e == e && g.tau == tau && g.ws == ws) slot = &g;
     if (slot) ++gc.hits;
     if (!slot) {
         ++gc.misses;
@@ -1184,19 +1301,19 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
         if (ok) {
             SytrdEmitter em;
             em.graph = graph;
-            ok = rows ? emit_sytrd_default(em, n64, A, ld, d, e, tau, ws) : emit_sytrd(em, n64, A, ld, d, e, tau, ws);
+            ok = emit_sytrd_default(em, n64, A, ld, d, e, tau, ws, form);
         }
         if (ok) ok = hipGraphInstantiate(&victim->exec, graph, nullptr, nullptr, 0) == hipSuccess;
         if (graph) hipGraphDestroy(graph);
         if (!ok) {  // graph construction failed: plain launches
             victim->exec = nullptr;
             (void)hipGetLastError();
-            launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, rows);
+            launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, form);
             return;
         }
         victim->n = n64;
         victim->ld = ld;
-        victim->rows = rows;
+        victim->form = form;
         victim->A = A;
         victim->d = d;
         victim->e = e;
@@ -1206,13 +1323,13 @@ void launch_sytrd(sdpsr_ctx* c, int64_t n64, double* A, int64_t ld, double* d, d
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
         gc.instantiate_ms += ms;
         if (dbg_on())
-            fprintf(stderr, "[sdpsr] sytrd graph cache MISS: n=%lld ld=%lld rows=%d built + instantiated in %.2f ms (hits %llu, misses %llu)\n",
-                    (long long)n64, (long long)ld, (int)rows, ms, (unsigned long long)gc.hits, (unsigned long long)gc.misses);
+            fprintf(stderr, "[sdpsr] sytrd graph cache MISS: n=%lld ld=%lld form=%d built + instantiated in %.2f ms (hits %llu, misses %llu)\n",
+                    (long long)n64, (long long)ld, form, ms, (unsigned long long)gc.hits, (unsigned long long)gc.misses);
     }
     slot->last_use = gc.clock;
     if (hipGraphLaunch(slot->exec, s) != hipSuccess) {
         (void)hipGetLastError();
-        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, rows);
+        launch_sytrd_direct(s, n64, A, ld, d, e, tau, ws, form);
     }
 }
 

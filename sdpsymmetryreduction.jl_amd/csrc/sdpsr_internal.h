@@ -275,6 +275,22 @@ void launch_cx_basis_image(hipStream_t s, int64_t n, int64_t d, int64_t S, const
 void launch_eigdec_batched64(hipStream_t s, int64_t n, int64_t d, int64_t count, const uint32_t* L, const double* values,
                              uint64_t seed, uint64_t stream_base, double atol, int32_t* status, int32_t* neig,
                              int32_t* nclasses, int num_cus);
+// kernels_sytrd_look.hip: the panel form with one launch per column (the launches are emitted by kernels_sytrd.hip)
+struct SytrdLookArgs {
+    double* A;  // n x n, leading dimension ld (multiple of 128, <= 8192), lower triangle referenced
+    int64_t ld;
+    int n;
+    double* PT;        // ld x 64 row-major panel [V | W] (the layout of the trailing update's MFMA kernel)
+    double* PTc;       // 64 x ld: the same panel column-major (the layout a row's owner thread reads)
+    double* P;         // [2][ld / 128][ld]: partial products of the unnormalised column, one slot per partner block
+    double* acol;      // [2][ld]: the updated column of the launch
+    double* rec_norm;  // [2][ld / 128]: partial |a|^2 of the rows of a block
+    double* rec_dots;  // [2][ld / 128][64]: partial [V'a | W'a]
+    double* rec_vaz;   // [2][vaz_cap]: partial a'(A0 a), two per tile
+    int64_t vaz_cap;
+    double *d, *e, *tau;
+};
+const void* sytrd_look_kernel_fn(int mode, int64_t ld);
 void sytrd_graph_cache_destroy(SytrdGraphCache* g);
 void sytrd_graph_cache_stats(const SytrdGraphCache* g, uint64_t* hits, uint64_t* misses, double* instantiate_ms);
 
