@@ -38,8 +38,10 @@
 
 namespace sdpsr {
 
-// development aid (-DLK_TIMING): wall-clock stamps (100 MHz) of the phases of the form kernel's first / middle / last workgroup
+// development aid (-DLK_TIMING, and SDPSR_DEBUG set at run time; launches one by one: SDPSR_FLAG_NO_GRAPH): wall-clock
+// stamps (100 MHz) of the phases of the form kernel's first / middle / last workgroup
 #ifdef LK_TIMING
+bool dbg_on();  // ctx.cpp (SDPSR_DEBUG)
 __device__ long long* sy_dbg = nullptr;
 #define SY_STAMP(i)                                                                                                   \
     do {                                                                                                               \
@@ -794,9 +796,14 @@ sytrd_row_kernel(SytrdRowArgs a, int j) {
     const double ajj = linej[j];
     double pd = 0.0;  // every wave adds up all G partials itself: no barrier in front of w_{j-1}
     if (j > 0) {
+        // four loads, then four selects, then the sum: `if (..) pd += load` compiles to a load, a wait and an add per slice,
+        // i.e. up to three more memory round trips behind the one of the matrix rows (round 4; all 256 slots exist)
+        double t4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (64 * q + lane < G) pd += a.pdot[pp * 256 + 64 * q + lane];
+        for (int q = 0; q < 4; ++q) t4[q] = a.pdot[pp * 256 + 64 * q + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t4[q] = 64 * q + lane < G ? t4[q] : 0.0;
+        pd = (t4[0] + t4[1]) + (t4[2] + t4[3]);
     }
 
     // ---- s = y'v of the previous column, then w_{j-1} (LDS) and the updated column x
@@ -1046,7 +1053,7 @@ static bool emit_sytrd(SytrdEmitter& em, int64_t n64, double* A, int64_t ld, dou
             hipFree(dbg);
         }
     } dump{dbg, em.s, n};
-    if (!em.graph && getenv("SDPSR_LOOK_TIMING")) {
+    if (!em.graph && dbg_on()) {
         hipMalloc(&dbg, (size_t)(n + 64) * 3 * 16 * 8);
         hipMemset(dbg, 0, (size_t)(n + 64) * 3 * 16 * 8);
         hipMemcpyToSymbol(HIP_SYMBOL(sy_dbg), &dbg, sizeof(dbg));
@@ -1154,7 +1161,7 @@ static bool emit_sytrd_look(SytrdEmitter& em, int64_t n64, double* A, int64_t ld
     };
 #ifdef LK_TIMING
     long long* dbg = nullptr;
-    if (!em.graph && getenv("SDPSR_LOOK_TIMING")) {
+    if (!em.graph && dbg_on()) {
         hipMalloc(&dbg, (size_t)(stop + 64) * 3 * 16 * 8);
         hipMemset(dbg, 0, (size_t)(stop + 64) * 3 * 16 * 8);
         sytrd_look_debug_buffer(dbg);

@@ -41,7 +41,9 @@ def test_opts_struct_layout(pkg):
                       ("UNPACK_EVERY_STEP", L.FLAG_UNPACK_EVERY_STEP), ("SPMM_ONE_BY_ONE", L.FLAG_SPMM_ONE_BY_ONE),
                       ("SINGLE_COUPLING_ELEMENT", L.FLAG_SINGLE_COUPLING_ELEMENT), ("SMALL_EIGEN_ON_DEVICE", L.FLAG_SMALL_EIGEN_ON_DEVICE),
                       ("NO_GRAPH", L.FLAG_NO_GRAPH), ("NO_VERIFY_SHORTCUT", L.FLAG_NO_VERIFY_SHORTCUT),
-                      ("FULL_BASIS_IMAGE", L.FLAG_FULL_BASIS_IMAGE), ("ALWAYS_PROJECT", L.FLAG_ALWAYS_PROJECT)):
+                      ("FULL_BASIS_IMAGE", L.FLAG_FULL_BASIS_IMAGE), ("ALWAYS_PROJECT", L.FLAG_ALWAYS_PROJECT),
+                      ("SYTRD_PANELS", L.FLAG_SYTRD_PANELS), ("COUPLING_ON_HOST", L.FLAG_COUPLING_ON_HOST),
+                      ("SYTRD_ONE_LAUNCH", L.FLAG_SYTRD_ONE_LAUNCH)):
         m = re.search(r"SDPSR_FLAG_%s = 1u << (\d+)" % name, hdr)
         assert m and (1 << int(m.group(1))) == val, name
 

@@ -211,10 +211,13 @@ def test_syev_matches_lapack(pkg, gpu_ctx):
 def test_syev_row_form_panel_form_and_hybrid(pkg):
     """The tridiagonalisation has two forms: one launch per column with row-owning workgroups (n <= 2048, default) and
     Householder panels with trailing updates on the matrix cores (SDPSR_FLAG_SYTRD_PANELS, and the leading columns of
-    larger orders, whose last 2048 columns are handed to the row form).  All three against LAPACK."""
+    larger orders, whose last 2048 columns are handed to the row form).  SDPSR_FLAG_SYTRD_ONE_LAUNCH: the panel columns of
+    the larger orders with one launch per column (product with the unnormalised column, csrc/kernels_sytrd_look.hip).  All
+    against LAPACK."""
     lib = pkg.load_library()
     rng = np.random.default_rng(7)
-    for n, flags in ((777, 0), (777, pkg._lib.FLAG_SYTRD_PANELS), (1536, 0), (2304, 0), (2500, 0)):
+    for n, flags in ((777, 0), (777, pkg._lib.FLAG_SYTRD_PANELS), (1536, 0), (2304, 0), (2500, 0),
+                     (2304, pkg._lib.FLAG_SYTRD_ONE_LAUNCH), (2500, pkg._lib.FLAG_SYTRD_ONE_LAUNCH)):
         A = rng.standard_normal((n, n))
         A = np.asfortranarray((A + A.T) / 2)
         A[np.triu_indices(n, 1)] = 1e300  # only the lower triangle is referenced (the row form mirrors it first)
