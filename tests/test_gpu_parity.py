@@ -364,6 +364,31 @@ def test_syev_n4096_degenerate_and_generic(pkg, problems, gpu_ctx):
         assert np.allclose(w, np.linalg.eigvalsh(A), atol=1e-11 * scale)
 
 
+def test_syev_one_launch_panels_beyond_4096(pkg, problems):
+    """SDPSR_FLAG_SYTRD_ONE_LAUNCH at an order whose leading dimension exceeds 4096 (the kernel instance with 64 slots of partial
+    products per row) and is ragged (n = 4200, ld = 4224): the degenerate generic element of a 34-class scheme and a generic
+    symmetric matrix; residual, orthogonality, trace and the two-launch form's eigenvalues."""
+    lib = pkg.load_library()
+    n = 4200
+    Ls, d = problems.synthetic_jordan_partition(n, seed=2)
+    A1 = np.asfortranarray(np.concatenate([[0.0], np.random.default_rng(0).random(d)])[Ls])
+    G = np.random.default_rng(4).standard_normal((n, n))
+    A2 = np.asfortranarray((G + G.T) / 2)
+    for A in (A1, A2):
+        ws = []
+        for flags in (pkg._lib.FLAG_SYTRD_ONE_LAUNCH, 0):
+            w = np.zeros(n)
+            V = np.zeros((n, n), order="F")
+            with pkg.Context(seed=1, flags=flags) as ctx:
+                ctx.check(lib.sdpsr_syev_f64(ctx._h, n, C.c_void_p(A.ctypes.data), C.c_void_p(w.ctypes.data), C.c_void_p(V.ctypes.data), 0))
+            scale = np.abs(w).max()
+            assert np.abs(A @ V - V * w).max() <= 2e-12 * scale, flags
+            assert np.abs(V.T @ V - np.eye(n)).max() < 1e-11, flags
+            assert abs(w.sum() - np.trace(A)) <= 1e-10 * scale * n ** 0.5, flags
+            ws.append(w)
+        assert np.allclose(ws[0], ws[1], atol=1e-11 * np.abs(ws[1]).max())
+
+
 # ------------------------------------------------------------------ the whole path
 def _problem(problems, name):
     if name == "petersen":

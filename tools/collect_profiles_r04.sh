@@ -57,4 +57,17 @@ if [ "$WHAT" = all ] || [ "$WHAT" = seeds ]; then
   python3 tools/big_instance_seeds.py 30 0 >> $O/big_instance_seeds.txt 2>&1
   ( python3 tools/bd_failure_compare.py device 8 3000 4 0; python3 tools/bd_failure_compare.py device 8 3000 6 0; python3 tools/bd_failure_rate.py 4096 2000 commutative 2>&1 | tail -3; python3 tools/bd_failure_rate.py 4104 2000 er7 2>&1 | tail -3 ) > $O/bd_failure_rates.txt 2>&1
 fi
+if [ "$WHAT" = sytrd ]; then
+  # after the rework of the tridiagonalisation's latency chains: the default line again (kernels.sytrd_*), the dense driver's
+  # kernel statistics, every form of the tridiagonalisation against LAPACK + its time, the eigensolver beside rocSOLVER's
+  cd $R
+  python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+  SDPSR_TOOL_FLAGS=0 python3 tools/sytrd_time.py 512 1024 2048 3072 4096 8192 > $O/sytrd_time.txt 2>&1
+  python3 tools/sytrd_forms_check.py > $O/sytrd_forms_check.txt 2>&1
+  rm -f $O/eig_drivers.txt
+  for n in 1024 2048 4096; do for drv in 0 1; do python3 tools/eig_only.py $n $drv random 2>&1 | grep "syev n=" | tail -1 >> $O/eig_drivers.txt; done; done
+  python3 tools/config_times.py > $O/config_times.txt 2>&1
+  ( cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/dense -o dense -- python3 $R/bench.py --steps 3 --warmup 1 --skip-roofline --eig-driver 4 --no-graph > $O/dense_under_rocprof.json 2> /dev/null )
+  tail -n 8 $O/sytrd_time.txt $O/eig_drivers.txt $O/sytrd_forms_check.txt
+fi
 ls $O | head -80

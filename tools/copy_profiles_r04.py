@@ -19,7 +19,7 @@ pairs = [(stats("bench"), "r04_bench_n4096_kernel_stats.csv"), (stats("bench_the
 for name in ("bench_under_rocprof.json", "bench_theta_under_rocprof.json", "bench_er7_under_rocprof.json", "dense_under_rocprof.json",
              "bench_n8192.json", "bench_n8192_under_rocprof.json", "config_times.txt", "eig_drivers.txt", "stress_seeds.txt", "big_instance_seeds.txt",
              "bd_failure_rates.txt", "ab_full_basis_image.json", "ab_square_kernel_128tiles.json", "ab_square_kernel_128tiles_theta.json",
-             "restarts_per_gpu_2.json", "stedc_check.txt", "sytrd_time.txt"):
+             "restarts_per_gpu_2.json", "stedc_check.txt", "sytrd_time.txt", "sytrd_forms_check.txt"):
     pairs.append((os.path.join(src, name), "r04_" + name))
 pairs.append((os.path.join(src, "bench_default.json"), "r04_bench_n4096.json"))
 for a, b in pairs:

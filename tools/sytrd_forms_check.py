@@ -12,7 +12,7 @@ threadpool_limits(8)
 L = pkg._lib
 rng = np.random.default_rng(7)
 lib = pkg.load_library()
-cases = [(777, L.FLAG_SYTRD_PANELS), (1536, L.FLAG_SYTRD_PANELS), (2500, 0), (2500, L.FLAG_SYTRD_ONE_LAUNCH), (4104, 0), (4104, L.FLAG_SYTRD_ONE_LAUNCH)]
+cases = [(777, L.FLAG_SYTRD_PANELS), (1536, L.FLAG_SYTRD_PANELS), (2500, 0), (2500, L.FLAG_SYTRD_ONE_LAUNCH), (4104, 0), (4104, L.FLAG_SYTRD_ONE_LAUNCH), (4200, L.FLAG_SYTRD_ONE_LAUNCH)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick": cases = cases[:3]
 mats = {}
 for n, flags in cases:
