@@ -1024,6 +1024,22 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned 
     return NO_SLOT;
 }
 
+// development aid (-DLK_TIMING and SDPSR_DEBUG): wall-clock stamps (100 MHz) of the phases of the first four chunks of the
+// first / middle / last workgroup of an insert launch
+#ifdef LK_TIMING
+bool dbg_on();  // ctx.cpp (SDPSR_DEBUG)
+__device__ long long* ri_dbg = nullptr;
+#define RI_STAMP(i)                                                                                                      \
+    do {                                                                                                                  \
+        if (ri_dbg && threadIdx.x == 0 && ri_it < 4 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.x == gridDim.x / 2)) { \
+            const int which = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1);                               \
+            ri_dbg[(which * 4 + ri_it) * 8 + (i)] = wall_clock64();                                                       \
+        }                                                                                                                 \
+    } while (0)
+#else
+#define RI_STAMP(i)
+#endif
+
 // One workgroup dedups INSERT_CHUNK entries in an LDS table before touching the global one.
 // An entry whose LDS probe sequence gets long (many distinct signatures in the chunk) goes to
 // the global table directly instead.
@@ -1067,7 +1083,11 @@ refine_insert_kernel(int64_t len, const SRC src,
     // candidates per class: the extra LDS reads cost more than the nine 64-bit multiplies they replace); and the waves
     // of a workgroup running free inside a chunk -- creator lanes resolve their own slots, other waves spin on the LDS
     // word, one barrier per chunk instead of three -- 80.3 us against 79.6: the barriers are not what the waves wait for.)
+    int ri_it = -1;
+    (void)ri_it;
     for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x) {
+        ++ri_it;
+        RI_STAMP(0);
         if (need_clear) {
             for (int i = threadIdx.x; i < LDS_SLOTS; i += THREADS) {
                 l_sig[i] = 0ull;
@@ -1080,6 +1100,7 @@ refine_insert_kernel(int64_t len, const SRC src,
             l_new = 0;
         }
         __syncthreads();
+        RI_STAMP(1);
         if (l_overflow) return;  // uniform: the host repeats the pass with a larger table
         const int64_t base = blk * INSERT_CHUNK;
         if (bypass) {
@@ -1123,6 +1144,7 @@ refine_insert_kernel(int64_t len, const SRC src,
                 sgs[q] = (e < len) ? src(e) : 0ull;
             }
         }
+        RI_STAMP(2);
 #pragma unroll
         for (int q = 0; q < INSERT_PER_THREAD; ++q) {
             const int64_t e = base + q * THREADS + threadIdx.x;
@@ -1172,7 +1194,9 @@ refine_insert_kernel(int64_t len, const SRC src,
                 }
             }
         }
+        RI_STAMP(3);
         __syncthreads();
+        RI_STAMP(4);
         // publish the signatures this workgroup has not resolved yet (few classes: nothing new after the first chunks,
         // the scan of the table and its barrier are skipped; l_new is uniform after the barrier above)
         if (l_new) {
@@ -1200,9 +1224,11 @@ refine_insert_kernel(int64_t len, const SRC src,
                 slot_out[e] = out;
             }
         }
+        RI_STAMP(5);
         need_clear = l_count > LDS_SLOTS / 2;  // uniform (read after the barrier above)
         bypass = need_clear;
         __syncthreads();
+        RI_STAMP(6);
     }
 }
 
@@ -1474,8 +1500,34 @@ static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SR
     // resident workgroups per CU, measured 2..8: 5 is the minimum of a flat curve (sdpsr_opts.insert_wgs_per_cu overrides)
     if (SLOTS == 1024) g_chunks_cap = 256 * (ws.insert_wgs_per_cu > 0 ? ws.insert_wgs_per_cu : 5);
     const int g = (int)(nchunk < g_chunks_cap ? nchunk : g_chunks_cap);
+#ifdef LK_TIMING
+    long long* dbg = nullptr;
+    if (dbg_on()) {
+        hipMalloc(&dbg, 3 * 4 * 8 * 8);
+        hipMemset(dbg, 0, 3 * 4 * 8 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(ri_dbg), &dbg, sizeof(dbg));
+    }
+#endif
     refine_insert_kernel<SRC, PER, SLOTS><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
                                                                 (uint32_t)(cap - 1), ws.counters);
+#ifdef LK_TIMING
+    if (dbg) {
+        hipStreamSynchronize(s);
+        long long h[3 * 4 * 8];
+        hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 3; ++w)
+            for (int it = 0; it < 4; ++it) {
+                const long long* t = &h[(w * 4 + it) * 8];
+                if (!t[0]) continue;
+                fprintf(stderr, "[insert timing] %s grid=%d len=%lld wg=%d chunk=%d:", __PRETTY_FUNCTION__ + 40, g, (long long)len, w, it);
+                for (int i = 1; i < 7; ++i) fprintf(stderr, " %6.2f", t[i] ? (t[i] - t[0]) * 0.01 : -1.0);
+                fprintf(stderr, "  (start rel. to wg0 chunk0 %.2f)\n", (t[0] - h[0]) * 0.01);
+            }
+        long long* z = nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(ri_dbg), &z, sizeof(z));
+        hipFree(dbg);
+    }
+#endif
 }
 
 template <typename CT>
