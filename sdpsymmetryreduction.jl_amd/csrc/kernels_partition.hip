@@ -749,6 +749,7 @@ struct IjWalk {
 };
 struct SrcArray {
     static constexpr bool kIJ = false;
+    static constexpr int kFetchBatch = 1;
     const uint64_t* __restrict__ sig;
     __device__ __forceinline__ bool walks() const { return false; }
     __device__ __forceinline__ bool lower() const { return false; }
@@ -758,6 +759,7 @@ struct SrcArray {
 };
 struct SrcPair {  // sig_f64_pair_kernel; packed: the lower triangle column by column (a, b symmetric)
     static constexpr bool kIJ = true;
+    static constexpr int kFetchBatch = 8;  // refine_insert_kernel: entries loaded before their signatures are formed
     const double* __restrict__ a;
     const double* __restrict__ b;
     int n, packed;
@@ -795,6 +797,7 @@ struct SrcPair {  // sig_f64_pair_kernel; packed: the lower triangle column by c
 template <int R>
 struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig only
     static constexpr bool kIJ = true;
+    static constexpr int kFetchBatch = 1;
     const double* __restrict__ U;
     const uint32_t* L;  // may alias the label output of the refinement (read before the entry's own write)
     const double* __restrict__ coef;
@@ -862,6 +865,7 @@ struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig onl
 template <typename CT, int T>
 struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by column
     static constexpr bool kIJ = true;
+    static constexpr int kFetchBatch = T <= 2 ? 4 : 1;  // (measured at T = 2: 65 -> 58 us; wider entries not measured)
     int n;
     int64_t ld;
     const uint32_t* L;
@@ -913,6 +917,7 @@ struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by c
 template <int R, int T>  // T = 2 or 4 channels
 struct SrcJoint {
     static constexpr bool kIJ = true;
+    static constexpr int kFetchBatch = 1;  // (2: 79 -> 99 us, 8: 114 us for SrcJoint<2, 2>)
     const double* __restrict__ U;
     const uint32_t* L;
     const double* __restrict__ coef;
@@ -1126,18 +1131,41 @@ refine_insert_kernel(int64_t len, const SRC src,
         // all 16 signature loads are issued before the first probe: the probe loop contains LDS
         // atomics, which the compiler will not move global loads across
         uint64_t sgs[INSERT_PER_THREAD];
-        if (SRC::kIJ && src.walks()) {  // uniform
-            const int nn = src.order();
-            const bool low = src.lower();
-            uint32_t wi = 0, wj = 0;
-            if (base + threadIdx.x < len) IjWalk::locate(nn, low, base + threadIdx.x, wi, wj);
+        bool walked = false;
+        if constexpr (SRC::kIJ) {
+            if (src.walks()) {  // uniform
+                walked = true;
+                const int nn = src.order();
+                const bool low = src.lower();
+                uint32_t wi = 0, wj = 0;
+                if (base + threadIdx.x < len) IjWalk::locate(nn, low, base + threadIdx.x, wi, wj);
+                // SRC::kFetchBatch entries are loaded before their signatures are formed.  `sgs[q] = sig(fetch(..))` entry by entry,
+                // with the walk's column-wrap loop between two entries, compiles to load - wait - hash per entry: eight dependent
+                // memory round trips per chunk (round 4, profiles/r04_insert_phases.txt: 9-10 us of a 14 us chunk for the pair
+                // source, 4.5-7 of 10 for the channel source).  The batch is bounded by registers: all 8 entries at once take
+                // the channel source from 71 to 138 registers and the joint source to 199 (2-3 resident workgroups per CU instead
+                // of 5) and make them slower, 65 -> 73 and 82 -> 114 us.  Kept where it measured faster: the pair source with all 8
+                // (71 -> 54 us, four workgroups per CU), the channel source with 4 (65 -> 58 us); the joint source stays at 1.
+                constexpr int FB = SRC::kFetchBatch;
+                static_assert(INSERT_PER_THREAD % FB == 0, "");
 #pragma unroll
-            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-                const int64_t e = base + q * THREADS + threadIdx.x;
-                sgs[q] = (e < len) ? src.at(wi, wj, e) : 0ull;
-                IjWalk::step(nn, low, wi, wj, THREADS);
+                for (int q0 = 0; q0 < INSERT_PER_THREAD; q0 += FB) {
+                    typename SRC::Raw raws[FB];
+#pragma unroll
+                    for (int q = 0; q < FB; ++q) {
+                        const int64_t e = base + (q0 + q) * THREADS + threadIdx.x;
+                        if (e < len) raws[q] = src.fetch(wi, wj, e);
+                        IjWalk::step(nn, low, wi, wj, THREADS);
+                    }
+#pragma unroll
+                    for (int q = 0; q < FB; ++q) {
+                        const int64_t e = base + (q0 + q) * THREADS + threadIdx.x;
+                        sgs[q0 + q] = (e < len) ? src.sig(raws[q]) : 0ull;
+                    }
+                }
             }
-        } else {
+        }
+        if (!walked) {
 #pragma unroll
             for (int q = 0; q < INSERT_PER_THREAD; ++q) {
                 const int64_t e = base + q * THREADS + threadIdx.x;
@@ -1498,7 +1526,8 @@ static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SR
                           size_t cap) {
     const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
     // resident workgroups per CU, measured 2..8: 5 is the minimum of a flat curve (sdpsr_opts.insert_wgs_per_cu overrides)
-    if (SLOTS == 1024) g_chunks_cap = 256 * (ws.insert_wgs_per_cu > 0 ? ws.insert_wgs_per_cu : 5);
+    // (a fetch-first source holds its raw entries in registers: 126 of them, four workgroups per CU are resident)
+    if (SLOTS == 1024) g_chunks_cap = 256 * (ws.insert_wgs_per_cu > 0 ? ws.insert_wgs_per_cu : (SRC::kFetchBatch >= 8 ? 4 : 5));
     const int g = (int)(nchunk < g_chunks_cap ? nchunk : g_chunks_cap);
 #ifdef LK_TIMING
     long long* dbg = nullptr;
