@@ -1654,31 +1654,45 @@ verify_lower_kernel(int n, int64_t ld, const uint32_t* __restrict__ Lp, const do
         const uint32_t* Lj = Lp + poff;
         const int32_t* Cj = C + (int64_t)j * ld;
         const double* Uj = U + (int64_t)j * n;
-#pragma unroll 2
-        for (int i = j + threadIdx.x; i < n; i += 256) {
-            const uint32_t l = __builtin_nontemporal_load(&Lj[i]);
-            int32_t c[T];
+        // VB entries of a thread per trip: their labels and values in one batch of loads, then the representatives of their
+        // classes in a second one (entry by entry it was two dependent memory round trips per entry, round 4)
+        constexpr int VB = 4;
+        for (int i0 = j + threadIdx.x; i0 < n; i0 += 256 * VB) {
+            uint32_t l[VB];
+            int32_t c[VB][T];
+            double u[VB][R > 0 ? R : 1];
 #pragma unroll
-            for (int t = 0; t < T; ++t) c[t] = __builtin_nontemporal_load(&Cj[(int64_t)t * ld * ld + i]);
-            double u[R > 0 ? R : 1];
-            if (JOINT) {
+            for (int b = 0; b < VB; ++b) {
+                const int i = i0 + 256 * b;
+                const bool ok = i < n;
+                l[b] = ok ? __builtin_nontemporal_load(&Lj[i]) : 0u;
 #pragma unroll
-                for (int k = 0; k < R; ++k) u[k] = __builtin_nontemporal_load(&Uj[(int64_t)k * nn + i]);
+                for (int t = 0; t < T; ++t) c[b][t] = ok ? __builtin_nontemporal_load(&Cj[(int64_t)t * ld * ld + i]) : 0;
+                if (JOINT) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) u[b][k] = ok ? __builtin_nontemporal_load(&Uj[(int64_t)k * nn + i]) : 0.0;
+                }
             }
-            VerifyRef r;
-            r.x = 0;
-            r.ybits = 0;
-            r.c[0] = r.c[1] = r.c[2] = r.c[3] = 0;
-            if (l) r = ref[l - 1];  // label 0: the zero class stays together only while every value is zero
-            if (JOINT) {
-                double p = 0;
+            VerifyRef r[VB];
 #pragma unroll
-                for (int k = 0; k < R; ++k) p = fma(u[k], cf[k], p);
-                const uint64_t yb = sdpsr_round_key(r.x - p, atol, scale);
-                bad = bad || yb != r.ybits;
+            for (int b = 0; b < VB; ++b) {
+                r[b].x = 0;
+                r[b].ybits = 0;
+                r[b].c[0] = r[b].c[1] = r[b].c[2] = r[b].c[3] = 0;
+                if (l[b]) r[b] = ref[l[b] - 1];  // label 0 (and the slots past the column): the zero class stays together only while every value is zero
             }
 #pragma unroll
-            for (int t = 0; t < T; ++t) bad = bad || c[t] != r.c[t];
+            for (int b = 0; b < VB; ++b) {
+                if (JOINT) {
+                    double p = 0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) p = fma(u[b][k], cf[k], p);
+                    const uint64_t yb = sdpsr_round_key(r[b].x - p, atol, scale);
+                    bad = bad || yb != r[b].ybits;
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) bad = bad || c[b][t] != r[b].c[t];
+            }
         }
     }
     if (bad) flag[0] = 1u;
@@ -1724,14 +1738,27 @@ uconst_check_kernel(int n, const uint32_t* __restrict__ Lp, const double* __rest
         const int64_t poff = (int64_t)j * n - (int64_t)j * (j - 1) / 2 - j;
         const uint32_t* Lj = Lp + poff;
         const double* Uj = U + (int64_t)j * n;
-#pragma unroll 2
-        for (int i = j + threadIdx.x; i < n; i += 256) {
-            const uint32_t l = __builtin_nontemporal_load(&Lj[i]);
+        constexpr int VB = 4;  // entries per trip: labels and values first, then the classes' reference codes (see verify_lower_kernel)
+        for (int i0 = j + threadIdx.x; i0 < n; i0 += 256 * VB) {
+            uint32_t l[VB];
+            double uv[VB][R];
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const uint64_t code = sdpsr_round_key(__builtin_nontemporal_load(&Uj[(int64_t)k * nn + i]), atol, scale);
-                bad = bad || code != (l ? ref[(int64_t)(l - 1) * R + k] : zero_code);
+            for (int b = 0; b < VB; ++b) {
+                const int i = i0 + 256 * b;
+                const bool ok = i < n;
+                l[b] = ok ? __builtin_nontemporal_load(&Lj[i]) : 0u;
+#pragma unroll
+                for (int k = 0; k < R; ++k) uv[b][k] = ok ? __builtin_nontemporal_load(&Uj[(int64_t)k * nn + i]) : 0.0;
             }
+            uint64_t rc[VB][R];
+#pragma unroll
+            for (int b = 0; b < VB; ++b)
+#pragma unroll
+                for (int k = 0; k < R; ++k) rc[b][k] = l[b] ? ref[(int64_t)(l[b] - 1) * R + k] : zero_code;
+#pragma unroll
+            for (int b = 0; b < VB; ++b)
+#pragma unroll
+                for (int k = 0; k < R; ++k) bad = bad || sdpsr_round_key(uv[b][k], atol, scale) != rc[b][k];
         }
     }
     if (bad) flag[0] = 1u;
