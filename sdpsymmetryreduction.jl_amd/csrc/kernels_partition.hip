@@ -1416,8 +1416,25 @@ __global__ void refine_label_kernel(int64_t len, const uint32_t* slot, uint32_t*
     // store into pinned host memory instead of a separate 16-byte copy launch (~5 us + a launch gap per refinement)
     if (host_counters && blockIdx.x == 0 && threadIdx.x < 4) host_counters[threadIdx.x] = threadIdx.x < 3 ? counters[threadIdx.x] : 0u;
     if (counters[1] || (expect_small && counters[0] > SMALL_K)) return;
+    // four consecutive entries per thread and trip: one 16-byte load, four gathers in flight together, one 16-byte store (one
+    // entry per trip was a load, a wait, a gather, a wait and a store, sixteen times per thread; round 4)
+    typedef uint32_t rl_u32x4 __attribute__((ext_vector_type(4)));
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride) {
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (16-byte accesses only when both arrays allow them: the labels may be a caller's device pointer)
+    const int64_t len4 = ((reinterpret_cast<uintptr_t>(slot) | reinterpret_cast<uintptr_t>(labels_out)) & 15) ? 0 : (len >> 2);
+    const rl_u32x4* slot4 = reinterpret_cast<const rl_u32x4*>(slot);
+    rl_u32x4* out4 = reinterpret_cast<rl_u32x4*>(labels_out);
+    for (int64_t q = t0; q < len4; q += stride) {
+        const rl_u32x4 sl = __builtin_nontemporal_load(&slot4[q]);
+        rl_u32x4 o;
+        o.x = (sl.x == NO_SLOT) ? 0u : tab_lab[sl.x];
+        o.y = (sl.y == NO_SLOT) ? 0u : tab_lab[sl.y];
+        o.z = (sl.z == NO_SLOT) ? 0u : tab_lab[sl.z];
+        o.w = (sl.w == NO_SLOT) ? 0u : tab_lab[sl.w];
+        out4[q] = o;
+    }
+    for (int64_t e = 4 * len4 + t0; e < len; e += stride) {
         const uint32_t sl = __builtin_nontemporal_load(&slot[e]);
         labels_out[e] = (sl == NO_SLOT) ? 0u : tab_lab[sl];
     }
