@@ -865,7 +865,7 @@ struct SrcProj {  // proj_apply_kernel with xin = nullptr, do_round = 1, sig onl
 template <typename CT, int T>
 struct SrcChan {  // sig_channels_kernel; packed: the lower triangle column by column
     static constexpr bool kIJ = true;
-    static constexpr int kFetchBatch = T <= 2 ? 4 : 1;  // (measured at T = 2: 65 -> 58 us; wider entries not measured)
+    static constexpr int kFetchBatch = T <= 2 ? 4 : 1;  // (measured at T = 2: 65 -> 58 us; all 8 with three workgroups per CU: 64 us; wider entries not measured)
     int n;
     int64_t ld;
     const uint32_t* L;
