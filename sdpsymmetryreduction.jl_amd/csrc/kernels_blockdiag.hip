@@ -920,11 +920,17 @@ class_sums_small_d_kernel(int n, int d, int tstride, const uint32_t* __restrict_
         const int rr = bq / bpr, bb = bq - rr * bpr;
         if (bb == 0)
             for (int i = 0; i <= d; ++i) mine[i] = 0.0;
+        // LDS adds without a return value: the eight updates of a batch queue up behind each other in the LDS pipe (in order
+        // per wave, so the sums are formed in the same order as by `mine[l] += v`) instead of eight read - add - write round
+        // trips, each waiting for the one before (round 4: 32.9 -> 29.2 us at N = 4096, d = 34)
+        double vv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = bb * 512 + u * 64 + lane;
-            mine[lab[u]] += c < n ? sx[c] : 0.0;
+            vv[u] = c < n ? sx[c] : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) atomicAdd(&mine[lab[u]], vv[u]);
         if (bb == bpr - 1) {
             const int r = blockIdx.x * 4 + rr * rows_per_round + wave;
             __syncthreads();
@@ -1055,6 +1061,7 @@ class_sums2_kernel(int n, int d, int tstride, const uint32_t* __restrict__ L, co
         const int rr = bq / bpr, bb = bq - rr * bpr;
         if (bb == 0)
             for (int i = 0; i <= d; ++i) mine[i] = make_double2(0.0, 0.0);
+        // (LDS adds without a return value as in class_sums_small_d_kernel -- two per entry here -- measured no faster: 39.8 -> 41.3 us)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = bb * 512 + u * 64 + lane;

@@ -6,5 +6,5 @@ python3 - <<PY
 import csv,glob
 f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/abins/**/b_kernel_stats.csv",recursive=True)[0]
 for r in list(csv.DictReader(open(f))):
-    if any(k in r['Name'] for k in ('insert','verify_lower','uconst_check','refine_label_kernel')): print(r['Name'][:90], r['Calls'], "%.1f us"%(float(r['AverageNs'])/1e3))
+    if any(k in r['Name'] for k in ('insert','class_sums','uconst_check','refine_label_kernel')): print(r['Name'][:90], r['Calls'], "%.1f us"%(float(r['AverageNs'])/1e3))
 PY
