@@ -26,6 +26,8 @@ extern "C" {
        returns in ms_per_launch[0] the largest absolute deviation of sampled rows of Y from a host
        evaluation in extended precision instead of the time.
    10 = the HOST eigensolver of the compressed problem (order n <= 512, one host core, no device work);
+   11 = kind 3 as the FIRST refinement of a call meets it: the class-count prediction is reset before every
+       repetition (a many-classes input pays the overflowing first pass, the sample and the path it selects);
    ms_per_launch[0] = average milliseconds per launch. */
 int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps,
                          double* ms_per_launch);

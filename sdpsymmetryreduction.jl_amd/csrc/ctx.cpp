@@ -221,19 +221,20 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
     if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || c->num_cus < 1)
         c->num_cus = 256;
     // per-device kernel attributes (dynamic LDS above 64 KiB); cheap and idempotent
-    gemm_set_device_attributes();
-    gemm_sym_set_device_attributes();
-    refine_bucket_set_device_attributes();
-    blockdiag_set_device_attributes();
-    module_set_device_attributes();
-    partition_set_device_attributes();
-    sytrd_set_device_attributes();
-    small_syev_set_device_attributes();
-    stedc_set_device_attributes();
-    batched_set_device_attributes();
-    backtransform_set_device_attributes();
-    complex_set_device_attributes();
-    if (hipGetLastError() != hipSuccess) {
+    bool attrs_ok = true;
+    attrs_ok &= gemm_set_device_attributes();
+    attrs_ok &= gemm_sym_set_device_attributes();
+    attrs_ok &= refine_bucket_set_device_attributes();
+    attrs_ok &= blockdiag_set_device_attributes();
+    attrs_ok &= module_set_device_attributes();
+    attrs_ok &= partition_set_device_attributes();
+    attrs_ok &= sytrd_set_device_attributes();
+    attrs_ok &= small_syev_set_device_attributes();
+    attrs_ok &= stedc_set_device_attributes();
+    attrs_ok &= batched_set_device_attributes();
+    attrs_ok &= backtransform_set_device_attributes();
+    attrs_ok &= complex_set_device_attributes();
+    if (hipGetLastError() != hipSuccess || !attrs_ok) {  // a failed LDS opt-in would surface later as an opaque launch error
         hipStreamDestroy(c->stream);
         delete c;
         return SDPSR_HIP_ERROR;

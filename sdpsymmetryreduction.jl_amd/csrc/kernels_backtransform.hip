@@ -115,9 +115,11 @@ bt_larft_kernel(const double* __restrict__ Gall, const double* __restrict__ tau,
     }
 }
 
-void backtransform_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+bool backtransform_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (128 * 129 + 16 * 128) * 8);
+    return ok;
 }
 
 void launch_bt_extract_panel(hipStream_t s, int64_t n, int64_t ld, const double* A, int64_t j0, int64_t r0, double* Vp,

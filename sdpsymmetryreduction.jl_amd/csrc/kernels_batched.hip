@@ -270,9 +270,11 @@ size_t batched_eigdec_lds_bytes(int64_t n) {
     return (size_t)(3 * ldl * m) * 8 + (size_t)n * n * 8 + (size_t)(m - 1) * half * 4 + 64;
 }
 
-void batched_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&eigdec_batched64_kernel),
+bool batched_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&eigdec_batched64_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    return ok;
 }
 
 // status/neig/nclasses: device arrays of `count` ints.

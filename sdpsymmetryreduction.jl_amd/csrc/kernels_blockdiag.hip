@@ -1187,22 +1187,24 @@ bool launch_basis_image_fix_pair(hipStream_t s, int64_t n, int64_t d, int64_t S1
 }
 
 // per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes)
-void blockdiag_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
+bool blockdiag_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&class_sums_small_d_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_qtaq_block_norms_kernel),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&small_qtaq_block_norms_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_cluster_qtaq_block_norms_kernel),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&small_cluster_qtaq_block_norms_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_outer_mfma_kernel),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_outer_mfma_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<2>),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&basis_image_rows_kernel<2>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    return ok;
 }
 
 // ldo: distance between the output columns (>= n; rows >= n are not written)

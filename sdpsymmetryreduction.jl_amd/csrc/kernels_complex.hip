@@ -576,13 +576,15 @@ void launch_cx_basis_image_sorted(hipStream_t s, int64_t n, int64_t d, int64_t S
     cx_basis_image_sorted_kernel<<<(unsigned)d, 256, 0, s>>>((int)n, (int)S, ent, cls_ptr, Qhat, descA, descB, atol, out);
 }
 
-void complex_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_heev_jacobi64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+bool complex_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_heev_jacobi64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_block_norms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_block_norms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         64 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_irreducible_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&cx_irreducible_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         144 * 1024);
+    return ok;
 }
 
 void launch_cx_gather_herm(hipStream_t s, int64_t n, const uint32_t* L, uint64_t key, double* Hr, double* Hi) {

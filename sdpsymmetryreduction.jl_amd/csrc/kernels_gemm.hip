@@ -666,23 +666,27 @@ gemm_tn_dma256_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restri
 // Dynamic-LDS limits are a per-device property of a kernel: sdpsr_create() calls this with the
 // ctx's device current, so a process may hold ctxs on several GPUs (no process-global flags).
 template <int KIND>
-static void gemm_set_attributes_kind() {
+static bool gemm_set_attributes_kind() {
+    bool ok = true;
     constexpr int KBt = GemmTraits<KIND>::KB;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<KIND>),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<KIND>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM * (KBt + 16));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND, 0>),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND, 0>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM * 128);
     if constexpr (KIND == KIND_F64)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND, 1>),
+        ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<KIND, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM * 128);
     if constexpr (KIND == KIND_I8 || KIND == KIND_F32)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma256_kernel<KIND>),
+        ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma256_kernel<KIND>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * BM2 * 128);
+    return ok;
 }
-void gemm_set_device_attributes() {
-    gemm_set_attributes_kind<KIND_I8>();
-    gemm_set_attributes_kind<KIND_F32>();
-    gemm_set_attributes_kind<KIND_F64>();
+bool gemm_set_device_attributes() {
+    bool ok = true;
+    ok &= gemm_set_attributes_kind<KIND_I8>();
+    ok &= gemm_set_attributes_kind<KIND_F32>();
+    ok &= gemm_set_attributes_kind<KIND_F64>();
+    return ok;
 }
 
 template <int KIND>

@@ -354,8 +354,10 @@ __global__ void __launch_bounds__(SYM_NT) i8_symsquare_kernel(SymSquareArgs a) {
     }
 }
 
-void gemm_sym_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&i8_symsquare_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+bool gemm_sym_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&i8_symsquare_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return ok;
 }
 
 // Does the persistent launch pay for an n x n problem with T channels?  Its big jobs (lower-triangle macro-tiles of

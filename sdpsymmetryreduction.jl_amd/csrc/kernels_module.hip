@@ -552,9 +552,11 @@ label_spmm_mfma_kernel(int n, const uint32_t* __restrict__ L, SpmmKeys keys, int
 
 // per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes): two slabs of the
 // four-tile form are 80 KiB
-void module_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&label_spmm_mfma_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+bool module_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&label_spmm_mfma_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         150 * 1024);
+    return ok;
 }
 
 size_t label_spmm_partial_doubles(int64_t n, int w) {

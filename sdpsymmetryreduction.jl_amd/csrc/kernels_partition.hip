@@ -2151,9 +2151,11 @@ __global__ void reduce_columns_final_kernel(int64_t nchunks, int m, int d, const
     out[r + i * m] = acc;  // m x d column-major
 }
 // per-device kernel attributes, set by sdpsr_create() (see gemm_set_device_attributes)
-void partition_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
+bool partition_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    return ok;
 }
 
 int64_t reduce_columns_chunk(int64_t len, int64_t m, int64_t d) {

@@ -705,8 +705,10 @@ size_t stedc_descriptors(int64_t ld, std::vector<int>& out) {
     return desc.size() * sizeof(DcMerge);
 }
 void* stedc_descriptor_slot(void* ws, int64_t ld) { return (char*)ws + (size_t)(16 * ld + 64) * 8 + (size_t)(16 * ld + 64) * 4; }
-void stedc_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&dc_build_u_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DC_COLMAX * 8);
+bool stedc_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&dc_build_u_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DC_COLMAX * 8);
+    return ok;
 }
 
 // d, e: device (n, n-1); w: device n (ascending); Z: ld x ld (eigenvectors in the leading n x n, rest zero); W1, W2:

@@ -954,9 +954,11 @@ static SytrdArgs sytrd_args(int64_t n, double* A, int64_t ld, double* d, double*
 }
 
 // per-device kernel attributes, set by sdpsr_create() with the ctx's device current
-void sytrd_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_syr2k_mfma_kernel),
+bool sytrd_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&sytrd_syr2k_mfma_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return ok;
 }
 
 // The launch sequence of a tridiagonalisation goes either to a stream or, node by node, into a
@@ -1580,13 +1582,15 @@ small_syev_jacobi64_kernel(int n, double* __restrict__ Ag, int64_t lda, double* 
     }
 }
 
-void small_syev_set_device_attributes() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel<true>),
+bool small_syev_set_device_attributes() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel<true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel<false>),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi64_kernel<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi_kernel),
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&small_syev_jacobi_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    return ok;
 }
 
 bool launch_small_syev(hipStream_t s, int64_t n, double* A, int64_t lda, double* w, double* Vtmp, int* info) {

@@ -44,21 +44,30 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
     int log2cap = std::min(full, std::max(12, c->table_log2_hint));
     const int64_t rb = (int64_t)refine_block_entries();
     const int64_t nblk = (len + rb - 1) / rb;
-    int attempts = 0;
-    bool mispredicted = false;
+    bool mispredicted = false, sampled = false, cub_fallback = false;
     c->first_idx_labels = nullptr;  // whatever happens below, the old representatives no longer describe `labels`
-    // many-classes regime (problems without symmetry: ~len/2 distinct signatures): a hash table
-    // that large means one global atomic per entry into memory no cache holds; the radix-sort
-    // relabel (kernels_refine_sort.hip) moves ~15x the algorithmic bytes but streams.  Taken when
-    // the previous refinement ended above 2^18 classes, or when a table of 2^20 slots overflows.
-    // refine_path 2 / 3 force the hipCUB sort / the bucketed grouping at any size (comparison, tests)
+    // Which relabel?  Few classes: a hash table (LDS level + a global one that stays in L2).  Many classes (problems
+    // without symmetry: ~len / 2 distinct signatures): a table that large is one global atomic per entry into memory no
+    // cache holds -- the bucketed grouping of kernels_refine_bucket.hip streams instead.  The choice is made BEFORE a
+    // pass runs to its end: from the class count the previous refinement of this call ended with (table_log2_hint), and,
+    // when a table built on that prediction overflows (the pass stops within its first chunks then), from a SAMPLE of
+    // the signatures: 65 536 stratified entries through a small table give the distinct count d_s and the numbers f1,
+    // f2 of signatures seen once / twice; Chao's estimate d_s + f1 (f1 - 1) / (2 (f2 + 1)) of the total is within a few
+    // percent where it matters (classes of ~2 entries: f1 ~ m, f2 ~ m^2 / len) and errs low only for partitions whose
+    // small classes hide behind huge ones -- then the table sized from it overflows once more and the grouping runs.
+    // (Rounds 3-4 walked a ladder of 2^12 -> 2^16 -> 2^20 slots: 12.7 ms of failing passes on a fresh N = 4096 problem
+    // without symmetry.)  refine_path 2 / 3 force the hipCUB sort / the bucketed grouping at any size (comparison, tests)
     const bool forced_relabel = c->opts.refine_path == 2 || c->opts.refine_path == 3;
     const bool sort_ok = ((len >= (int64_t(1) << 18) && c->opts.refine_path != 1) || forced_relabel) && len < (int64_t(1) << 31);
-    bool use_sort = sort_ok && (c->table_log2_hint >= 21 || forced_relabel);
+    // the grouping's time does not depend on the class count (0.4 ms at 16.7 M entries); the table path's does
+    const int64_t group_from = std::max<int64_t>(int64_t(1) << 16, len >> 7);
+    // (table_log2_hint = ceil(log2(8 d + 1)) of the previous refinement's class count d)
+    bool use_sort = sort_ok && (forced_relabel || (c->table_log2_hint >= 4 && (int64_t(1) << (c->table_log2_hint - 4)) >= group_from));
     for (;;) {
         if (use_sort) {
             // the hand-written bucketed grouping (kernels_refine_bucket.hip); hipCUB's radix sort behind refine_path = 2
-            const bool cub = c->opts.refine_path == 2;
+            // and as the fallback for signatures the grouping reports it cannot resolve
+            const bool cub = c->opts.refine_path == 2 || cub_fallback;
             const size_t wsb = cub ? refine_sorted_workspace_bytes(len) : refine_bucketed_workspace_bytes(len);
             void* wsp = ctx_buf(c, "ref_sort_ws", wsb);
             uint32_t* counters = (uint32_t*)ctx_buf(c, "ref_counters", refine_counters_bytes());
@@ -67,17 +76,23 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
             if (!wsp || !counters || !firsts || !h) return SDPSR_OUT_OF_MEMORY;
             if (!materialize()) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "refine: signature source needs scratch");
             if (cub ? !launch_refine_sorted(c->stream, len, src.sig, labels, wsp, wsb, counters)
-                    : !launch_refine_bucketed(c->stream, len, src.sig, labels, wsp, wsb, counters, firsts, refine_first_cap()))
+                    : !launch_refine_bucketed(c->stream, len, src.sig, labels, wsp, wsb, counters, firsts, refine_first_cap(), h))
                 return ctx_fail(c, SDPSR_HIP_ERROR, "sorted / bucketed refinement failed");
-            HIP_TRY(c, hipMemcpyAsync(h, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            if (cub) HIP_TRY(c, hipMemcpyAsync(h, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));  // (the grouping's label pass stores them itself)
             if (sym_n > 0 && symflag_dev) {
                 launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);
                 HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             }
             HIP_TRY(c, ctx_sync_stream(c, c->stream));
-            if (sym_n > 0 && symflag_dev && sym_out) *sym_out = h[8] ? 0 : 1;
             HIP_TRY(c, hipGetLastError());
-            if (h[1]) return ctx_fail(c, SDPSR_HIP_ERROR, "bucketed refinement: a hash bucket could not be resolved (signatures that do not spread)");
+            if (h[1]) {
+                // a bucket the grouping could not resolve (signatures that do not spread over its sub-passes): the radix sort
+                // has no such case.  (The grouping reads the signature ARRAY, never the old labels: nothing to restore.)
+                if (cub) return ctx_fail(c, SDPSR_HIP_ERROR, "sorted refinement reported a failure");
+                cub_fallback = true;
+                continue;
+            }
+            if (sym_n > 0 && symflag_dev && sym_out) *sym_out = h[8] ? 0 : 1;
             *nparts = h[2];
             c->table_log2_hint = std::min(full, std::max(12, ceil_log2((uint64_t)h[2] * 8 + 1)));
             if (!cub && h[2] <= refine_first_cap()) c->first_idx_labels = labels;  // "ref_first" describes these labels
@@ -97,7 +112,7 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         ws.insert_wgs_per_cu = c->opts.insert_wgs_per_cu;
         ws.nblk = (int)nblk;
         // hint 12 <=> last dim <= 512; a table grown after an overflow in this call holds more than 0.75 * 2^12 classes
-        ws.expect_small = (!mispredicted && c->table_log2_hint <= 12 && log2cap <= 12) ? 1 : 0;
+        ws.expect_small = (!mispredicted && !sampled && c->table_log2_hint <= 12 && log2cap <= 12) ? 1 : 0;
         const bool sym_fused = sym_n > 0 && sym_n * sym_n == len;  // verdict in counters[3], same read-back
         uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
         if (!h) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
@@ -117,18 +132,46 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
             continue;
         }
         if (h[1]) {  // table too small for this many classes
-            if (sort_ok) {  // 2^16, 2^20 slots, then the sorted relabel (it wins beyond ~2^18 classes)
-                // (up to 2^21 entries the sorted relabel follows the FIRST overflow -- more than 3072 classes: it takes
-                // 0.25 ms at 524 800 entries whatever their number, a failing pass over a 2^16-slot table 0.66 ms, a
-                // successful one over 2^20 slots with all entries distinct 0.5 ms)
-                if (log2cap >= 20 || len <= (int64_t(1) << 21)) use_sort = true;
-                else log2cap = std::min(full, log2cap < 16 ? 16 : 20);
+            if (log2cap >= full) return ctx_fail(c, SDPSR_HIP_ERROR, "refine hash table overflow at full size");
+            if (len < (int64_t(1) << 16)) {  // small inputs: the full-size table is a few hundred KB
+                log2cap = full;
                 continue;
             }
-            if (log2cap >= full) return ctx_fail(c, SDPSR_HIP_ERROR, "refine hash table overflow at full size");
-            // the dimension can jump by orders of magnitude between two refinements (generic
-            // problems go from a handful of classes to ~n^2/2 in one step): one large step, then full
-            log2cap = (++attempts >= 2) ? full : std::min(full, log2cap + 6);
+            if (sampled) {  // the estimate was too low (small classes hidden behind huge ones)
+                if (sort_ok) use_sort = true;
+                else log2cap = full;
+                continue;
+            }
+            // how many classes are there?  (A computed source is written out as an array first: the sample reads it, and so
+            // does whichever relabel follows -- the grouping needs it anyway, the table path takes it as its source.)
+            if (!materialize()) {
+                log2cap = std::min(full, log2cap + 6);
+                continue;
+            }
+            slot = labels;  // array source: the slots go in place, nothing reads the old labels any more
+            void* sws = ctx_buf(c, "ref_sample", refine_sample_workspace_bytes());
+            uint32_t* hs = (uint32_t*)ctx_pinned(c, 1024);
+            if (!sws || !hs) return SDPSR_OUT_OF_MEMORY;
+            hs += 224;  // its own pinned words (counters at 0, verify verdict at 128, basis verdict at 192)
+            const int64_t m = launch_refine_sample(c->stream, len, src.sig, sws, hs);
+            if (m <= 0) return ctx_fail(c, SDPSR_HIP_ERROR, "refine: sample launch failed");
+            HIP_TRY(c, ctx_sync_stream(c, c->stream));
+            HIP_TRY(c, hipGetLastError());
+            sampled = true;
+            const double nz = hs[0], ds = hs[1], f1 = hs[2], f2 = hs[3];
+            double est = ds;
+            if (m < len) {
+                est = ds + f1 * std::max(f1 - 1.0, 0.0) / (2.0 * (f2 + 1.0));
+                est = std::min(est, nz * (double)len / (double)m + 1.0);  // no more classes than non-zero entries
+            }
+            if (dbg_on()) fprintf(stderr, "[sdpsr] refine: sample of %lld: %g non-zero, %g distinct, %g once, %g twice -> ~%.3g classes\n",
+                                  (long long)m, nz, ds, f1, f2, est);
+            if (sort_ok && est >= (double)group_from) {
+                use_sort = true;
+                continue;
+            }
+            // a table with <= 1/3 of its slots taken by the estimate (the flag goes up at 3/4), at least four times the last one
+            log2cap = std::min(full, std::max(log2cap + 2, ceil_log2((uint64_t)(est * 3.0) + 1)));
             continue;
         }
         *nparts = h[2];

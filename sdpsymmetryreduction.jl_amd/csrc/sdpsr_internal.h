@@ -215,9 +215,13 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
 
 // kernels_refine_sort.hip: radix-sort relabel for the many-classes regime
 size_t refine_bucketed_workspace_bytes(int64_t len);
-void refine_bucket_set_device_attributes();
+bool refine_bucket_set_device_attributes();
 bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
-                            uint32_t* counters, uint32_t* first_idx, uint32_t first_cap);
+                            uint32_t* counters, uint32_t* first_idx, uint32_t first_cap, uint32_t* host_counters = nullptr);
+// distinct-signature estimate of a signature array from <= 65536 sampled entries; host_out (pinned, 4 words): non-zero
+// entries sampled, distinct signatures among them, signatures seen once, seen twice.  Returns the sample size (0: failed)
+size_t refine_sample_workspace_bytes();
+int64_t launch_refine_sample(hipStream_t s, int64_t len, const uint64_t* sig, void* ws, uint32_t* host_out);
 size_t refine_sorted_workspace_bytes(int64_t len);
 bool launch_refine_sorted(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
                           uint32_t* counters);
@@ -239,17 +243,18 @@ void launch_rank1_update(hipStream_t s, int64_t len, int64_t m, double* R, const
 void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double* b, double atol, double scale, double* out);
 
 // Kernels with more than 64 KiB of dynamic LDS carry a per-DEVICE attribute: sdpsr_create() sets
-// them all with the ctx's device current (no process-global "already set" flags).
-void gemm_set_device_attributes();
-void blockdiag_set_device_attributes();
-void module_set_device_attributes();
-void partition_set_device_attributes();
-void sytrd_set_device_attributes();
-void small_syev_set_device_attributes();
-void stedc_set_device_attributes();
-void batched_set_device_attributes();
-void backtransform_set_device_attributes();
-void complex_set_device_attributes();
+// them all with the ctx's device current (no process-global "already set" flags) and fails when one
+// hipFuncSetAttribute does (false: a later launch would otherwise fail with an opaque error).
+bool gemm_set_device_attributes();
+bool blockdiag_set_device_attributes();
+bool module_set_device_attributes();
+bool partition_set_device_attributes();
+bool sytrd_set_device_attributes();
+bool small_syev_set_device_attributes();
+bool stedc_set_device_attributes();
+bool batched_set_device_attributes();
+bool backtransform_set_device_attributes();
+bool complex_set_device_attributes();
 // kernels_complex.hip (complex path of blockDiagonalize, n <= 64; planes re / im, ld = n)
 void launch_cx_embed(hipStream_t s, int64_t n, const double* Hr, const double* Hi, int64_t ld2, double* M);
 void launch_cx_rot(hipStream_t s, int64_t n, int64_t cols, int64_t ld2, const double* E, double* R);
@@ -311,7 +316,7 @@ void launch_gemm_tn_i8_sym(hipStream_t s, int64_t n, int64_t k, const int8_t* X,
 bool launch_i8_symsquare(hipStream_t s, int64_t n, int64_t k, const int8_t* X, int64_t ldx, int32_t* C, int64_t ldc, int batch,
                          int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag, int num_cus, int variant);
 bool i8_symsquare_pays(int64_t n, int T, int num_cus);
-void gemm_sym_set_device_attributes();
+bool gemm_sym_set_device_attributes();
 void launch_gemm_tn_f32_sym(hipStream_t s, int64_t n, int64_t k, const float* X, int64_t ldx, float* C, int64_t ldc,
                             int batch, int64_t strideX, int64_t strideC, const uint32_t* nonsym_flag);
 void launch_unpack_symmetric_labels(hipStream_t s, int64_t n, const uint32_t* Lp, uint32_t* L);
