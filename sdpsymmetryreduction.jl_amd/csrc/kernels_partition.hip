@@ -1109,19 +1109,36 @@ refine_insert_kernel(int64_t len, const SRC src,
         if (l_overflow) return;  // uniform: the host repeats the pass with a larger table
         const int64_t base = blk * INSERT_CHUNK;
         if (bypass) {
-            // many classes (the previous chunk half filled the LDS table on its own): the LDS
-            // level only costs probes, every entry goes to the global table directly
-#pragma unroll 4
-            for (int q = 0; q < INSERT_PER_THREAD; ++q) {
-                const int64_t e = base + q * THREADS + threadIdx.x;
-                if (e < len) {
-                    const uint64_t sg = src(e);
-                    uint32_t out = NO_SLOT;
-                    if (sg) {
-                        out = global_find_or_insert(sg, tab_sig, mask, counters);
-                        if (out != NO_SLOT && tab_min[out] > (uint32_t)e) atomicMin(&tab_min[out], (uint32_t)e);
-                    }
-                    slot_out[e] = out;
+            // many classes (the previous chunk half filled the LDS table on its own): the LDS level only costs probes,
+            // every entry goes to the global table directly.  The table is write-once, so the usual case -- the signature
+            // already sits in its home slot -- is a plain read: eight entries' home slots are read together, then their
+            // minima (round 5; entry by entry this was two dependent L2 round trips per entry, 340 us at 3000 classes and
+            // 16.7 M entries).  Whatever the read does not settle (an empty or foreign slot) takes the probing path.
+            constexpr int BB = INSERT_PER_THREAD < 8 ? INSERT_PER_THREAD : 8;
+#pragma unroll
+            for (int q0 = 0; q0 < INSERT_PER_THREAD; q0 += BB) {
+                uint64_t sb[BB];
+                unsigned long long cur[BB];
+                uint32_t outs[BB], mn[BB];
+#pragma unroll
+                for (int q = 0; q < BB; ++q) {
+                    const int64_t e = base + (q0 + q) * THREADS + threadIdx.x;
+                    sb[q] = (e < len) ? src(e) : 0ull;
+                }
+#pragma unroll
+                for (int q = 0; q < BB; ++q) cur[q] = sb[q] ? tab_sig[(uint32_t)sb[q] & mask] : 0ull;
+#pragma unroll
+                for (int q = 0; q < BB; ++q) {
+                    outs[q] = NO_SLOT;
+                    if (sb[q]) outs[q] = (cur[q] == sb[q]) ? ((uint32_t)sb[q] & mask) : global_find_or_insert(sb[q], tab_sig, mask, counters);
+                }
+#pragma unroll
+                for (int q = 0; q < BB; ++q) mn[q] = outs[q] != NO_SLOT ? tab_min[outs[q]] : 0u;
+#pragma unroll
+                for (int q = 0; q < BB; ++q) {
+                    const int64_t e = base + (q0 + q) * THREADS + threadIdx.x;
+                    if (outs[q] != NO_SLOT && mn[q] > (uint32_t)e) atomicMin(&tab_min[outs[q]], (uint32_t)e);
+                    if (e < len) slot_out[e] = outs[q];
                 }
             }
             continue;
@@ -1920,10 +1937,16 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
     // anyway, but three empty launches cost ~15 us of a ~150 us refinement)
     refine_small_rank_kernel<<<1, 1024, 0, s>>>(ws.tab_min, ws.tab_lab, ws.counters, ws.first_idx);
     if (!ws.expect_small) {
-        refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt, ws.counters);
-        refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
-        refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt,
-                                                         ws.tab_lab, ws.counters, ws.first_idx);
+        // more than SMALL_K classes: ranked from the table's side (kernels_refine_bucket.hip: one bit per first index, rank
+        // records per 64 entries) -- work on the classes and on len / 64 words.  The entry-level count / scan / rank passes
+        // stay for callers without that workspace.
+        if (!(ws.rank_ws && launch_rank_slots(s, len, (int64_t)cap, ws.tab_sig, ws.tab_min, ws.tab_lab, ws.counters, SMALL_K, ws.first_idx,
+                                              REFINE_FIRST_CAP, ws.rank_ws, ws.rank_ws_bytes))) {
+            refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt, ws.counters);
+            refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
+            refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt,
+                                                             ws.tab_lab, ws.counters, ws.first_idx);
+        }
     }
     if (sym_n > 0 && sym_n * sym_n == len) {  // labels of an n x n matrix: the symmetry verdict comes with the label pass
         const unsigned t = (unsigned)((sym_n + 63) / 64);

@@ -20,17 +20,23 @@
 // Signature 0 is the structurally-zero class (label 0, not counted).  Results are the canonical numbering whatever
 // order the atomics put entries in (only minima of indices are taken).
 //
-// Round 5 (the b2_* kernels below; the two-level bk_* front end stays for len > 27 M entries):
-//   * ONE scatter level: ~len / 13312 (<= 2048) buckets by range reduction of the hash's high word; a workgroup stages
-//     8192 entries in LDS ordered by bucket and writes 12-byte records (hash, index) in runs.  The record carries the
-//     HASH (a bijection of the signature), so the resolver never hashes.
-//   * the resolver holds a whole bucket (<= 16384 entries) in REGISTERS (1024 threads x 16) and walks it in 1-8
-//     sub-passes over an 8192-slot LDS table (sub-pass = hash bits 13.., slot = hash bits 0..12, bucket = high word:
-//     disjoint); buckets beyond the register file (skewed inputs) go to a list that a second launch resolves with 64
-//     workgroups per bucket, one sub-pass each.
-//   * ranks from an L2-RESIDENT structure instead of a gather from the label array: one bit per entry ("is the first
-//     of its class", 2 MB at 16.7 M entries) + a prefix count per 64 entries; label(e) = rank(first(e)) + 1 is two
-//     small lookups, the 128-byte line per 4-byte label of the old bk_label_rest pass (1.2 GB at N = 4096) is gone.
+// Round 5 (the b2_* kernels below; the two-level bk_* front end stays for len > 22 M entries):
+//   * ONE scatter level: ~len / 5632 (<= 4032) buckets by range reduction of the hash's high word.  The count pass and the
+//     scatter pass split the entries the same way (workgroup w owns one span), so the scatter's write offsets are exact
+//     sums of the count pass's per-workgroup histograms: no cursor atomics.  A workgroup stages 8192 entries at a time
+//     in LDS ordered by bucket and writes 12-byte records (hash, index) in runs.  The record carries the HASH (a
+//     bijection of the signature), so the resolver never hashes.
+//   * the resolver holds a whole bucket (<= 8192 records) in REGISTERS (512 threads x 16), two workgroups per CU, and
+//     walks it in 4-8 sub-passes over a 4096-slot LDS table (sub-pass = hash bits 13.., slot = hash bits 0..11, bucket =
+//     high word: disjoint); a sub-pass first compacts its records into an LDS list, then the threads walk the list
+//     densely with their compare-and-swaps in flight together.  Buckets beyond the register file (skewed inputs) go to
+//     a list that a second launch resolves with 16 workgroups per bucket, one sub-pass each; what that cannot take is
+//     reported and the host repeats the refinement through the radix sort.
+//   * ranks from an L2-RESIDENT structure instead of a gather from the label array: per 64 entries one 16-byte record
+//     {bit per entry "is the first of its class", number of firsts before the word}; label(e) = rank(first(e)) + 1 is
+//     one small gather for the entries that are not first and pure ballot arithmetic for those that are -- the 128-byte
+//     line per 4-byte label of the old bk_label_rest pass (1.2 GB at N = 4096) is gone.
+// N = 4096, len / 2 classes: 0.72 -> 0.48 ms, 172 -> 99 bytes per entry (PMC); see DESIGN.md section 5.
 #include "sdpsr_internal.h"
 #include "sdpsr_hash.h"
 
@@ -375,12 +381,15 @@ bk_resolve_kernel(int NB, const uint32_t* __restrict__ bstart, const uint64_t* _
 // ---------------------------------------------------------------------------
 constexpr int B2_THREADS = 1024;
 constexpr int B2_CAP = 8192;                     // the largest bucket the register form takes (512 threads x 16 records)
-constexpr int B2_MEAN = 6656;                    // mean bucket size aimed at (Poisson sigma 82: the cap is 18 sigma away)
+constexpr int B2_MEAN = 5632;                    // mean bucket size aimed at.  Classes of k entries make the bucket sizes vary by
+                                                 // sqrt(k * mean): the cap is 3 sigma away at k = 128 (the grouping runs from len / 128
+                                                 // classes on), 30 at k = 2; 6656 sent 1 % of the buckets of a 64-entries-per-class
+                                                 // input to the second launch, more than it takes
 constexpr int B2_MAXNB = 4032;                   // buckets of the one scatter level (three LDS words each in the scatter)
 constexpr int B2_TS = 4096;                      // slots of the resolver's LDS table (48 KiB with the minima)
 constexpr int B2_CH = 8192;                      // entries staged per scatter workgroup
-constexpr int B2_MAXBIG = 16;                    // buckets beyond B2_CAP that the second launch resolves
-constexpr int B2_BIGSP = 64;                     // its sub-passes = workgroups per such bucket
+constexpr int B2_MAXBIG = 64;                    // buckets beyond B2_CAP that the second launch resolves
+constexpr int B2_BIGSP = 16;                     // its sub-passes = workgroups per such bucket
 constexpr int64_t B2_MAXLEN = (int64_t)B2_MAXNB * B2_MEAN;
 
 __device__ __forceinline__ uint32_t b2_bucket(uint64_t hh, uint32_t NB) { return (uint32_t)(((hh >> 32) * (uint64_t)NB) >> 32); }
@@ -675,96 +684,144 @@ b2_resolve_kernel(int NB, const uint32_t* __restrict__ bstart, const uint32_t* _
                 if (k < wv) pos += v;
                 total += v;
             }
-            if (total > (uint32_t)B2_LIST) {  // uniform: hash bits that do not spread over the sub-passes -- the second launch has 64 of them
-                if (threadIdx.x == 0) b2_defer(big, fail, bk);
-                break;
-            }
+            // The list takes B2_LIST records.  A sub-pass that has more (classes of many entries make the sub-pass sizes vary by
+            // sqrt(entries per class * mean): 2 % of the sub-passes at 64 entries per class) goes through it in BATCHES: all
+            // batches insert, then all batches look their minima up (the slot found again by probing) -- the table's limit is
+            // the number of DISTINCT hashes of the sub-pass, which such inputs are far from.
+            const uint32_t nbatch = (total + B2_LIST - 1) / B2_LIST;  // uniform
+            const uint32_t npass = nbatch > 1 ? 2u : 1u;
+            bool broke = false;
+            for (uint32_t pass = 0; pass < npass && !broke; ++pass)
+                for (uint32_t bt = 0; bt < nbatch; ++bt) {
+                    const uint32_t lo = bt * (uint32_t)B2_LIST;
+                    const uint32_t cntb = total - lo < (uint32_t)B2_LIST ? total - lo : (uint32_t)B2_LIST;
+                    uint32_t pp = pos;
 #pragma unroll
-            for (int q = 0; q < B2_REPT; ++q) {
-                const uint32_t i = q * B2_RTHREADS + threadIdx.x;
-                if (i < ncur && ((hl[q] >> 13) & (nsp - 1)) == sp) {
-                    l_lo[pos] = hl[q];
-                    l_hi[pos] = hh[q];
-                    l_ix[pos] = ix[q];
-                    ++pos;
-                }
-            }
-            __syncthreads();
-            B2_STAMP(2 + sp * 6);
-            // ---- insert: eight records per thread, their compare-and-swaps in flight together ----
-            uint32_t e_lo[B2_LPT], e_hi[B2_LPT], e_ix[B2_LPT];
-            int sl[B2_LPT];
-            unsigned long long old[B2_LPT];
-            bool need[B2_LPT];
-#pragma unroll
-            for (int k = 0; k < B2_LPT; ++k) {
-                const uint32_t i = k * B2_RTHREADS + threadIdx.x;
-                const uint32_t ic = i < total ? i : 0u;  // (every value defined on every path: nothing lives across the loops)
-                e_lo[k] = l_lo[ic];
-                e_hi[k] = l_hi[ic];
-                e_ix[k] = l_ix[ic];
-                sl[k] = i < total ? (int)(e_lo[k] & (B2_TS - 1)) : -1;
-                old[k] = empty;
-            }
-#pragma unroll
-            for (int k = 0; k < B2_LPT; ++k)
-                if (sl[k] >= 0) old[k] = atomicCAS(&t_sig[sl[k]], empty, (unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32));
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < B2_LPT; ++k) {
-                need[k] = sl[k] >= 0 && old[k] != empty && old[k] != ((unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32));
-                any = any || need[k];
-            }
-            for (int probes = 0; any; ++probes) {  // occupied by another hash: the next slots, the records' probes together
-                if (probes >= 512) {
-                    t_ovf = 1u;
-#pragma unroll
-                    for (int k = 0; k < B2_LPT; ++k)
-                        if (need[k]) sl[k] = -1;
-                    break;
-                }
-#pragma unroll
-                for (int k = 0; k < B2_LPT; ++k)
-                    if (need[k]) {
-                        sl[k] = (sl[k] + 1) & (B2_TS - 1);
-                        old[k] = atomicCAS(&t_sig[sl[k]], empty, (unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32));
+                    for (int q = 0; q < B2_REPT; ++q) {
+                        const uint32_t i = q * B2_RTHREADS + threadIdx.x;
+                        if (i < ncur && ((hl[q] >> 13) & (nsp - 1)) == sp) {
+                            if (pp - lo < (uint32_t)B2_LIST) {  // lo <= pp < lo + B2_LIST
+                                l_lo[pp - lo] = hl[q];
+                                l_hi[pp - lo] = hh[q];
+                                l_ix[pp - lo] = ix[q];
+                            }
+                            ++pp;
+                        }
                     }
-                any = false;
+                    __syncthreads();
+                    B2_STAMP(2 + sp * 6);
+                    // ---- four records per thread ----
+                    uint32_t e_lo[B2_LPT], e_hi[B2_LPT], e_ix[B2_LPT];
+                    int sl[B2_LPT];
+                    unsigned long long old[B2_LPT];
+                    bool need[B2_LPT];
 #pragma unroll
-                for (int k = 0; k < B2_LPT; ++k) {
-                    need[k] = need[k] && old[k] != empty && old[k] != ((unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32));
-                    any = any || need[k];
+                    for (int k = 0; k < B2_LPT; ++k) {
+                        const uint32_t i = k * B2_RTHREADS + threadIdx.x;
+                        const uint32_t ic = i < cntb ? i : 0u;  // (every value defined on every path: nothing lives across the loops)
+                        e_lo[k] = l_lo[ic];
+                        e_hi[k] = l_hi[ic];
+                        e_ix[k] = l_ix[ic];
+                        sl[k] = i < cntb ? (int)(e_lo[k] & (B2_TS - 1)) : -1;
+                        old[k] = empty;
+                        need[k] = false;
+                    }
+                    if (pass == 0) {
+                        // ---- insert.  Two rounds: the threads' first records, a barrier, then the rest.  A plain read comes
+                        // before every atomic: a slot that already holds the hash needs no compare-and-swap, a minimum that is
+                        // already smaller no atomicMin.  Classes of many entries put dozens of lanes on ONE LDS address, and
+                        // same-address LDS atomics retire one lane at a time; after the first round most records find their
+                        // class in the table and a minimum below their own index.
+                        bool any = false;
+                        auto insert_range = [&](const int k0, const int k1) {
+#pragma unroll
+                            for (int k = k0; k < k1; ++k)
+                                if (sl[k] >= 0) old[k] = t_sig[sl[k]];
+#pragma unroll
+                            for (int k = k0; k < k1; ++k)
+                                if (sl[k] >= 0 && old[k] == empty) old[k] = atomicCAS(&t_sig[sl[k]], empty, (unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32));
+                            any = false;
+#pragma unroll
+                            for (int k = k0; k < k1; ++k) {
+                                need[k] = sl[k] >= 0 && old[k] != empty && old[k] != ((unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32));
+                                any = any || need[k];
+                            }
+                            for (int probes = 0; any; ++probes) {  // occupied by another hash: the next slots, the records' probes together
+                                if (probes >= 512) {
+                                    t_ovf = 1u;
+#pragma unroll
+                                    for (int k = k0; k < k1; ++k)
+                                        if (need[k]) sl[k] = -1;
+                                    break;
+                                }
+#pragma unroll
+                                for (int k = k0; k < k1; ++k)
+                                    if (need[k]) {
+                                        sl[k] = (sl[k] + 1) & (B2_TS - 1);
+                                        old[k] = t_sig[sl[k]];
+                                        if (old[k] == empty) old[k] = atomicCAS(&t_sig[sl[k]], empty, (unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32));
+                                    }
+                                any = false;
+#pragma unroll
+                                for (int k = k0; k < k1; ++k) {
+                                    need[k] = need[k] && old[k] != empty && old[k] != ((unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32));
+                                    any = any || need[k];
+                                }
+                            }
+#pragma unroll
+                            for (int k = k0; k < k1; ++k)
+                                if (sl[k] >= 0 && t_min[sl[k]] > e_ix[k]) atomicMin(&t_min[sl[k]], e_ix[k]);  // (only ever decreases)
+                        };
+                        insert_range(0, 1);
+                        __syncthreads();
+                        insert_range(1, B2_LPT);
+                        // (measured and not kept: the record that claimed a slot STORES its index, and after one more barrier the
+                        // others lower it where they must -- fewer atomics, but the barrier and the extra live registers cost
+                        // more: 178 -> 220 us)
+                        __syncthreads();
+                        B2_STAMP(3 + sp * 6);
+                        if (t_ovf) {  // uniform: more distinct hashes than the table takes
+                            if (threadIdx.x == 0) b2_defer(big, fail, bk);
+                            dirty = true;
+                            broke = true;
+                            break;
+                        }
+                    } else {
+                        // ---- second pass of a batched sub-pass: every hash is in the table, find its slot again ----
+#pragma unroll
+                        for (int k = 0; k < B2_LPT; ++k)
+                            if (sl[k] >= 0) {
+                                const unsigned long long v = (unsigned long long)e_lo[k] | ((unsigned long long)e_hi[k] << 32);
+                                while (t_sig[sl[k]] != v) sl[k] = (sl[k] + 1) & (B2_TS - 1);
+                            }
+                    }
+                    if (pass + 1 == npass) {
+                        // ---- every record that is not the first of its class learns which one is ----
+                        uint32_t mn[B2_LPT];
+#pragma unroll
+                        for (int k = 0; k < B2_LPT; ++k) mn[k] = sl[k] >= 0 ? t_min[sl[k]] : 0u;
+#pragma unroll
+                        for (int k = 0; k < B2_LPT; ++k)
+                            if (sl[k] >= 0 && mn[k] != e_ix[k]) first[e_ix[k]] = mn[k];
+                        B2_STAMP(4 + sp * 6);
+                    }
+                    __syncthreads();  // the list is free for the next batch; all look-ups of this one are done
+                    B2_STAMP(5 + sp * 6);
+                    if (nbatch == 1) {
+                        // ---- the slots this sub-pass used go back to empty (by their users; the next insert is a barrier away) ----
+#pragma unroll
+                        for (int k = 0; k < B2_LPT; ++k)
+                            if (sl[k] >= 0) {
+                                t_sig[sl[k]] = empty;
+                                t_min[sl[k]] = 0xFFFFFFFFu;
+                            }
+                    }
                 }
+            if (broke) break;
+            if (nbatch > 1) {  // uniform: a batched sub-pass leaves the whole table to be cleared
+                clear_table(empty);
+                __syncthreads();
             }
-#pragma unroll
-            for (int k = 0; k < B2_LPT; ++k)
-                if (sl[k] >= 0) atomicMin(&t_min[sl[k]], e_ix[k]);
-            // (measured and not kept: the record that claimed a slot STORES its index, and after one more barrier the others
-            // lower it where they must -- fewer atomics, but the barrier and the extra live registers cost more: 178 -> 220 us)
-            __syncthreads();
-            B2_STAMP(3 + sp * 6);
-            if (t_ovf) {  // uniform (cannot happen with <= 4096 records in 8192 slots; the guard of the probe loop)
-                if (threadIdx.x == 0) b2_defer(big, fail, bk);
-                dirty = true;
-                break;
-            }
-            // ---- every record that is not the first of its class learns which one is ----
-            uint32_t mn[B2_LPT];
-#pragma unroll
-            for (int k = 0; k < B2_LPT; ++k) mn[k] = sl[k] >= 0 ? t_min[sl[k]] : 0u;
-#pragma unroll
-            for (int k = 0; k < B2_LPT; ++k)
-                if (sl[k] >= 0 && mn[k] != e_ix[k]) first[e_ix[k]] = mn[k];
-            B2_STAMP(4 + sp * 6);
-            __syncthreads();
-            B2_STAMP(5 + sp * 6);
-            // ---- the slots this sub-pass used go back to empty (by their users; the next insert is a barrier away) ----
-#pragma unroll
-            for (int k = 0; k < B2_LPT; ++k)
-                if (sl[k] >= 0) {
-                    t_sig[sl[k]] = empty;
-                    t_min[sl[k]] = 0xFFFFFFFFu;
-                }
         }
         B2_STAMP(30);
         if (dirty || empty != 0ull) {  // uniform.  Bucket 0's table was filled with ~0: every later bucket of this workgroup wants 0
@@ -775,8 +832,8 @@ b2_resolve_kernel(int NB, const uint32_t* __restrict__ bstart, const uint32_t* _
     }
 }
 
-// Buckets beyond the register file, or whose sub-passes overflowed: 64 workgroups per bucket, workgroup = one
-// sub-pass (hash bits 13 .. 18), two sweeps over the bucket's records.  A deferred bucket's earlier partial stores
+// Buckets beyond the register file, or whose sub-passes overflowed: 16 workgroups per bucket, workgroup = one
+// sub-pass (hash bits 13 .. 16), two sweeps over the bucket's records.  A deferred bucket's earlier partial stores
 // are overwritten here: every non-first entry of every sub-pass is stored again, first entries were never stored.
 __global__ void __launch_bounds__(B2_THREADS)
 b2_resolve_big_kernel(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ rec, uint32_t* __restrict__ first,
@@ -956,6 +1013,90 @@ bk_label_kernel(int64_t len, const uint32_t* __restrict__ first, uint32_t* __res
             if (e < len) __builtin_nontemporal_store(o[k], &labels[e]);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Ranks of the classes of a hash-table refinement from the TABLE's side (kernels_partition.hip, more than SMALL_K
+// classes): one bit per first index, the rank records of the pass above, label of a slot = rank of its first index + 1.
+// Work on the d classes and on len / 64 words -- the entry-level count / scan / rank passes they replace read every
+// entry's slot and gathered its minimum twice (140 us at 16.7 M entries).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rs_mark_kernel(int64_t cap, const unsigned long long* __restrict__ tab_sig, const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ bitmap,
+               const uint32_t* __restrict__ counters, uint32_t small_k) {
+    if (counters[0] <= small_k || counters[1]) return;  // ranked by the one-workgroup kernel / a pass the host repeats
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t sl = (int64_t)blockIdx.x * 256 + threadIdx.x; sl < cap; sl += stride)
+        if (tab_sig[sl]) {
+            const uint32_t m = tab_min[sl];
+            atomicOr(&bitmap[m >> 5], 1u << (m & 31u));
+        }
+}
+// one wave per block of 64 words
+__global__ void __launch_bounds__(64)
+rs_words_kernel(int64_t nwords, const unsigned long long* __restrict__ bitmap, BkRank* __restrict__ rk, uint32_t* __restrict__ blk_cnt,
+                const uint32_t* __restrict__ counters, uint32_t small_k) {
+    if (counters[0] <= small_k || counters[1]) return;
+    const int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const unsigned long long b = w < nwords ? bitmap[w] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(b);
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o, 64);
+        if ((int)threadIdx.x >= o) incl += y;
+    }
+    if (w < nwords) {
+        BkRank r;
+        r.bits = b;
+        r.before = incl - c;
+        r.pad = 0u;
+        rk[w] = r;
+    }
+    if (threadIdx.x == 63) blk_cnt[blockIdx.x] = incl;
+}
+__global__ void __launch_bounds__(256)
+rs_assign_kernel(int64_t cap, const unsigned long long* __restrict__ tab_sig, const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ tab_lab,
+                 const BkRank* __restrict__ rk, const uint32_t* __restrict__ total, uint32_t* __restrict__ counters, uint32_t small_k,
+                 uint32_t* __restrict__ first_idx, uint32_t first_cap) {
+    if (counters[0] <= small_k || counters[1]) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[2] = total[0];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t sl = (int64_t)blockIdx.x * 256 + threadIdx.x; sl < cap; sl += stride)
+        if (tab_sig[sl]) {
+            const uint32_t m = tab_min[sl];
+            const uint32_t lab = bk_rank_of(m, rk) + 1u;
+            tab_lab[sl] = lab;
+            if (first_idx && lab <= first_cap) first_idx[lab - 1] = m;
+        }
+}
+size_t refine_rank_slots_workspace_bytes(int64_t len) {
+    const int64_t nw = (len + 63) / 64, nb = (nw + 63) / 64;
+    return (size_t)nw * 8 + 256 + (size_t)nb * 64 * sizeof(BkRank) + 256 + (size_t)(nb + 1) * 4 + 256 + 64;
+}
+// tab_lab[slot] = canonical label of the slot's class, counters[2] = number of classes, first_idx as in the other passes.
+// Every kernel returns at once when the one-workgroup ranking (<= small_k classes) has done the job or the table overflowed.
+bool launch_rank_slots(hipStream_t s, int64_t len, int64_t cap, const uint64_t* tab_sig, const uint32_t* tab_min, uint32_t* tab_lab,
+                       uint32_t* counters, uint32_t small_k, uint32_t* first_idx, uint32_t first_cap, void* ws, size_t ws_bytes) {
+    if (ws_bytes < refine_rank_slots_workspace_bytes(len) || len >= (int64_t(1) << 32)) return false;
+    const int64_t nw = (len + 63) / 64, nb = (nw + 63) / 64;
+    auto align = [](char* p) { return (char*)(((uintptr_t)p + 255) & ~uintptr_t(255)); };
+    char* p = align((char*)ws);
+    unsigned long long* bitmap = (unsigned long long*)p;
+    p = align(p + (size_t)nw * 8);
+    BkRank* rk = (BkRank*)p;
+    p = align(p + (size_t)nb * 64 * sizeof(BkRank));
+    uint32_t* blk_cnt = (uint32_t*)p;
+    p = align(p + (size_t)(nb + 1) * 4);
+    uint32_t* total = (uint32_t*)p;
+    if (hipMemsetAsync(bitmap, 0, (size_t)nw * 8, s) != hipSuccess) return false;
+    const unsigned gs = (unsigned)std::min<int64_t>((cap + 255) / 256, 2048);
+    rs_mark_kernel<<<gs, 256, 0, s>>>(cap, (const unsigned long long*)tab_sig, tab_min, (uint32_t*)bitmap, counters, small_k);
+    rs_words_kernel<<<(unsigned)nb, 64, 0, s>>>(nw, bitmap, rk, blk_cnt, counters, small_k);
+    bk_scan_kernel<<<1, 1024, 0, s>>>(nb, blk_cnt, total);
+    bk_rank_finish_kernel<<<(unsigned)((nb * 64 + 255) / 256), 256, 0, s>>>(nw, blk_cnt, rk);
+    rs_assign_kernel<<<gs, 256, 0, s>>>(cap, (const unsigned long long*)tab_sig, tab_min, tab_lab, rk, total, counters, small_k, first_idx, first_cap);
+    return true;
 }
 
 // ---------------------------------------------------------------------------

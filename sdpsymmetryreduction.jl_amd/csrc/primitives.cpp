@@ -109,6 +109,11 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         if (!ws.tab_sig || !ws.tab_min || !ws.tab_lab || !ws.blk_cnt || !ws.counters || !ws.first_idx)
             return SDPSR_OUT_OF_MEMORY;
         ws.log2cap = log2cap;
+        if (log2cap > 12 || mispredicted || sampled) {  // (a table of 2^12 slots holds at most 3072 classes: mostly the one-workgroup ranking)
+            ws.rank_ws_bytes = refine_rank_slots_workspace_bytes(len);
+            ws.rank_ws = ctx_buf(c, "ref_rank_ws", ws.rank_ws_bytes);
+            if (!ws.rank_ws) return SDPSR_OUT_OF_MEMORY;
+        }
         ws.insert_wgs_per_cu = c->opts.insert_wgs_per_cu;
         ws.nblk = (int)nblk;
         // hint 12 <=> last dim <= 512; a table grown after an overflow in this call holds more than 0.75 * 2^12 classes

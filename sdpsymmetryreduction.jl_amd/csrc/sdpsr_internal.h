@@ -173,6 +173,8 @@ struct RefineWs {
     uint32_t* host_counters = nullptr;  // pinned host memory: counters[0..2] are also stored there by the label pass (plain label pass only)
     int expect_small = 0;  // host prediction: <= refine_small_k() classes (see launch_refine)
     uint32_t* first_idx = nullptr;  // optional: first-occurrence index of class l at [l - 1], l <= refine_first_cap()
+    void* rank_ws = nullptr;        // refine_rank_slots_workspace_bytes(len): the ranking of more than refine_small_k() classes
+    size_t rank_ws_bytes = 0;
     uint32_t* counters;  // [0] = inserted, [1] = overflow flag, [2] = nparts, [16..] slot list (refine_counters_bytes())
     int log2cap;
     int nblk;
@@ -218,6 +220,9 @@ size_t refine_bucketed_workspace_bytes(int64_t len);
 bool refine_bucket_set_device_attributes();
 bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
                             uint32_t* counters, uint32_t* first_idx, uint32_t first_cap, uint32_t* host_counters = nullptr);
+size_t refine_rank_slots_workspace_bytes(int64_t len);
+bool launch_rank_slots(hipStream_t s, int64_t len, int64_t cap, const uint64_t* tab_sig, const uint32_t* tab_min, uint32_t* tab_lab,
+                       uint32_t* counters, uint32_t small_k, uint32_t* first_idx, uint32_t first_cap, void* ws, size_t ws_bytes);
 // distinct-signature estimate of a signature array from <= 65536 sampled entries; host_out (pinned, 4 words): non-zero
 // entries sampled, distinct signatures among them, signatures seen once, seen twice.  Returns the sample size (0: failed)
 size_t refine_sample_workspace_bytes();

@@ -2,6 +2,8 @@
 finishes in seconds the comparison is bit-exact against it; at N >= 4096 the checks are the
 size-independent properties of the domain: the generator's partition is a fixed point
 (known closure), idempotence, seed independence, block sizes known by construction."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -25,6 +27,47 @@ def test_config1_gnp1024_theta_prime(pkg, problems, oracle):
         assert ne == n and nc == 1
         Qh = pkg.diagonalize(P, atol=1.4901161193847656e-8, ctx=ctx)  # 1024*1025/2 = dim
         assert [q.shape for q in Qh] == [(n, n)]
+
+
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_generic_theta_prime_fresh_call_needs_no_overflow_ladder(pkg, problems, oracle, n):
+    """G(n, 1/2) theta' at n = 2048 / 4096 (configs[1] at the sizes where the relabel path matters): no symmetry, the loop
+    jumps from 3 classes to (n^2 + n) / 2 in its first iteration.  A call has no class-count prediction (the loop resets
+    it), so this is the path the round-3/4 ladder of overflowing hash tables (2^12 -> 2^16 -> 2^20 slots, 12.7 ms at
+    n = 4096) used to take: the first table's overflow is now followed by a sample of the signatures and the grouping.
+    Device-resident inputs and labels, second call on the ctx timed: <= 3 ms at 2048, <= 8 ms at 4096.
+    The canonical matrix of a partition whose classes are the unordered pairs {i, j} is known in closed form (column-major
+    first occurrence = the packed lower-triangle index + 1); at 2048 the oracle's loop is run as well."""
+    import time
+    import torch
+    Cv, A, b = problems.theta_prime_problem(problems.gnp_adjacency(n, 0.5, seed=7))
+    setup = pkg.admissible_setup(Cv, A, b)
+    nn, CL, X0L, U = setup
+    j, i = np.meshgrid(np.arange(n, dtype=np.int64), np.arange(n, dtype=np.int64))
+    lo, hi = np.minimum(i, j), np.maximum(i, j)
+    expect = (lo * n - lo * (lo - 1) // 2 + (hi - lo) + 1).astype(np.uint32)
+    if n <= 2048:
+        ref = oracle.admissible_subspace(Cv, A, b, rng=np.random.default_rng(0))
+        assert ref.nparts == (n * n + n) // 2 and np.array_equal(ref.matrix.astype(np.uint32), expect)
+    tCL, tX0 = torch.from_numpy(CL).cuda(), torch.from_numpy(X0L).cuda()
+    tU = torch.from_numpy(np.ascontiguousarray(U.T)).cuda()
+    tP = torch.zeros(n * n, dtype=torch.int32, device="cuda")
+    dd, it = C.c_int64(0), C.c_int32(0)
+    with pkg.Context(seed=5) as ctx:
+        times = []
+        for rep in range(3):
+            if getattr(setup, "hint", 0):
+                ctx._lib.sdpsr_hint_symmetric_basis(ctx._h, setup.hint)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.check(ctx._lib.sdpsr_admissible_subspace(ctx._h, n, C.c_void_p(tCL.data_ptr()), C.c_void_p(tX0.data_ptr()), C.c_void_p(tU.data_ptr()),
+                                                        U.shape[1], 1.4901161193847656e-08, C.c_void_p(tP.data_ptr()), C.byref(dd), C.byref(it), None, 1))
+            times.append((time.perf_counter() - t0) * 1e3)
+            assert dd.value == (n * n + n) // 2 and it.value <= 3
+            got = tP.cpu().numpy().view(np.uint32).reshape(n, n, order="F")
+            assert np.array_equal(got, expect), rep
+        print(f"G({n}, 1/2) theta' admissible_subspace, device-resident: {['%.2f' % t for t in times]} ms")
+        assert min(times[1:]) <= (3.0 if n <= 2048 else 8.0), times
 
 
 def test_config2_qap_grid30(pkg, problems, oracle):

@@ -970,6 +970,10 @@ def test_sort_based_refine_matches_oracle(pkg, oracle):
         "skewed": np.where(rng.random((n, n)) < 0.5, 7.0, rng.integers(1, 200000, size=(n, n)).astype(np.float64)),
     }
     cases["many"][rng.random((n, n)) < 0.1] = 0.0
+    # classes of ~64 and ~500 entries: bucket and sub-pass sizes vary by sqrt(entries per class * mean) -- sub-pass lists
+    # walked in batches, buckets beyond the register file (round 5: such inputs fell back to the radix sort)
+    cases["mult64"] = rng.integers(1, n * n // 64, size=(n, n)).astype(np.float64)
+    cases["mult500"] = rng.integers(1, n * n // 500, size=(n, n)).astype(np.float64)
     for path in ("bucket", "sort", "auto"):
         with pkg.Context(seed=2, refine_path=path) as ctx:  # sdpsr_opts.refine_path
             for name, M in cases.items():

@@ -24,6 +24,26 @@ with pkg.Context(seed=1, flags=int(os.environ.get("SDPSR_TOOL_FLAGS", "0"))) as 
     os.environ["SDPSR_DEBUG"] = "1"  # phase marks of one more run on stderr
     timeit(lambda: pkg.eigen_decomposition(P, atol=1.5e-8, ctx=ctx), reps=1)
     del os.environ["SDPSR_DEBUG"]
+    # G(2048, 1/2) and G(4096, 1/2): the sizes where the relabel path of a fresh call matters (device-resident inputs and labels)
+    import torch, ctypes as C
+    for ng in (2048, 4096):
+        Cg, Ag, bg = pr.theta_prime_problem(pr.gnp_adjacency(ng, 0.5, seed=7))
+        sg = pkg.admissible_setup(Cg, Ag, bg)
+        _, CLg, X0g, Ug = sg
+        tCL, tX0 = torch.from_numpy(CLg).cuda(), torch.from_numpy(X0g).cuda()
+        tU = torch.from_numpy(np.ascontiguousarray(Ug.T)).cuda()
+        tP = torch.zeros(ng * ng, dtype=torch.int32, device="cuda")
+        dd, it = C.c_int64(0), C.c_int32(0)
+        ts = []
+        for rep in range(4):
+            if getattr(sg, "hint", 0):
+                ctx._lib.sdpsr_hint_symmetric_basis(ctx._h, sg.hint)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            ctx.check(ctx._lib.sdpsr_admissible_subspace(ctx._h, ng, C.c_void_p(tCL.data_ptr()), C.c_void_p(tX0.data_ptr()), C.c_void_p(tU.data_ptr()), Ug.shape[1],
+                                                        1.4901161193847656e-08, C.c_void_p(tP.data_ptr()), C.byref(dd), C.byref(it), None, 1))
+            ts.append((time.perf_counter() - t) * 1e3)
+        print("G(%d,.5) theta': admissible_subspace device-resident, calls 1-4: %s ms, dim %d, iters %d" % (ng, ["%.2f" % x for x in ts], dd.value, it.value))
+        del tCL, tX0, tU, tP
     # config 2: QAP grid 30
     flow, dist = pr.grid_qap_instance(5, 6, seed=4)
     Cv, A, b = pr.qap_problem(flow, dist)
