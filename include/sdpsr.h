@@ -36,9 +36,10 @@ extern "C" {
 #endif
 
 #define SDPSR_VERSION_MAJOR 0
-#define SDPSR_VERSION_MINOR 3
+#define SDPSR_VERSION_MINOR 5
 
 typedef struct sdpsr_ctx sdpsr_ctx;
+typedef struct sdpsr_problem sdpsr_problem; /* device-resident inputs of the loop, sdpsr_problem_create */
 
 typedef enum sdpsr_status {
     SDPSR_OK = 0,
@@ -394,6 +395,36 @@ int sdpsr_jordan_reduce_batch(sdpsr_ctx* ctx, int32_t R, const uint64_t* seeds, 
                               const double* U, int64_t r, double atol, double epsilon, uint32_t* const* P_out, int64_t* dim_out,
                               int32_t* iters_out, int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* const* blks,
                               const int64_t* blks_capacity, int32_t* status, int mem);
+/* (With host arrays, mem = SDPSR_MEM_HOST, C_L / X0_L / U are uploaded ONCE for all R restarts -- into ctx's own input
+   buffers -- not once per restart.) */
+/* blkSizes (nblocks[restart] ints) of restart `restart` of the last batch call on ctx whose status[restart] was SDPSR_OK or
+   SDPSR_DIMENSION_MISMATCH -- sdpsr_block_sizes for a restart. */
+int sdpsr_batch_block_sizes(sdpsr_ctx* ctx, int32_t restart, int32_t* blk_sizes);
+
+/* ---- upload once, reduce many times ----------------------------------------------------------------
+   The reference's seam hands host arrays to admissible_subspace on every call (src/partitions.jl:109-116); a caller
+   who restarts the randomized reduction of ONE problem many times (the reference's "try again",
+   src/eigen_decomposition.jl:264-270, the multi-GPU restarts) pays the upload of C_L, X0_L and U -- 3 x 134 MB at
+   N = 4096, ~9 ms against a 0.8 ms reduction -- on each of them.  A problem handle holds the three arrays on ctx's
+   device: created once (mem names where CL / X0L / U live; device-resident inputs are COPIED, the caller's buffers are
+   free on return), used by any number of sdpsr_problem_reduce / sdpsr_problem_reduce_batch calls of ctxs on that
+   device, read-only, destroyed by the caller (after the last call that names it has returned).
+     hint    bits of sdpsr_hint_symmetric_basis that hold for these inputs (they then apply to every reduction);
+     mem_out where P_out / blks / Q_hat live; everything else as in sdpsr_jordan_reduce / sdpsr_jordan_reduce_batch.
+   A Julia caller holding AMDGPU.jl arrays passes their device pointers with SDPSR_MEM_DEVICE. */
+int sdpsr_problem_create(sdpsr_ctx* ctx, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r, int hint,
+                         int mem, sdpsr_problem** out);
+int sdpsr_problem_destroy(sdpsr_problem* problem);
+int sdpsr_problem_reduce(sdpsr_ctx* ctx, const sdpsr_problem* problem, double atol, double epsilon, uint32_t* P_out,
+                         int64_t* dim_out, int32_t* iters_out, int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks,
+                         int64_t blks_capacity, double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem_out);
+int sdpsr_problem_reduce_batch(sdpsr_ctx* ctx, const sdpsr_problem* problem, int32_t R, const uint64_t* seeds, double atol,
+                               double epsilon, uint32_t* const* P_out, int64_t* dim_out, int32_t* iters_out, int32_t* nblocks,
+                               int64_t* sum_sq, int64_t* sum_s, double* const* blks, const int64_t* blks_capacity,
+                               int32_t* status, int mem_out);
+/* Bytes ctx (and the restarts' ctxs inside it) has moved host -> device / device -> host since its creation: what a
+   caller of the host-array interface pays on PCIe (tests: a 4-restart batch uploads what one call uploads). */
+int sdpsr_transfer_bytes(sdpsr_ctx* ctx, uint64_t* h2d, uint64_t* d2h);
 
 /* ---- blockDiagonalize(P; complex = true), src/compat.jl:26-32,46-68 with T = ComplexF64 ---------
    diagonalize(ComplexF64, P) = desymmetrize (src/diagonalize.jl:26-28) + Murota's decomposition

@@ -11,5 +11,5 @@ from ._lib import (MEM_DEVICE, MEM_HOST, SQUARE_AUTO, SQUARE_F32, SQUARE_F64, SQ
 from .api import (BlockDiagonalization, Context, DimensionMismatch, InvalidDecompositionField,  # noqa: F401
                   LabelOverflow, NotConverged, NumericalInconsistency, Partition, SdpsrError,
                   admissible_setup, admissible_subspace, blockDiagonalize, default_context, desymmetrize, unSymmetrize,
-                  diagonalize, dim, eigen_decomposition, jordan_reduce_batch, eigen_decomposition_batched, fill, partition_checksum, randomize, reduce_constraints,
+                  diagonalize, dim, eigen_decomposition, jordan_reduce_batch, Problem, eigen_decomposition_batched, fill, partition_checksum, randomize, reduce_constraints,
                   refine, relabel_keys)

@@ -113,6 +113,12 @@ def load_library():
         "sdpsr_jordan_reduce": (C.c_int, [vp, i64, vp, vp, vp, i64, dbl, dbl, vp, pi64, pi32, pi32, pi64, pi64, vp, i64, vp, i64, vp, C.c_int]),
         "sdpsr_jordan_reduce_batch": (C.c_int, [vp, C.c_int32, vp, i64, vp, vp, vp, i64, dbl, dbl, vp, pi64, pi32, pi32, pi64, pi64, vp, vp, pi32,
                                                 C.c_int]),
+        "sdpsr_problem_create": (C.c_int, [vp, i64, vp, vp, vp, i64, C.c_int, C.c_int, C.POINTER(vp)]),
+        "sdpsr_problem_destroy": (C.c_int, [vp]),
+        "sdpsr_problem_reduce": (C.c_int, [vp, vp, dbl, dbl, vp, pi64, pi32, pi32, pi64, pi64, vp, i64, vp, i64, vp, C.c_int]),
+        "sdpsr_problem_reduce_batch": (C.c_int, [vp, vp, C.c_int32, vp, dbl, dbl, vp, pi64, pi32, pi32, pi64, pi64, vp, vp, pi32, C.c_int]),
+        "sdpsr_batch_block_sizes": (C.c_int, [vp, C.c_int32, vp]),
+        "sdpsr_transfer_bytes": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "sdpsr_reduce_constraints": (C.c_int, [vp, i64, vp, i64, i64, vp, vp, C.c_int]),
         "sdpsr_desymmetrize": (C.c_int, [vp, i64, vp, pi64, pi32, C.c_int]),
         "sdpsr_block_diagonalize": (C.c_int, [vp, i64, vp, i64, dbl, pi32, pi64, pi64, vp, C.c_int]),

@@ -137,6 +137,12 @@ class Context:
         self.check(self._lib.sdpsr_dimension_trajectory(self._h, dims.ctypes.data_as(C.c_void_p), cnt.value, C.byref(cnt)))
         return [int(x) for x in dims[:cnt.value]]
 
+    def transfer_bytes(self):
+        """(host -> device, device -> host) bytes this context has moved since its creation (``sdpsr_transfer_bytes``)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.check(self._lib.sdpsr_transfer_bytes(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def wait_for(self, *arrays):
         """Order ctx's stream behind torch's current stream when any argument is a CUDA tensor
         (it may have been produced by a kernel that is still running): sdpsr_wait_stream."""
@@ -437,53 +443,97 @@ def admissible_subspace(C_, A, b, atol=RTOL_DEFAULT, ctx=None, verbose=False, se
     return out
 
 
-def jordan_reduce_batch(C_, A, b, restarts=2, seeds=None, atol=RTOL_DEFAULT, epsilon=RTOL_DEFAULT, ctx=None, setup=None):
-    """``restarts`` independent random restarts of ``admissible_subspace`` + ``blockDiagonalize`` of one problem in ONE
-    call on one host thread (``sdpsr_jordan_reduce_batch``): restart i with its own random streams, HIP stream and
-    workspace; while one restart's host side waits for a verdict the others' work is submitted.  The reference's answer
-    to the randomized failures of ``blockDiagonalize`` is "try again" (src/eigen_decomposition.jl:264-270,
-    src/diagonalize.jl:4-9): here the tries run side by side and the caller takes the first whose status is 0.
-    Returns a list of dicts: status, P (Partition), iterations, blkSizes, blks (d x sum s_k^2 array, class-major)."""
-    ctx = _ctx(ctx)
-    lib = ctx._lib
-    setup = setup if setup is not None else admissible_setup(C_, A, b, atol)
-    n, CL, X0L, U = setup
-    R = int(restarts)
-    r = U.shape[1]
-    Uf = np.asfortranarray(U) if r else None
-    hint = int(getattr(setup, "hint", 0))
-    sd = None
-    if seeds is not None:
+class Problem:
+    """The loop's inputs (C_L, X0_L, U of ``admissible_setup``) made device-resident ONCE (``sdpsr_problem_create``); any
+    number of ``reduce`` / ``reduce_batch`` calls then read them there.  The reference's seam hands host arrays to
+    ``admissible_subspace`` on every call (src/partitions.jl:109-116); restarting the randomized reduction of one problem
+    ("try again", src/eigen_decomposition.jl:264-270) through it pays the upload -- 3 x 134 MB at N = 4096 -- every time."""
+
+    def __init__(self, C_=None, A=None, b=None, atol=RTOL_DEFAULT, ctx=None, setup=None):
+        self.ctx = _ctx(ctx)
+        setup = setup if setup is not None else admissible_setup(C_, A, b, atol)
+        self.n, CL, X0L, U = setup
+        self.r = U.shape[1]
+        self.atol = atol
+        Uf = np.asfortranarray(U) if self.r else None
+        h = C.c_void_p()
+        self.ctx.check(self.ctx._lib.sdpsr_problem_create(self.ctx._h, self.n, _ptr(CL), _ptr(X0L), _ptr(Uf) if self.r else None, self.r,
+                                                          int(getattr(setup, "hint", 0)), L.MEM_HOST, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.sdpsr_problem_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def reduce(self, seed=None, epsilon=RTOL_DEFAULT, atol=None):
+        """One reduction (``admissible_subspace`` + ``blockDiagonalize``): the dict of a one-restart batch; raises the
+        reference's exception for a status that is not 0."""
+        res = self.reduce_batch(1, seeds=None if seed is None else [seed], epsilon=epsilon, atol=atol)[0]
+        if res["status"]:
+            self.ctx.check(res["status"])
+        return res
+
+    def reduce_batch(self, restarts=2, seeds=None, epsilon=RTOL_DEFAULT, atol=None):
+        """``restarts`` independent random restarts in one call (``sdpsr_problem_reduce_batch``); a list of dicts as
+        ``jordan_reduce_batch`` returns them."""
+        ctx, lib, n = self.ctx, self.ctx._lib, self.n
+        R = int(restarts)
+        atol = self.atol if atol is None else atol
+        if seeds is None:  # explicit seeds: the sizes call and the images call must run the same restarts
+            seeds = [int(x) for x in np.random.SeedSequence().generate_state(R, dtype=np.uint64)]
+        if len(seeds) != R:
+            raise ValueError(f"{len(seeds)} seeds for {R} restarts")
         sd = (C.c_uint64 * R)(*[int(x) & (2 ** 64 - 1) for x in seeds])
 
-    def call(blk_arrays):
-        Ps = [np.zeros(n * n, dtype=np.uint32) for _ in range(R)]
-        pP = (C.c_void_p * R)(*[a.ctypes.data for a in Ps])
-        dd, it, nb = (C.c_int64 * R)(), (C.c_int32 * R)(), (C.c_int32 * R)()
-        ssq, ss, st = (C.c_int64 * R)(), (C.c_int64 * R)(), (C.c_int32 * R)()
-        if blk_arrays is None:
-            pb, caps = None, None
-        else:
-            pb = (C.c_void_p * R)(*[a.ctypes.data for a in blk_arrays])
-            caps = (C.c_int64 * R)(*[a.size for a in blk_arrays])
-        if hint:
-            lib.sdpsr_hint_symmetric_basis(ctx._h, hint)
-        lib.sdpsr_jordan_reduce_batch(ctx._h, R, C.cast(sd, C.c_void_p) if sd is not None else None, n, _ptr(CL), _ptr(X0L), _ptr(Uf), r,
-                                      atol, epsilon, C.cast(pP, C.c_void_p), dd, it, nb, ssq, ss,
-                                      C.cast(pb, C.c_void_p) if pb is not None else None, caps, st, L.MEM_HOST)
-        return Ps, dd, it, nb, ssq, ss, st
+        def call(blk_arrays):
+            Ps = [np.zeros(n * n, dtype=np.uint32) for _ in range(R)]
+            pP = (C.c_void_p * R)(*[a.ctypes.data for a in Ps])
+            dd, it, nb = (C.c_int64 * R)(), (C.c_int32 * R)(), (C.c_int32 * R)()
+            ssq, ss = (C.c_int64 * R)(), (C.c_int64 * R)()
+            st = (C.c_int32 * R)(*([-1] * R))  # a sentinel no status code has
+            pb = caps = None
+            if blk_arrays is not None:
+                pb = (C.c_void_p * R)(*[a.ctypes.data for a in blk_arrays])
+                caps = (C.c_int64 * R)(*[a.size for a in blk_arrays])
+            rc = lib.sdpsr_problem_reduce_batch(ctx._h, self._h, R, C.cast(sd, C.c_void_p), atol, epsilon, C.cast(pP, C.c_void_p), dd, it, nb, ssq, ss,
+                                                C.cast(pb, C.c_void_p) if pb is not None else None, caps, st, L.MEM_HOST)
+            # the call's own status counts unless some restart reports one: a failure before the restarts start (bad
+            # arguments, memory) must not read as R clean restarts of dimension 0
+            if rc != 0 and all(x in (0, -1) for x in st):
+                ctx.check(rc)
+            return Ps, dd, it, nb, ssq, ss, st
 
-    # sizes first (the same seeds give the same restarts), then the images into buffers of the right size
-    Ps, dd, it, nb, ssq, ss, st = call(None)
-    bl = [np.zeros(max(1, dd[i] * ssq[i])) for i in range(R)]
-    if sd is not None:
+        Ps, dd, it, nb, ssq, ss, st = call(None)  # sizes first, then the images into buffers of the right size
+        bl = [np.zeros(max(1, dd[i] * ssq[i])) for i in range(R)]
         Ps, dd, it, nb, ssq, ss, st = call(bl)
-    out = []
-    for i in range(R):
-        out.append({"status": int(st[i]), "P": Partition(int(dd[i]), Ps[i].reshape(n, n, order="F")), "iterations": int(it[i]),
-                    "nblocks": int(nb[i]), "sum_sq": int(ssq[i]), "sum_s": int(ss[i]),
-                    "blks": bl[i][:dd[i] * ssq[i]].reshape(dd[i], ssq[i]) if sd is not None and st[i] == 0 else None})
-    return out
+        out = []
+        for i in range(R):
+            out.append({"status": int(st[i]), "P": Partition(int(dd[i]), Ps[i].reshape(n, n, order="F")), "iterations": int(it[i]),
+                        "nblocks": int(nb[i]), "sum_sq": int(ssq[i]), "sum_s": int(ss[i]),
+                        "blks": bl[i][:dd[i] * ssq[i]].reshape(dd[i], ssq[i]) if st[i] == 0 else None})
+        return out
+
+
+def jordan_reduce_batch(C_, A, b, restarts=2, seeds=None, atol=RTOL_DEFAULT, epsilon=RTOL_DEFAULT, ctx=None, setup=None):
+    """``restarts`` independent random restarts of ``admissible_subspace`` + ``blockDiagonalize`` of one problem in ONE
+    call on one host thread: restart i with its own random streams, HIP stream and workspace; while one restart's host
+    side waits for a verdict the others' work is submitted.  The reference's answer to the randomized failures of
+    ``blockDiagonalize`` is "try again" (src/eigen_decomposition.jl:264-270, src/diagonalize.jl:4-9): here the tries run
+    side by side and the caller takes the first whose status is 0.  The problem is uploaded once (``Problem``) and both
+    passes -- sizes, then images -- read it on the device; ``seeds=None`` draws explicit seeds, so that the two passes run
+    the same restarts.  Returns a list of dicts: status, P (Partition), iterations, nblocks, sum_sq, sum_s, blks
+    (d x sum s_k^2 array, class-major; None for a restart whose status is not 0)."""
+    with Problem(C_, A, b, atol=atol, ctx=ctx, setup=setup) as prob:
+        return prob.reduce_batch(restarts, seeds=seeds, epsilon=epsilon)
 
 
 def reduce_constraints(P, A, ctx=None):

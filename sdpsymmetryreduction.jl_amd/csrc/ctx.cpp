@@ -96,6 +96,7 @@ int d2h_sync(sdpsr_ctx* c, void* host, const void* dev, size_t bytes) {
     if (!p) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
     HIP_TRY(c, hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, ctx_sync_stream(c, c->stream));
+    c->d2h_bytes += bytes;
     memcpy(host, p, bytes);
     return SDPSR_OK;
 }
@@ -105,6 +106,7 @@ int d2h_sync(sdpsr_ctx* c, void* host, const void* dev, size_t bytes) {
 constexpr size_t H2D_SLOT = 32 * 1024;
 constexpr int H2D_SLOTS = 32;
 int h2d_sync(sdpsr_ctx* c, void* dev, const void* host, size_t bytes) {
+    c->h2d_bytes += bytes;
     if (bytes <= H2D_SLOT) {
         if (!c->h2d_ring && hipHostMalloc(&c->h2d_ring, H2D_SLOT * H2D_SLOTS, hipHostMallocDefault) != hipSuccess) {
             c->h2d_ring = nullptr;
@@ -307,6 +309,18 @@ int sdpsr_wait_stream(sdpsr_ctx* c, void* hip_stream) {
 int sdpsr_hint_symmetric_basis(sdpsr_ctx* c, int yes) {
     if (!c) return SDPSR_BAD_ARGUMENT;
     c->hint_symmetric_basis = yes & 3;
+    return SDPSR_OK;
+}
+
+int sdpsr_transfer_bytes(sdpsr_ctx* c, uint64_t* h2d, uint64_t* d2h) {
+    if (!c) return SDPSR_BAD_ARGUMENT;
+    uint64_t a = c->h2d_bytes, b = c->d2h_bytes;
+    for (const sdpsr_ctx* ch : c->batch_children) {
+        a += ch->h2d_bytes;
+        b += ch->d2h_bytes;
+    }
+    if (h2d) *h2d = a;
+    if (d2h) *d2h = b;
     return SDPSR_OK;
 }
 

@@ -42,6 +42,7 @@ const T* in_dev(sdpsr_ctx* c, const char* name, const T* p, size_t count, int me
         *st = ctx_fail(c, SDPSR_HIP_ERROR, std::string("H2D copy of ") + name);
         return nullptr;
     }
+    c->h2d_bytes += count * sizeof(T);
     return d;
 }
 
@@ -56,8 +57,10 @@ T* out_dev(sdpsr_ctx* c, const char* name, T* p, size_t count, int mem, int* st)
 template <typename T>
 int out_finish(sdpsr_ctx* c, T* host, const T* dev, size_t count, int mem) {
     // outputs are complete on return in both memory spaces (ordering rule of sdpsr.h)
-    if (mem != SDPSR_MEM_DEVICE)
+    if (mem != SDPSR_MEM_DEVICE) {
         HIP_TRY(c, hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        c->d2h_bytes += count * sizeof(T);
+    }
     HIP_TRY(c, ctx_sync_stream(c, c->stream));
     return SDPSR_OK;
 }
@@ -81,6 +84,14 @@ bool label_overflows(const sdpsr_ctx* c, uint64_t value);
 int label_overflow_fail(sdpsr_ctx* c, const char* where, uint64_t value);
 uint64_t next_key(sdpsr_ctx* c);
 int check_len(sdpsr_ctx* c, int64_t len);
+// reduce.cpp / batch.cpp: the entry points with the memory spaces of the inputs and of the outputs named separately
+int jordan_reduce_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r, double atol, double epsilon,
+                       uint32_t* P_out, int64_t* dim_out, int32_t* iters_out, int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks,
+                       int64_t blks_capacity, double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem_in, int mem_out);
+int jordan_reduce_batch_impl(sdpsr_ctx* c, int32_t R, const uint64_t* seeds, int64_t n, const double* CL, const double* X0L, const double* U,
+                             int64_t r, int hint, double atol, double epsilon, uint32_t* const* P_out, int64_t* dim_out, int32_t* iters_out,
+                             int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* const* blks, const int64_t* blks_capacity,
+                             int32_t* status, int mem_in, int mem_out);
 
 // ---- phase timing with events; collected after the syncs the loop needs anyway ----
 struct PhaseTimer {

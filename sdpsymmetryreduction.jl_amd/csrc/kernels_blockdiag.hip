@@ -3,9 +3,7 @@
 // irreducible_decomposition, and basis_image as a segmented outer-product reduction.
 #include <cstdlib>
 #include <type_traits>
-#include "sdpsr_internal.h"
-
-#include <hipcub/hipcub.hpp>
+#include "host_internal.h"
 
 namespace sdpsr {
 
@@ -1255,11 +1253,6 @@ void launch_transpose_to_rowmajor(hipStream_t s, int64_t n, int64_t S1, const do
 // ---------------------------------------------------------------------------
 // entries grouped by class: _constraints(P), src/diagonalize.jl:42-50
 // ---------------------------------------------------------------------------
-__global__ void iota_kernel(int64_t len, uint32_t* __restrict__ v) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += stride)
-        v[e] = (uint32_t)e;
-}
 // class_start[l] = first position of label l in the sorted key array (sorted_keys ascending)
 __global__ void class_starts_kernel(int64_t len, const uint32_t* __restrict__ sorted_keys,
                                     int64_t* __restrict__ class_start) {
@@ -1270,40 +1263,175 @@ __global__ void class_starts_kernel(int64_t len, const uint32_t* __restrict__ so
     }
 }
 
+// Stable sort of (label, index) pairs by label: an LSD radix sort with 4-bit digits, written for this use (round 5; hipCUB's
+// SortPairs before).  A workgroup owns 2048 CONSECUTIVE pairs, a thread 8 consecutive ones, so "earlier thread, then earlier
+// register" is index order and the ranks below are stable.  Per pass: per-workgroup digit histograms (bin-major, so that one
+// linear exclusive scan gives every workgroup its write offset per digit: no atomics anywhere, a deterministic order), then
+// the scatter with ranks from a block-wide scan of the threads' packed digit counts.
+constexpr int RX_T = 256, RX_E = 8, RX_CH = RX_T * RX_E;
+__device__ __forceinline__ void rx_load(int64_t len, int64_t e0, const uint32_t* __restrict__ k, const uint32_t* __restrict__ v, uint32_t (&kk)[RX_E],
+                                        uint32_t (&vv)[RX_E]) {
+#pragma unroll
+    for (int q = 0; q < RX_E; ++q) {
+        const int64_t e = e0 + q;
+        kk[q] = e < len ? k[e] : 0xFFFFFFFFu;
+        vv[q] = e < len ? (v ? v[e] : (uint32_t)e) : 0u;
+    }
+}
+__global__ void __launch_bounds__(RX_T)
+rx_hist_kernel(int64_t len, const uint32_t* __restrict__ keys, int shift, uint32_t G, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t e0 = (int64_t)blockIdx.x * RX_CH + (int64_t)threadIdx.x * RX_E;
+    uint32_t c[16] = {};
+#pragma unroll
+    for (int q = 0; q < RX_E; ++q)
+        if (e0 + q < len) {
+            const uint32_t dg = (keys[e0 + q] >> shift) & 15u;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) c[b] += dg == (uint32_t)b;
+        }
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+        if (c[b]) atomicAdd(&h[b], c[b]);
+    __syncthreads();
+    if (threadIdx.x < 16) hist[(size_t)threadIdx.x * G + blockIdx.x] = h[threadIdx.x];
+}
+// exclusive scan of v[0 .. m) in place by one workgroup
+__global__ void __launch_bounds__(1024)
+rx_scan_kernel(int64_t m, uint32_t* __restrict__ v) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0u;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += 8192) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * 8;
+        uint32_t x[8], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            x[q] = (i0 + q < m) ? v[i0 + q] : 0u;
+            sum += x[q];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t run = carry_s + incl - sum;
+        for (int k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (i0 + q < m) v[i0 + q] = run;
+            run += x[q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(RX_T)
+rx_scatter_kernel(int64_t len, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int shift, uint32_t G,
+                  const uint32_t* __restrict__ offs, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t wtot[RX_T / 64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t e0 = (int64_t)blockIdx.x * RX_CH + (int64_t)threadIdx.x * RX_E;
+    uint32_t kk[RX_E], vv[RX_E];
+    rx_load(len, e0, keys, vals, kk, vv);
+    // the thread's counts per digit, two 16-bit counters per word (<= 2048 per workgroup)
+    uint32_t pk[8] = {};
+#pragma unroll
+    for (int q = 0; q < RX_E; ++q)
+        if (e0 + q < len) {
+            const uint32_t dg = (kk[q] >> shift) & 15u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] += (dg >> 1) == (uint32_t)j ? (1u << (16 * (dg & 1u))) : 0u;
+        }
+    // exclusive scan over the threads, every word (both counters at once)
+    uint32_t ex[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t incl = pk[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wtot[w][j] = incl;
+        ex[j] = incl - pk[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        for (int k = 0; k < w; ++k) ex[j] += wtot[k][j];
+    // write: position = the workgroup's offset of the digit + earlier threads' records of that digit + earlier registers'
+    uint32_t seen[8] = {};
+#pragma unroll
+    for (int q = 0; q < RX_E; ++q)
+        if (e0 + q < len) {
+            const uint32_t dg = (kk[q] >> shift) & 15u;
+            uint32_t before = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if ((dg >> 1) == (uint32_t)j) {
+                    before = ((ex[j] + seen[j]) >> (16 * (dg & 1u))) & 0xFFFFu;
+                    seen[j] += 1u << (16 * (dg & 1u));
+                }
+            const uint32_t pos = offs[(size_t)dg * G + blockIdx.x] + before;
+            keys_out[pos] = kk[q];
+            vals_out[pos] = vv[q];
+        }
+}
+
 int sort_entries_by_label(sdpsr_ctx* c, int64_t len, int64_t d, const uint32_t* L,
                           uint32_t** ent_out, int64_t** class_ptr_host) {
     hipStream_t s = c->stream;
-    uint32_t* idx_in = (uint32_t*)ctx_buf(c, "bi_idx_in", len * sizeof(uint32_t));
-    uint32_t* idx_out = (uint32_t*)ctx_buf(c, "bi_idx_out", len * sizeof(uint32_t));
-    uint32_t* key_out = (uint32_t*)ctx_buf(c, "bi_key_out", len * sizeof(uint32_t));
+    if (len >= (int64_t(1) << 32)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "sort_entries_by_label: len >= 2^32");
+    const uint32_t G = (uint32_t)((len + RX_CH - 1) / RX_CH);
+    uint32_t* kA = (uint32_t*)ctx_buf(c, "bi_key_a", len * sizeof(uint32_t));
+    uint32_t* kB = (uint32_t*)ctx_buf(c, "bi_key_out", len * sizeof(uint32_t));
+    uint32_t* vA = (uint32_t*)ctx_buf(c, "bi_idx_in", len * sizeof(uint32_t));
+    uint32_t* vB = (uint32_t*)ctx_buf(c, "bi_idx_out", len * sizeof(uint32_t));
+    uint32_t* hist = (uint32_t*)ctx_buf(c, "bi_sort_tmp", (size_t)16 * G * sizeof(uint32_t));
     int64_t* cstart = (int64_t*)ctx_buf(c, "bi_cstart", (d + 2) * sizeof(int64_t));
-    if (!idx_in || !idx_out || !key_out || !cstart) return SDPSR_OUT_OF_MEMORY;
-    iota_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, idx_in);
+    if (!kA || !kB || !vA || !vB || !hist || !cstart) return SDPSR_OUT_OF_MEMORY;
     int bits = 1;
     while (((int64_t)1 << bits) <= d) ++bits;
-    size_t tmp_bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, L, key_out, idx_in, idx_out, (int)len, 0,
-                                       bits, s);
-    void* tmp = ctx_buf(c, "bi_sort_tmp", tmp_bytes);
-    if (!tmp) return SDPSR_OUT_OF_MEMORY;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, L, key_out, idx_in, idx_out,
-                                                      (int)len, 0, bits, s);
-    if (e != hipSuccess) return ctx_fail(c, SDPSR_HIP_ERROR, "radix sort failed");
-    hipMemsetAsync(cstart, 0xFF, (d + 2) * sizeof(int64_t), s);  // -1 = class absent
-    class_starts_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, key_out, cstart);
-    int64_t* h = (int64_t*)malloc((d + 2) * sizeof(int64_t));
+    const int passes = (bits + 3) / 4;
+    // pass p reads (kin, vin) and writes (kout, vout); the first pass reads the labels themselves with the index as the value
+    const uint32_t* kin = L;
+    const uint32_t* vin = nullptr;
+    uint32_t* kout = (passes & 1) ? kB : kA;  // so that the last pass ends in (kB, vB)
+    uint32_t* vout = (passes & 1) ? vB : vA;
+    for (int p = 0; p < passes; ++p) {
+        rx_hist_kernel<<<G, RX_T, 0, s>>>(len, kin, 4 * p, G, hist);
+        rx_scan_kernel<<<1, 1024, 0, s>>>((int64_t)16 * G, hist);
+        rx_scatter_kernel<<<G, RX_T, 0, s>>>(len, kin, vin, 4 * p, G, hist, kout, vout);
+        kin = kout;
+        vin = vout;
+        kout = (kout == kA) ? kB : kA;
+        vout = (vout == vA) ? vB : vA;
+    }
+    const uint32_t* key_sorted = kin;
+    uint32_t* idx_sorted = const_cast<uint32_t*>(vin);
+    HIP_TRY(c, hipMemsetAsync(cstart, 0xFF, (d + 2) * sizeof(int64_t), s));  // -1 = class absent
+    class_starts_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, key_sorted, cstart);
+    int64_t* h = (int64_t*)malloc((d + 2) * sizeof(int64_t));  // handed to the caller, who frees it
     if (!h) return SDPSR_OUT_OF_MEMORY;
-    e = hipMemcpyAsync(h, cstart, (d + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
+    const int st = d2h_sync(c, h, cstart, (size_t)(d + 1) * sizeof(int64_t));  // (a wait that yields inside a batch call)
+    if (st) {
         free(h);
-        return ctx_fail(c, SDPSR_HIP_ERROR, "class start read-back failed");
+        return st;
     }
     // class_ptr[i] .. class_ptr[i+1] = entries of label i (i = 0..d); fill absent classes
     h[d + 1] = len;
     for (int64_t l = d; l >= 0; --l)
         if (h[l] < 0) h[l] = h[l + 1];
-    *ent_out = idx_out;
+    *ent_out = idx_sorted;
     *class_ptr_host = h;
     return SDPSR_OK;
 }

@@ -666,7 +666,7 @@ gemm_tn_dma256_kernel(int64_t k, const typename GemmTraits<KIND>::in_t* __restri
 // Dynamic-LDS limits are a per-device property of a kernel: sdpsr_create() calls this with the
 // ctx's device current, so a process may hold ctxs on several GPUs (no process-global flags).
 template <int KIND>
-static bool gemm_set_attributes_kind() {
+bool gemm_set_attributes_kind() {
     bool ok = true;
     constexpr int KBt = GemmTraits<KIND>::KB;
     ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<KIND>),

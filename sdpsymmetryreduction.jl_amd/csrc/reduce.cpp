@@ -5,15 +5,18 @@
 // reduction that a caller who wants both results does not need).
 #include <algorithm>
 #include <cstring>
+#include <new>
 
 #include "host_internal.h"
 
 using namespace sdpsr;
 
-extern "C" int sdpsr_jordan_reduce(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r,
-                                   double atol, double epsilon, uint32_t* P_out, int64_t* dim_out, int32_t* iters_out,
-                                   int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks, int64_t blks_capacity,
-                                   double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem) {
+namespace sdpsr {
+// mem_in: where CL / X0L / U live; mem_out: where P_out / blks / Q_hat live
+int jordan_reduce_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r, double atol, double epsilon,
+                       uint32_t* P_out, int64_t* dim_out, int32_t* iters_out, int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks,
+                       int64_t blks_capacity, double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem_in, int mem_out) {
+    const int mem = mem_out;
     CHECK_CTX(c);
     if (!dim_out || n < 1 || !(epsilon > 0) || blks_capacity < 0 || qhat_capacity < 0 || (blks_capacity > 0 && !blks) ||
         (qhat_capacity > 0 && !Q_hat))
@@ -32,12 +35,14 @@ extern "C" int sdpsr_jordan_reduce(sdpsr_ctx* c, int64_t n, const double* CL, co
     c->bd_labels_ext = nullptr;
     double pm_a[SDPSR_T_COUNT] = {}, pm_b[SDPSR_T_COUNT] = {}, pm_i[SDPSR_T_COUNT] = {};
     int labels_sym = 0;
-    st = admissible_subspace_impl(c, n, CL, X0L, U, r, atol, L, dim_out, iters_out, phase_ms ? pm_a : nullptr, mem, SDPSR_MEM_DEVICE,
+    st = admissible_subspace_impl(c, n, CL, X0L, U, r, atol, L, dim_out, iters_out, phase_ms ? pm_a : nullptr, mem_in, SDPSR_MEM_DEVICE,
                                   /*final_sync=*/false, &labels_sym);
     const int st_loop = st;
     if (st && st != SDPSR_NOT_CONVERGED) return st;
-    if (P_out && !in_place)  // stream-ordered; complete when the call returns (it ends with a synchronisation on every path)
-        HIP_TRY(c, hipMemcpyAsync(P_out, L, (size_t)len * 4, hipMemcpyDeviceToHost, s));
+    if (P_out && !in_place) {  // stream-ordered; complete when the call returns (it ends with a synchronisation on every path)
+        HIP_TRY(c, hipMemcpyAsync(P_out, L, (size_t)len * 4, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        if (mem != SDPSR_MEM_DEVICE) c->d2h_bytes += (size_t)len * 4;
+    }
     const int64_t d = *dim_out;
     int32_t nb = 0;
     int64_t S = 0, S1 = 0;
@@ -81,4 +86,78 @@ extern "C" int sdpsr_jordan_reduce(sdpsr_ctx* c, int64_t n, const double* CL, co
         for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = pm_a[i] + pm_b[i] + pm_i[i];
     }
     return st ? st : st_loop;
+}
+}  // namespace sdpsr
+
+extern "C" int sdpsr_jordan_reduce(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r,
+                                   double atol, double epsilon, uint32_t* P_out, int64_t* dim_out, int32_t* iters_out,
+                                   int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks, int64_t blks_capacity,
+                                   double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem) {
+    return jordan_reduce_impl(c, n, CL, X0L, U, r, atol, epsilon, P_out, dim_out, iters_out, nblocks, sum_sq, sum_s, blks, blks_capacity, Q_hat,
+                              qhat_capacity, phase_ms, mem, mem);
+}
+
+// ---------------------------------------------------------------------------
+// Upload once, reduce many times: the problem handle (include/sdpsr.h)
+// ---------------------------------------------------------------------------
+extern "C" int sdpsr_problem_create(sdpsr_ctx* c, int64_t n, const double* CL, const double* X0L, const double* U, int64_t r, int hint, int mem,
+                                    sdpsr_problem** out) {
+    CHECK_CTX(c);
+    if (!out || !CL || !X0L || n < 1 || r < 0 || (r > 0 && !U)) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    *out = nullptr;
+    const int64_t len = n * n;
+    int st = check_len(c, len);
+    if (st) return st;
+    DeviceGuard dg(c->device);
+    sdpsr_problem* p = new (std::nothrow) sdpsr_problem();
+    if (!p) return SDPSR_OUT_OF_MEMORY;
+    p->device = c->device;
+    p->n = n;
+    p->r = r;
+    p->hint = hint & 3;
+    const size_t vb = (size_t)len * 8;
+    auto fail = [&](int code, const char* what) {
+        sdpsr_problem_destroy(p);
+        return ctx_fail(c, code, what);
+    };
+    if (hipMalloc((void**)&p->CL, vb) != hipSuccess || hipMalloc((void**)&p->X0, vb) != hipSuccess ||
+        (r > 0 && hipMalloc((void**)&p->U, vb * (size_t)r) != hipSuccess))
+        return fail(SDPSR_OUT_OF_MEMORY, "sdpsr_problem_create: device memory");
+    const hipMemcpyKind kind = mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (hipMemcpyAsync(p->CL, CL, vb, kind, c->stream) != hipSuccess || hipMemcpyAsync(p->X0, X0L, vb, kind, c->stream) != hipSuccess ||
+        (r > 0 && hipMemcpyAsync(p->U, U, vb * (size_t)r, kind, c->stream) != hipSuccess))
+        return fail(SDPSR_HIP_ERROR, "sdpsr_problem_create: copy");
+    if (mem != SDPSR_MEM_DEVICE) c->h2d_bytes += vb * (size_t)(2 + r);
+    if (ctx_sync_stream(c, c->stream) != hipSuccess) return fail(SDPSR_HIP_ERROR, "sdpsr_problem_create: synchronisation");
+    *out = p;
+    return SDPSR_OK;
+}
+
+extern "C" int sdpsr_problem_destroy(sdpsr_problem* p) {
+    if (!p) return SDPSR_OK;
+    DeviceGuard dg(p->device);
+    if (p->CL) hipFree(p->CL);
+    if (p->X0) hipFree(p->X0);
+    if (p->U) hipFree(p->U);
+    delete p;
+    return SDPSR_OK;
+}
+
+extern "C" int sdpsr_problem_reduce(sdpsr_ctx* c, const sdpsr_problem* p, double atol, double epsilon, uint32_t* P_out, int64_t* dim_out,
+                                    int32_t* iters_out, int32_t* nblocks, int64_t* sum_sq, int64_t* sum_s, double* blks, int64_t blks_capacity,
+                                    double* Q_hat, int64_t qhat_capacity, double* phase_ms, int mem_out) {
+    CHECK_CTX(c);
+    if (!p || p->device != c->device) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "sdpsr_problem_reduce: no problem, or one of another device");
+    c->hint_symmetric_basis = p->hint;
+    return jordan_reduce_impl(c, p->n, p->CL, p->X0, p->U, p->r, atol, epsilon, P_out, dim_out, iters_out, nblocks, sum_sq, sum_s, blks,
+                              blks_capacity, Q_hat, qhat_capacity, phase_ms, SDPSR_MEM_DEVICE, mem_out);
+}
+
+extern "C" int sdpsr_problem_reduce_batch(sdpsr_ctx* c, const sdpsr_problem* p, int32_t R, const uint64_t* seeds, double atol, double epsilon,
+                                          uint32_t* const* P_out, int64_t* dim_out, int32_t* iters_out, int32_t* nblocks, int64_t* sum_sq,
+                                          int64_t* sum_s, double* const* blks, const int64_t* blks_capacity, int32_t* status, int mem_out) {
+    CHECK_CTX(c);
+    if (!p || p->device != c->device) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "sdpsr_problem_reduce_batch: no problem, or one of another device");
+    return jordan_reduce_batch_impl(c, R, seeds, p->n, p->CL, p->X0, p->U, p->r, p->hint, atol, epsilon, P_out, dim_out, iters_out, nblocks, sum_sq,
+                                    sum_s, blks, blks_capacity, status, SDPSR_MEM_DEVICE, mem_out);
 }

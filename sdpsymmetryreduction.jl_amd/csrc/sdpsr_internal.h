@@ -74,20 +74,32 @@ struct sdpsr_ctx {
     void (*yield_fn)(void*) = nullptr;
     void* yield_arg = nullptr;
     std::vector<sdpsr_ctx*> batch_children;  // the ctxs of restarts 1 .. R - 1 (created on demand, destroyed with this ctx)
+    uint64_t h2d_bytes = 0, d2h_bytes = 0;   // bytes this ctx has moved over PCIe (sdpsr_transfer_bytes)
 };
 
-// Host wait for a stream of ctx c (every wait of the library goes through here).
+// sdpsr_problem_create: the loop's inputs, device-resident, shared (read-only) by every reduction / restart that names them
+struct sdpsr_problem {
+    int device = 0;
+    int64_t n = 0, r = 0;
+    double *CL = nullptr, *X0 = nullptr, *U = nullptr;  // hipMalloc'ed, owned
+    int hint = 0;  // sdpsr_hint_symmetric_basis bits that hold for these inputs
+};
+
+// Host wait for a stream of ctx c (every wait of the library goes through here).  Inside a batch call the wait polls and
+// hands the thread to the other restarts' fibers.  hipStreamQuery records its "not ready" as the thread's last error, and
+// all fibers share that slot: exactly that value is dropped on every way out (a fiber whose first query succeeds must not
+// inherit another fiber's "not ready" either), anything else -- a failed launch of this restart, recorded before the
+// wait -- is handed to the caller as the wait's result instead of being cleared with it.
 inline hipError_t ctx_sync_stream(sdpsr_ctx* c, hipStream_t s) {
     if (!c || !c->yield_fn) return hipStreamSynchronize(s);
-    bool waited = false;
+    const hipError_t before = hipPeekAtLastError();
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) {
-            // "not ready" is an answer, not a failure: it must not be what a later hipGetLastError() of this thread reports
-            if (waited && e == hipSuccess) (void)hipGetLastError();
+            if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
+            if (e == hipSuccess && before != hipSuccess && before != hipErrorNotReady) return before;
             return e;
         }
-        waited = true;
         c->yield_fn(c->yield_arg);
     }
 }
@@ -249,7 +261,7 @@ void launch_sub_round(hipStream_t s, int64_t len, const double* a, const double*
 
 // Kernels with more than 64 KiB of dynamic LDS carry a per-DEVICE attribute: sdpsr_create() sets
 // them all with the ctx's device current (no process-global "already set" flags) and fails when one
-// hipFuncSetAttribute does (false: a later launch would otherwise fail with an opaque error).
+// attribute call does (false: a later launch would otherwise fail with an opaque error).
 bool gemm_set_device_attributes();
 bool blockdiag_set_device_attributes();
 bool module_set_device_attributes();

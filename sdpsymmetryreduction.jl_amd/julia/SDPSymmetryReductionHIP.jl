@@ -268,6 +268,50 @@ function jordan_reduce_batch(C::AbstractVector{Float64}, A::AbstractMatrix{Float
     return [(status=Int(st[i]), P=HIPPartition(Int(d[i]), Ps[i]), iterations=Int(it[i]), nblocks=Int(nb[i]),
              sum_sq=Int(ssq[i]), sum_s=Int(ss[i])) for i in 1:R]
 end
+# (the library uploads C_L, X0_L, U once for the R restarts of this call; a caller who makes SEVERAL such calls on one
+# problem keeps a `Problem` and calls `reduce_batch(problem, R)`: nothing is uploaded again)
+
+# ---- upload once, restart many (sdpsr_problem_create / sdpsr_problem_reduce_batch): C_L, X0_L, U travel to the device
+# ONCE; every later reduce / reduce_batch call names the handle and moves only its results.  `mem` = MEM_DEVICE takes
+# device pointers instead (an AMDGPU.jl ROCArray: pass `pointer(a)` of the ROCArray{Float64} -- they are copied on the
+# device, the caller's arrays are free on return). ----
+const MEM_DEVICE = Cint(1)
+mutable struct Problem
+    handle::Ptr{Cvoid}
+    n::Int
+    ctx::Context
+    function Problem(C::AbstractVector{Float64}, A::AbstractMatrix{Float64}, b::AbstractVector{Float64};
+                     atol=Base.rtoldefault(Float64), cx::Context=ctx())
+        n = isqrt(length(C)); @assert n^2 == length(C)
+        F = qr(A'); U = Matrix(F.Q)[:, 1:rank(A)]; proj(v) = U * (U' * v)
+        c = Vector(C); c .-= proj(c); SR._clamp_round!(c, atol=atol); SR._symmetrize!(c, n)
+        x0, _ = SR.Krylov.craig(A, b); SR._symmetrize!(x0, n); x0 = proj(x0); SR._clamp_round!(x0, atol=atol)
+        hint = 2 | (all(k -> (M = reshape(view(U, :, k), n, n); isapprox(M, M'; atol=1e-12, rtol=0)), 1:size(U, 2)) ? 1 : 0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(cx, ccall((:sdpsr_problem_create, libsdpsr), Cint,
+                        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
+                        cx.handle, n, c, x0, U, size(U, 2), hint, MEM_HOST, h))
+        p = new(h[], n, cx)
+        finalizer(q -> (q.handle != C_NULL && ccall((:sdpsr_problem_destroy, libsdpsr), Cint, (Ptr{Cvoid},), q.handle); q.handle = C_NULL), p)
+        return p
+    end
+end
+
+function reduce_batch(p::Problem, R::Integer; seeds::Union{Nothing,Vector{UInt64}}=nothing, atol=Base.rtoldefault(Float64),
+                      epsilon=Base.rtoldefault(Float64))
+    n = p.n; cx = p.ctx
+    Ps = [Matrix{UInt32}(undef, n, n) for _ in 1:R]
+    pP = [pointer(P) for P in Ps]
+    d = zeros(Int64, R); it = zeros(Int32, R); nb = zeros(Int32, R); ssq = zeros(Int64, R); ss = zeros(Int64, R)
+    st = fill(Int32(-1), R)
+    rc = GC.@preserve Ps ccall((:sdpsr_problem_reduce_batch, libsdpsr), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{UInt64}, Float64, Float64, Ptr{Ptr{UInt32}}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32},
+               Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int32}, Cint),
+              cx.handle, p.handle, R, seeds === nothing ? C_NULL : seeds, atol, epsilon, pP, d, it, nb, ssq, ss, C_NULL, C_NULL, st, MEM_HOST)
+    (rc != 0 && all(x -> x <= 0, st)) && check(cx, rc)   # a failure before the restarts started
+    return [(status=Int(st[i]), P=HIPPartition(Int(d[i]), Ps[i]), iterations=Int(it[i]), nblocks=Int(nb[i]),
+             sum_sq=Int(ssq[i]), sum_s=Int(ss[i])) for i in 1:R]
+end
 
 # ---- test/numerical_issues.jl:85-94 in one call: `count` runs of eigen_decomposition on all CUs ----
 function eigen_decomposition_batched(P::HIPPartition, count::Integer; atol=1e-12 * size(P, 1))

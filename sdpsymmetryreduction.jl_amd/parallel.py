@@ -87,6 +87,45 @@ def agree_partition(labels, relabel, group=None, checksum=None):
     return False, new_labels
 
 
+def _slot_multiplier(k):
+    return _ODD[k % len(_ODD)] * (2 * (k // len(_ODD)) + 1)
+
+
+def agree_partitions(labels_list, relabel, group=None, checksum=None):
+    """The agreement step for R restarts PER RANK (``bench.py --restarts-per-gpu R``, ``sdpsr_jordan_reduce_batch``): every
+    rank holds R label tensors (independent draws of src/partitions.jl:154-185).  The R x world table of 128-bit
+    checksums is all-gathered (2 R words per rank); if all its rows are equal the restarts agree -- across ranks AND
+    within each rank.  Otherwise every restart's labels enter the meet: a universal hash with one odd multiplier per
+    (rank, restart) slot, summed over the rank's own restarts locally and over the ranks with ONE all-reduce, then the
+    canonical relabel -- a restart whose draws missed a split is refined by the others, whichever rank it ran on.
+    Returns (agreed_without_meet, labels); after a meet every restart adopts ``labels``."""
+    import torch
+    import torch.distributed as dist
+    R = len(labels_list)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = labels_list[0].device
+    words = []
+    for t in labels_list:
+        w0, w1 = (checksum or torch_checksum)(t)
+        words += [_signed(w0), _signed(w1)]
+    gdev = None if (dev.type != "cpu" and dist.get_backend(group) == "gloo") else dev
+    mine = torch.tensor(words, dtype=torch.int64, device=gdev)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
+    table = torch.stack(got).reshape(world * R, 2).cpu()
+    if bool((table == table[0]).all()):
+        return True, labels_list[0]
+    sig = None
+    for i, t in enumerate(labels_list):
+        term = (t.to(torch.int64) + 1) * _signed(_slot_multiplier(rank * R + i))  # wraps mod 2^64
+        sig = term if sig is None else sig + term
+    dist.all_reduce(sig, op=dist.ReduceOp.SUM, group=group)
+    zero_key = sum(_slot_multiplier(k) for k in range(world * R))
+    new_labels, _ = relabel(sig - _signed(zero_key))
+    return False, new_labels
+
+
 def agree_block_diagonalization(status, blk_sizes, q_hat=None, group=None, device=None):
     """``blockDiagonalize`` is randomized and the reference's answer to ``NumericalInconsistency`` /
     ``DimensionMismatch`` is "try again" (src/eigen_decomposition.jl:264-270, src/diagonalize.jl:4-9).  With one restart

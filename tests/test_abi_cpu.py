@@ -12,7 +12,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 25
     for s in names:
         assert hasattr(lib, s), s
-    assert lib.sdpsr_version() == 3
+    assert lib.sdpsr_version() == 5
     assert lib.sdpsr_status_string(3) == b"DIMENSION_MISMATCH"
     # the product library exports the reference-facing ABI only: the measurement entry points live in
     # libsdpsr_prof.so (include/sdpsr_prof.h)
@@ -219,9 +219,12 @@ def test_no_process_global_state_in_the_library():
         for m in re.finditer(r'getenv\("(\w+)"\)', txt):
             if m.group(1) != "SDPSR_DEBUG":
                 bad.append((f, m.group(0)))
-        # every hipFuncSetAttribute sits in a *_set_device_attributes function
+        # every hipFuncSetAttribute sits in a *_set_device_attributes function -- which returns bool (round 5) -- and its
+        # result is checked: sdpsr_create fails when an LDS opt-in does (it used to surface as an opaque launch error)
         for m in re.finditer(r"hipFuncSetAttribute", txt):
             head = txt[:m.start()]
-            fn = re.findall(r"\n(?:static\s+)?void\s+(\w+)\s*\([^)]*\)\s*\{", head)
+            fn = re.findall(r"\n(?:static\s+)?(?:void|bool)\s+(\w+)\s*\([^)]*\)\s*\{", head)
             assert fn and ("set_device_attributes" in fn[-1] or "set_attributes_kind" in fn[-1]), (f, fn[-1:] )
+            line = txt[txt.rfind("\n", 0, m.start()) + 1:m.start()]
+            assert "ok &=" in line, (f, line)
     assert bad == []

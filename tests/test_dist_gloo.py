@@ -70,6 +70,27 @@ def _worker(rank, world, port, q):
     res["long_form"] = winb == 1 and sb == big
     winc, sc, _ = par.agree_block_diagonalization(0, big if rank == 0 else [7, 7])
     res["long_form_rank0_wins"] = winc == 0 and sc == big
+    # 5) R restarts per rank (bench.py --restarts-per-gpu R): the R x world table of checksums.  All equal: agreement
+    #    without a meet.  Restart 1 of rank 1 missed a split: the meet over all four restarts -- across the ranks and
+    #    within rank 1 -- restores the finer partition on every rank.  A miss inside ONE rank only (rank 0's two restarts
+    #    differ, rank 1's agree with rank 0's first) is caught as well.
+    okr, outr = par.agree_partitions([flat.clone(), flat.clone()], par.relabel_numpy)
+    res["table_equal"] = okr and bool((outr == flat).all())
+    coarse = flat.clone()
+    coarse[coarse == 2] = 1
+    coarse, _ = par.relabel_numpy(coarse)
+    mine2 = [flat.clone(), coarse.clone() if rank == 1 else flat.clone()]
+    okm, meetr = par.agree_partitions(mine2, par.relabel_numpy)
+    res["table_meet_across_ranks"] = (not okm) and bool((meetr == flat).all())
+    mine3 = [flat.clone(), coarse.clone() if rank == 0 else flat.clone()]
+    okw, meetw = par.agree_partitions(mine3, par.relabel_numpy)
+    res["table_meet_within_rank"] = (not okw) and bool((meetw == flat).all())
+    # two different coarsenings on the two ranks: the meet is finer than both (= the common refinement)
+    c2 = flat.clone()
+    c2[c2 == 4] = 3
+    c2, _ = par.relabel_numpy(c2)
+    okx, meetx = par.agree_partitions([coarse.clone() if rank == 0 else c2.clone()] * 2, par.relabel_numpy)
+    res["table_meet_of_two_coarsenings"] = (not okx) and bool((meetx == flat).all())
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()

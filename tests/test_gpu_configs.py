@@ -449,6 +449,20 @@ def test_bench_forced_disagreement_reaches_the_hash_meet():
 
 
 @pytest.mark.gpu
+def test_bench_batched_restarts_two_ranks_forced_disagreement():
+    """`bench.py --gpus 2 --restarts-per-gpu 2` with restart 1 of rank 1 reporting a coarser partition in
+    the warm-up steps.  The batched multi-rank step runs parallel.agree_partitions over all four restarts (the R x world
+    checksum table; on a difference the hash-meet with the device relabel), never asserts on a randomized event, and the
+    agreed partition of every restart must be the generator's closure again (bench.py checks it in the warm-up steps)."""
+    js = _run_bench({"SDPSR_BENCH_FORCE_DISAGREE": "1"}, "--workload", "theta_c32xk128", "--restarts-per-gpu", "2")
+    assert js["n_gpus"] == 2 and js["value"] > 0 and js["config"]["restarts_per_step"] == 4
+    assert js["partition_meets"]["warmup"] == 2 and js["partition_meets"]["timed"] == 0
+    js = _run_bench({"SDPSR_BENCH_FORCE_BD_FAIL": "0"}, "--restarts-per-gpu", "2")
+    w = js["block_diagonalization_winner"]
+    assert w["adopted_warmup"] == 2 and w["adopted_timed"] == 0 and w["all_failed"] == 0
+
+
+@pytest.mark.gpu
 def test_bench_forced_block_diagonalize_failure_adopts_the_winner():
     """rank 0 reports DimensionMismatch for its blockDiagonalize in the warm-up steps; the one-integer
     MIN all-reduce must pick rank 1, whose block sizes are broadcast and adopted (bench.py asserts them against the

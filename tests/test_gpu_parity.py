@@ -1635,3 +1635,69 @@ def test_complex_path_largest_orders(pkg, problems):
         for c in range(Pd.nparts):
             M = (Mlab == c + 1).astype(np.float64)
             assert np.allclose(bd.blks[c][k], q.conj().T @ (M @ q), atol=1e-7), (k, c)
+
+
+def test_problem_handle_uploads_once(pkg, problems, golden):
+    """Upload once, restart many: the PCIe bytes of a 4-restart batch from HOST arrays are those of
+    one call -- through the problem handle (sdpsr_problem_create + sdpsr_problem_reduce_batch: nothing but small words
+    travel after the creation) and through sdpsr_jordan_reduce_batch itself with SDPSR_MEM_HOST (one upload into the
+    ctx's input buffers, not one per restart) -- counted by sdpsr_transfer_bytes; four single host-array calls move four
+    times as much.  Every restart still returns the golden partition and the pinned block sizes."""
+    Lg, d = problems.kron_with_complete(golden["er7_P"].astype(np.int64), 8, seed=3)  # N = 456, blocks [2,2,2,2,3] twice
+    n = Lg.shape[0]
+    Cv, A, b = problems.partition_as_sdp(Lg, seed=2)
+    setup = pkg.admissible_setup(Cv, A, b)
+    _, CL, X0L, U = setup
+    r = U.shape[1]
+    Uf = np.asfortranarray(U)
+    inputs = 8 * n * n * (2 + r)
+    outputs = 4 * n * n
+    expect = sorted([2, 2, 2, 2, 3] * 2)
+    R = 4
+    with pkg.Context(seed=9) as ctx:
+        lib = ctx._lib
+        h0, _ = ctx.transfer_bytes()
+        with pkg.Problem(setup=setup, ctx=ctx) as prob:
+            h1, d1 = ctx.transfer_bytes()
+            assert h1 - h0 == inputs
+            for attempt in range(4):
+                res = prob.reduce_batch(R, seeds=[50 + 10 * attempt + i for i in range(R)])
+                if all(x["status"] == 0 for x in res):
+                    break
+            h2, d2 = ctx.transfer_bytes()
+            assert h2 - h1 < inputs // 4, (h2 - h1, inputs)  # descriptors and class values only: no second copy of C_L, X0, U
+            for x in res:
+                assert x["status"] in (0, 2, 3)
+                assert x["P"].nparts == d and np.array_equal(x["P"].matrix, Lg)
+                if x["status"] == 0:
+                    assert x["sum_sq"] == sum(s * s for s in expect) and x["nblocks"] == len(expect)
+            one = prob.reduce(seed=77) if True else None
+            assert one["P"].nparts == d
+        # the host-array batch entry point: one upload for R restarts
+        Ps = [np.zeros(n * n, dtype=np.uint32) for _ in range(R)]
+        pP = (C.c_void_p * R)(*[a.ctypes.data for a in Ps])
+        dd, st = (C.c_int64 * R)(), (C.c_int32 * R)()
+        h3, _ = ctx.transfer_bytes()
+        lib.sdpsr_jordan_reduce_batch(ctx._h, R, None, n, CL.ctypes.data_as(C.c_void_p), X0L.ctypes.data_as(C.c_void_p), Uf.ctypes.data_as(C.c_void_p), r,
+                                      1.5e-8, 1.5e-8, C.cast(pP, C.c_void_p), dd, None, None, None, None, None, None, st, 0)
+        h4, _ = ctx.transfer_bytes()
+        assert inputs <= h4 - h3 < inputs + inputs // 4, (h4 - h3, inputs)
+        for i in range(R):
+            assert st[i] in (0, 2, 3) and dd[i] == d and np.array_equal(Ps[i].reshape(n, n, order="F"), Lg)
+        # four single calls from host arrays: four uploads
+        dim, it = C.c_int64(0), C.c_int32(0)
+        h5, _ = ctx.transfer_bytes()
+        for i in range(R):
+            rc = lib.sdpsr_jordan_reduce(ctx._h, n, CL.ctypes.data_as(C.c_void_p), X0L.ctypes.data_as(C.c_void_p), Uf.ctypes.data_as(C.c_void_p), r, 1.5e-8, 1.5e-8,
+                                         Ps[0].ctypes.data_as(C.c_void_p), C.byref(dim), C.byref(it), None, None, None, None, 0, None, 0, None, 0)
+            assert rc in (0, 2, 3) and dim.value == d
+        h6, _ = ctx.transfer_bytes()
+        assert h6 - h5 >= R * inputs
+    # bad arguments before the restarts start: every status word says so (ADVICE r4)
+    with pkg.Context(seed=1) as ctx:
+        st = (C.c_int32 * 2)(0, 0)
+        dd = (C.c_int64 * 2)()
+        rc = ctx._lib.sdpsr_jordan_reduce_batch(ctx._h, 2, None, 0, None, None, None, 0, 1.5e-8, 1.5e-8, None, dd, None, None, None, None, None, None, st, 0)
+        assert rc != 0 and all(s != 0 for s in st)
+        with pytest.raises(ValueError):
+            pkg.Problem(setup=setup, ctx=ctx).reduce_batch(2, seeds=[1, 2, 3])
