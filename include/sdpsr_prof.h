@@ -37,6 +37,9 @@ int sdpsr_profile_kernel(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int r
    The int8 squares run power-limited (the clock drops under the kernel); the roofline of
    bench.py reports the fraction of the peak both at the nominal and at this measured clock. */
 int sdpsr_profile_clock(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int reps, double* out);
+/* Host waits for a stream of ctx since its creation (every wait of the library goes through one function): the host round
+   trips of a reduction = the difference around it. */
+int sdpsr_profile_host_waits(sdpsr_ctx* ctx, uint64_t* out);
 /* What the hipGraph cache of the tridiagonalisation (one graph per problem shape and buffer set, kept in ctx) has done
    so far: out[0] = replays of a cached graph, out[1] = misses (a graph of ~2 n nodes built and instantiated on the
    host), out[2] = milliseconds spent building.  A caller that alternates between a few orders pays the build once per

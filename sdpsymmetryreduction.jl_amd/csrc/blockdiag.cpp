@@ -154,6 +154,7 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     // -- one vector's class sums -- with a randomized self-check; the projection formula below runs if the check
     // fails (kernels_blockdiag.hip, launch_basis_image_commutative) and always under SDPSR_FLAG_FULL_BASIS_IMAGE
     bool done = false;
+    bool done_synced = false;  // the stream was synchronised by the commutative path's verdict and nothing was enqueued since
     if (S == S1 && force == 0 && !(c->opts.flags & SDPSR_FLAG_FULL_BASIS_IMAGE) && d >= 1 && n >= 64) {
         double* ws = (double*)ctx_buf(c, "bi_comm_ws", basis_image_commutative_workspace_doubles(n, d) * 8);
         // per-column verdicts, stored by the check kernel straight into pinned host memory: its own words, beside
@@ -166,6 +167,7 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
             HIP_TRY(c, hipGetLastError());
             const uint32_t nbad = hv[0];
             done = nbad == 0;
+            done_synced = done;
             if (!done && nbad <= 8) {
                 // a few columns failed (the eigenvectors of a pair of close eigenvalues): the projection formula for
                 // those columns only, two per extra class-sum pass
@@ -291,16 +293,17 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
     }
     }
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, ctx_sync_stream(c, s));  // host vectors above must outlive the copies
-    st = out_finish(c, blks, out, (size_t)d * S, mem);
-    if (st) return st;
-    if (Q_hat) {
-        if (mem == SDPSR_MEM_DEVICE)
-            HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, hipMemcpyDeviceToDevice, s));
-        else
-            HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, ctx_sync_stream(c, s));
+    // ONE host wait for everything (the images, Q_hat, and the host vectors above, which must outlive their copies): the
+    // copies are enqueued first.  (Three waits before: the second and third found an idle stream, ~3 us each.)
+    if (mem != SDPSR_MEM_DEVICE) {
+        HIP_TRY(c, hipMemcpyAsync(blks, out, (size_t)d * S * 8, hipMemcpyDeviceToHost, s));
+        c->d2h_bytes += (size_t)d * S * 8;
     }
+    if (Q_hat) {
+        HIP_TRY(c, hipMemcpyAsync(Q_hat, Qhat, (size_t)n * S1 * 8, mem == SDPSR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        if (mem != SDPSR_MEM_DEVICE) c->d2h_bytes += (size_t)n * S1 * 8;
+    }
+    if (!(done_synced && mem == SDPSR_MEM_DEVICE && !Q_hat)) HIP_TRY(c, ctx_sync_stream(c, s));
     if (phase_ms) {
         const float ms = ev_total.stop(s);
         for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = 0;

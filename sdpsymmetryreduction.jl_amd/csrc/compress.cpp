@@ -151,6 +151,9 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
     };
     double ref = 0;  // squared scale of the current round's candidate columns before projection
     int abs_err = SDPSR_OK;
+    std::function<void()> before_wait;  // enqueued between an orthogonalisation step's product and its host wait
+    bool spec_b2 = false;               // the second compressed element was formed behind the final round's product ...
+    size_t spec_off = 0;                // ... and sits at this byte offset of the pinned buffer
     // One orthonormalisation step on the mc columns behind the basis, V = W[:, w : w+mc):
     // product [W V]' V, projected Gram matrix on the host, selection X (mc x r); returns r and
     // the stacked coefficients S = [-C X; X] ((w+mc) x r) with V_new = [W V] S.  r < 0: error.
@@ -161,6 +164,11 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
         bool host_filled = false;
         abs_err = hpin ? gram_tn(c, w + mc, mc, ld, W, ld, W + (size_t)w * ld, ld, Cc, ap, mp, hpin, &host_filled) : SDPSR_OUT_OF_MEMORY;
         if (abs_err) return -1;
+        if (before_wait) {  // work that rides on this step's host wait (one-shot)
+            const std::function<void()> f = std::move(before_wait);
+            before_wait = nullptr;
+            f();
+        }
         hG.resize((size_t)ap * mp);
         if (host_filled) {
             if (ctx_sync_stream(c, s) != hipSuccess) {
@@ -308,12 +316,35 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             int e2 = apply_generic(w, Y + (size_t)gidx * w * ld);
             if (e2) return e2;
         }
+        // A round with ONE element is the invariance check of a module that is (almost surely) complete, and the host path of
+        // the small problem will then want the second compressed element B2 = W'A2 W right away: it is formed behind this
+        // round's product and comes back with the same host wait (its pinned words sit behind the round's Gram matrix).
+        // If the round does add a direction, the element is dropped.
+        spec_b2 = false;
+        if (G == 1 && w <= 64 && !(c->opts.flags & SDPSR_FLAG_SMALL_EIGEN_ON_DEVICE) && (c->opts.eig_driver == 0 || c->opts.eig_driver >= 4)) {
+            const int ws = w;
+            spec_off = ((size_t)round_up(ws + m, 128) * (size_t)round_up(m, 128) * 8 + 255) & ~size_t(255);
+            // everything sized BEFORE the round's own requests: no buffer moves between the product and the wait
+            char* pinb = (char*)ctx_pinned(c, spec_off + (size_t)ws * ws * 8);
+            double* dBs = (double*)ctx_buf(c, "cm_bsmall", (size_t)64 * 64 * 8);
+            // (the largest request the round's own product can make: the pointer handed out here stays valid)
+            const size_t gpb = gram_small_partial_doubles(n, 128, 128) * 8;
+            double* gps = (double*)ctx_buf(c, "gram_partials", gpb);
+            if (pinb && dBs && gps)
+                before_wait = [&, ws, dBs, gps]() {
+                    if (apply_generic(ws, T) != SDPSR_OK) return;  // T[:, 0:ws) = A2 W
+                    launch_gram_small(s, n, ws, ws, W, ld, T, ld, gps, dBs, ws, ws, ws, (double*)((char*)c->pinned + spec_off));
+                    spec_b2 = true;
+                };
+        }
         const int got = absorb(m);
+        before_wait = nullptr;
         if (got < 0) {
             tm.end();
             tm.collect();
             return abs_err;
         }
+        if (got != 0) spec_b2 = false;
         if (got == 0) {
             module_complete = true;
             // the module is complete: the top block of this round's product, C = W' (A W), IS the
@@ -366,8 +397,16 @@ int compressed_diagonalize(sdpsr_ctx* c, int64_t n, const uint32_t* L, int64_t d
             if (!e2) e2 = fetch(B1.data());
             if (e2) return e2;
         }
-        bool pending = enqueue_element() == SDPSR_OK;  // B2, formed while the host diagonalises B1
+        bool spec_avail = spec_b2 && have_saved;  // B2 came back with the final round's product: no launch, no wait
+        bool pending = spec_avail ? false : enqueue_element() == SDPSR_OK;  // else B2 is formed while the host diagonalises B1
         const std::function<int(double*)> next_element = [&](double* dst) -> int {
+            if (spec_avail) {
+                spec_avail = false;
+                const double* ps = (const double*)((const char*)c->pinned + spec_off);
+                for (int j = 0; j < w; ++j)
+                    for (int i = 0; i < w; ++i) dst[(size_t)i + (size_t)j * w] = 0.5 * (ps[(size_t)i + (size_t)j * w] + ps[(size_t)j + (size_t)i * w]);
+                return SDPSR_OK;
+            }
             if (!pending) {
                 const int e2 = enqueue_element();
                 if (e2) return e2;

@@ -23,8 +23,10 @@ int ctx_fail(sdpsr_ctx* c, int status, const std::string& msg) {
 
 void* ctx_buf(sdpsr_ctx* c, const char* name, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    DevBuf& b = c->bufs[name];
-    if (b.bytes >= bytes) return b.p;
+    // ~100 calls per reduction: the usual call finds its buffer large enough -- no std::string is built for that
+    auto it = c->bufs.find(std::string_view(name));
+    if (it != c->bufs.end() && it->second.bytes >= bytes) return it->second.p;
+    DevBuf& b = it != c->bufs.end() ? it->second : c->bufs[std::string(name)];
     if (b.p) {
         ctx_sync_stream(c, c->stream);
         hipFree(b.p);

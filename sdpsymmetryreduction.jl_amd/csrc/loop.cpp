@@ -123,8 +123,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
     }
     tm.end();
     if (st) return st;
-    HIP_TRY(c, ctx_sync_stream(c, s));
-    tm.collect();
+    tm.collect();  // (the refinement has synchronised the stream)
     c->adm_dims.assign(1, d);
     if (label_overflows(c, (uint64_t)d)) return label_overflow_fail(c, "admissible_subspace: dim(S)", (uint64_t)d);
     // Projection on the lower triangle (half the bytes and hashes of the step) needs symmetric
@@ -219,6 +218,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                 // verify_*); only a yes runs the insert / rank / label passes.  A confirm round re-checks
                 // the channels only: its projected element is the one the previous round has cleared.
                 bool unchanged = false;
+                bool spec_confirmed = false;  // the confirm round ran speculatively behind this verify pass and found nothing either
                 if ((it == 1 || confirming) && jl2 && c->first_idx_labels == Lp && current >= 1 && current <= (int64_t)refine_first_cap() &&
                     !(c->opts.flags & SDPSR_FLAG_NO_VERIFY_SHORTCUT)) {
                     SigSource qv = qj;
@@ -230,9 +230,31 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                     if (!vref || !first || !hv) return SDPSR_OUT_OF_MEMORY;
                     hv += 128;
                     if (launch_verify_no_split(s, qv, current, first, vref, hv)) {  // the verdict is stored straight into pinned host memory
+                        // An input that was closed the last time (the restarts of ONE problem, the use this library is
+                        // built for) will be closed again: the confirm round -- a fresh square into its own buffers and its
+                        // verify pass -- is enqueued behind the first verdict's kernels and both verdicts come back with
+                        // one host wait instead of two.  A wrong guess costs the discarded square; the result is the same
+                        // either way (the first verdict decides first, exactly as without the guess).
+                        bool spec = false;
+                        uint32_t* hv2 = hv + 16;
+                        if (it == 1 && !confirming && confirm_left > 0 && c->predict_closed && c->predict_n == n) {
+                            void* Xs = ctx_buf(c, "adm_xi8_spec", (size_t)T * ld * ld);
+                            void* Cs = ctx_buf(c, "adm_ci32_spec", (size_t)T * ld * ld * 4);
+                            void* vref2 = ctx_buf(c, "adm_vref2", verify_ref_bytes(current));
+                            if (Xs && Cs && vref2) {
+                                const uint64_t key3 = next_key(c);
+                                launch_gather_i8_sym_packed(s, n, ld, T, Lp, key3, (int8_t*)Xs, current);
+                                launch_gemm_tn_i8_sym(s, ld, ld, (const int8_t*)Xs, ld, (int32_t*)Cs, ld, T, ld * ld, ld * ld, zero_flag, c->num_cus, c->opts.square_kernel);
+                                SigSource q2 = qj;
+                                q2.kind = SIG_CHAN_I32;
+                                q2.C = Cs;
+                                spec = launch_verify_no_split(s, q2, current, first, vref2, hv2);
+                            }
+                        }
                         HIP_TRY(c, ctx_sync_stream(c, s));
                         HIP_TRY(c, hipGetLastError());
                         unchanged = hv[0] == 0;
+                        spec_confirmed = spec && unchanged && hv2[0] == 0;
                     }
                 }
                 if (unchanged) dj = current;  // labels, class representatives and table hints stay as they are
@@ -244,6 +266,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                 tm.collect();
                 if (dj == current && confirm_left > 0) {  // extra independent draws before stopping
                     --confirm_left;
+                    if (spec_confirmed) break;  // the extra draw has been made and looked at already
                     confirming = true;
                     continue;  // (same projected element, a fresh square: the projection did not refine either)
                 }
@@ -427,6 +450,8 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
     }
     need_full();
     HIP_TRY(c, hipGetLastError());
+    c->predict_closed = converged && it == 1 && c->adm_dims.size() == 2 && c->adm_dims[0] == c->adm_dims[1];
+    c->predict_n = n;
     *dim_out = current;
     if (iters_out) *iters_out = it;
     if (labels_sym_out) *labels_sym_out = labels_sym;

@@ -34,6 +34,13 @@ extern "C" int sdpsr_profile_sytrd_graphs(sdpsr_ctx* c, double* out) {
     return SDPSR_OK;
 }
 
+extern "C" int sdpsr_profile_host_waits(sdpsr_ctx* c, uint64_t* out) {
+    CHECK_CTX(c);
+    if (!out) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "null pointer");
+    *out = c->host_waits;
+    return SDPSR_OK;
+}
+
 extern "C" int sdpsr_profile_kernel(sdpsr_ctx* c, int kind, int64_t n, int64_t aux, int reps,
                                     double* ms_per_launch) {
     CHECK_CTX(c);

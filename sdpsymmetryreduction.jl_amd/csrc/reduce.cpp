@@ -78,7 +78,7 @@ int jordan_reduce_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* 
         }
         forget.ok = true;
     }
-    {
+    if (!images_done) {  // (sdpsr_block_images ends synchronised, and nothing has been enqueued since)
         const hipError_t e = ctx_sync_stream(c, s);
         if (e != hipSuccess && st == SDPSR_OK) st = ctx_fail(c, SDPSR_HIP_ERROR, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     }

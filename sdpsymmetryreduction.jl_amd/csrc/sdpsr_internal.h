@@ -8,6 +8,7 @@
 #include <map>
 #include <functional>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "../../include/sdpsr.h"
@@ -37,7 +38,7 @@ struct sdpsr_ctx {
     bool own_stream = false;
     std::string err;
     double dbg_last_ms = 0;  // SDPSR_DEBUG traces: time of the previous mark
-    std::map<std::string, DevBuf> bufs;
+    std::map<std::string, DevBuf, std::less<>> bufs;  // (transparent comparator: looked up by string_view, no allocation per ctx_buf call)
     void* pinned = nullptr;  // small pinned host scratch for scalar read-backs
     size_t pinned_bytes = 0;
     uint32_t* pinned_small = nullptr;  // 256 B pinned: flags read back without their own synchronisation
@@ -75,6 +76,11 @@ struct sdpsr_ctx {
     void* yield_arg = nullptr;
     std::vector<sdpsr_ctx*> batch_children;  // the ctxs of restarts 1 .. R - 1 (created on demand, destroyed with this ctx)
     uint64_t h2d_bytes = 0, d2h_bytes = 0;   // bytes this ctx has moved over PCIe (sdpsr_transfer_bytes)
+    // the loop's branch predictor: the previous admissible_subspace call on this ctx (order predict_n) found its input closed in
+    // the first iteration -- the next call of that order runs the confirm round speculatively behind the first verify pass
+    bool predict_closed = false;
+    int64_t predict_n = 0;
+    uint64_t host_waits = 0;                 // host waits for one of this ctx's streams (ctx_sync_stream); sdpsr_profile_host_waits
 };
 
 // sdpsr_problem_create: the loop's inputs, device-resident, shared (read-only) by every reduction / restart that names them
@@ -91,6 +97,7 @@ struct sdpsr_problem {
 // inherit another fiber's "not ready" either), anything else -- a failed launch of this restart, recorded before the
 // wait -- is handed to the caller as the wait's result instead of being cleared with it.
 inline hipError_t ctx_sync_stream(sdpsr_ctx* c, hipStream_t s) {
+    if (c) ++c->host_waits;
     if (!c || !c->yield_fn) return hipStreamSynchronize(s);
     const hipError_t before = hipPeekAtLastError();
     for (;;) {
