@@ -40,6 +40,10 @@ int sdpsr_profile_clock(sdpsr_ctx* ctx, int kind, int64_t n, int64_t aux, int re
 /* Host waits for a stream of ctx since its creation (every wait of the library goes through one function): the host round
    trips of a reduction = the difference around it. */
 int sdpsr_profile_host_waits(sdpsr_ctx* ctx, uint64_t* out);
+/* Stage 2 of a two-stage tridiagonalisation (band -> tridiagonal by Householder bulge chasing, one workgroup per sweep,
+   hand-offs through progress words), built to be measured: A_host n x n dense symmetric with bandwidth b (16, 32 or 64),
+   d_host (n), e_host (n - 1) the tridiagonal result, out[0] = kernel milliseconds, out[1] = 1 if the chase gave up. */
+int sdpsr_profile_band_chase(sdpsr_ctx* ctx, int64_t n, int b, const double* A_host, double* d_host, double* e_host, double* out);
 /* What the hipGraph cache of the tridiagonalisation (one graph per problem shape and buffer set, kept in ctx) has done
    so far: out[0] = replays of a cached graph, out[1] = misses (a graph of ~2 n nodes built and instantiated on the
    host), out[2] = milliseconds spent building.  A caller that alternates between a few orders pays the build once per

@@ -20,6 +20,7 @@ namespace sdpsr {
 void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t* sig);
 void launch_clock_sampler(hipStream_t s, long long* buf, int ns, const unsigned* flag, long long max_ticks, int* count);
 void launch_wall_marker(hipStream_t s, long long* out);
+bool launch_band_chase(hipStream_t s, int n, int b, double* A, int64_t ld, unsigned* progress, unsigned* abort_flag, double* d, double* e, int max_wgs);
 }
 
 extern "C" int sdpsr_profile_sytrd_graphs(sdpsr_ctx* c, double* out) {
@@ -31,6 +32,41 @@ extern "C" int sdpsr_profile_sytrd_graphs(sdpsr_ctx* c, double* out) {
     out[0] = (double)h;
     out[1] = (double)m;
     out[2] = ms;
+    return SDPSR_OK;
+}
+
+// Stage 2 of a two-stage tridiagonalisation, measured: the symmetric band matrix A (n x n dense, column-major, host; entries
+// beyond bandwidth b zero) is reduced to tridiagonal form by bulge chasing on the device (prof_kernels.hip); d (n), e (n - 1)
+// come back to the host, out[0] = milliseconds of the chase kernel, out[1] = 1 if a workgroup gave up waiting.
+extern "C" int sdpsr_profile_band_chase(sdpsr_ctx* c, int64_t n, int b, const double* A_host, double* d_host, double* e_host, double* out) {
+    CHECK_CTX(c);
+    if (!A_host || !d_host || !e_host || !out || n < 3 || n > 16384) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bad arguments");
+    hipStream_t s = c->stream;
+    double* A = (double*)ctx_buf(c, "prof_band", (size_t)n * n * 8);
+    double* de = (double*)ctx_buf(c, "prof_d", (size_t)3 * n * 8);
+    unsigned* prog = (unsigned*)ctx_buf(c, "prof_prog", (size_t)(n + 16) * 4);
+    if (!A || !de || !prog) return SDPSR_OUT_OF_MEMORY;
+    HIP_TRY(c, hipMemcpyAsync(A, A_host, (size_t)n * n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(prog, 0, (size_t)(n + 16) * 4, s));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    HIP_TRY(c, hipEventRecord(e0, s));
+    const bool ok = launch_band_chase(s, (int)n, b, A, n, prog, prog + n + 8, de, de + n, c->num_cus);
+    HIP_TRY(c, hipEventRecord(e1, s));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (!ok) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "bandwidth must be 16, 32 or 64");
+    unsigned ab = 0;
+    HIP_TRY(c, hipMemcpy(&ab, prog + n + 8, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(d_host, de, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(e_host, de + n, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipGetLastError());
+    out[0] = ms;
+    out[1] = ab;
     return SDPSR_OK;
 }
 
