@@ -305,8 +305,13 @@ int sdpsr_gemm_tn_f64(sdpsr_ctx* ctx, int64_t m, int64_t n, int64_t k, const dou
    basis matrix U_k is constant on every class of the current partition S (compared on the device through the rounding of
    _clamp_round!, :159-164), x - U U'x of any x that is constant on the classes of S is constant on them too -- U_k in
    span(S) implies U U'x in span(S) -- and every finer partition inherits that; generically it holds right after the first
-   projection refinement.  The partition returned is the same; SDPSR_FLAG_ALWAYS_PROJECT keeps the projection in every
-   iteration. */
+   projection refinement.  TOLERANCE CAVEAT: "constant" is decided on the per-entry rounded codes of U_k (atol, 7 digits: an
+   entry |U_k| < atol counts as 0), while the reference rounds x - U U'x AFTER multiplying those differences by the
+   coefficients U_k'x (of the order of |x|): differences of U_k inside a class that are below the rounding resolution can
+   still split it there.  So the partition returned is the same up to that rounding -- exactly the same whenever the U_k
+   take exactly representable values on the classes (constraint matrices with integer entries: every test problem and
+   BASELINE config) --, and SDPSR_FLAG_ALWAYS_PROJECT keeps the projection in every iteration.  The check is made at most
+   three times per call. */
 int sdpsr_admissible_subspace(sdpsr_ctx* ctx, int64_t n, const double* CL, const double* X0L,
                               const double* U, int64_t r, double atol, uint32_t* P_out,
                               int64_t* dim_out, int32_t* iters_out, double* phase_ms, int mem);

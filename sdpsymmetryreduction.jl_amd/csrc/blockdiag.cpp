@@ -183,6 +183,48 @@ int sdpsr_block_images(sdpsr_ctx* c, double* blks, double* Q_hat, double* phase_
             }
         }
     }
+    // blocks up to 3 x 3 (non-commutative algebras with small blocks: ER(q) (x) K_k): the images from FOUR vectors' class
+    // sums with a per-block check (kernels_blockdiag.hip, launch_basis_image_blocks); blocks that fail get the projection
+    // formula, one block per extra pair of passes; many failures: the two-stage kernels below for everything
+    if (!done && S != S1 && force == 0 && !(c->opts.flags & SDPSR_FLAG_FULL_BASIS_IMAGE) && d >= 1 && n >= 64 && c->bd_sizes.size() <= 4096) {
+        int max_s = 0;
+        for (int32_t sz : c->bd_sizes) max_s = std::max(max_s, (int)sz);
+        if (max_s <= 3) {
+            const int nb = (int)c->bd_sizes.size();
+            std::vector<int32_t> hcs(2 * (size_t)nb);
+            std::vector<int64_t> hoff(nb);
+            int64_t colbase = 0, off = 0;
+            for (int k2 = 0; k2 < nb; ++k2) {
+                hcs[k2] = (int32_t)colbase;
+                hcs[nb + k2] = c->bd_sizes[k2];
+                hoff[k2] = off;
+                colbase += c->bd_sizes[k2];
+                off += (int64_t)c->bd_sizes[k2] * c->bd_sizes[k2];
+            }
+            int32_t* d_cs = (int32_t*)ctx_buf(c, "bi_colsz", (size_t)2 * nb * 4);
+            int64_t* d_off = (int64_t*)ctx_buf(c, "bi_off", (size_t)nb * 8);
+            double* ws = (double*)ctx_buf(c, "bi_comm_ws", basis_image_blocks_workspace_doubles(n, d) * 8);
+            uint32_t* hv = (uint32_t*)ctx_pinned(c, 256 + (size_t)(nb + 1) * 4);
+            if (!d_cs || !d_off || !ws || !hv) return SDPSR_OUT_OF_MEMORY;
+            hv += 64;
+            st = h2d_sync(c, d_cs, hcs.data(), (size_t)2 * nb * 4);
+            if (!st) st = h2d_sync(c, d_off, hoff.data(), (size_t)nb * 8);
+            if (st) return st;
+            if (launch_basis_image_blocks(s, n, d, S1, S, nb, d_cs, d_cs + nb, d_off, L, Qrm, next_key(c), -1, atol, 2e-10, ws, out, hv)) {
+                HIP_TRY(c, ctx_sync_stream(c, s));
+                HIP_TRY(c, hipGetLastError());
+                const uint32_t nbad = hv[0];
+                done = nbad == 0;
+                done_synced = done;
+                if (!done && nbad <= 4) {
+                    done = true;
+                    for (int k2 = 0; k2 < nb && done; ++k2)
+                        if (hv[1 + k2]) done = launch_basis_image_blocks(s, n, d, S1, S, nb, d_cs, d_cs + nb, d_off, L, Qrm, 0, k2, atol, 2e-10, ws, out, nullptr);
+                }
+                if (!done_synced && dbg_on()) fprintf(stderr, "[sdpsr] basis_image: invariance check failed for %u block(s)%s\n", nbad, done ? ", projection formula for those" : ", two-stage kernels instead");
+            }
+        }
+    }
     if (done) {
         // (out is complete)
     } else if (basis_image_two_stage_fits(n, d, S1) && !f_outer && !f_chunk) {

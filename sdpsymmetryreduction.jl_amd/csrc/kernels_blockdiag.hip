@@ -1114,11 +1114,21 @@ bi_contract_check_kernel(int n, int S1, const double* __restrict__ Qrm, const do
     const double2* Yi = Y + (int64_t)i * n;
     double a0 = 0, a1 = 0;
     if (k < S1)
-        for (int r = g; r < n; r += 64) {
-            const double q = Qrm[(int64_t)r * S1 + k];
-            const double2 y = Yi[r];
-            a0 = fma(q, y.x, a0);
-            a1 = fma(q, y.y, a1);
+        for (int r0 = g; r0 < n; r0 += 64 * 8) {  // eight rows per trip, their loads in flight together
+            double q[8];
+            double2 y[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int r = r0 + 64 * x;
+                const int rc = r < n ? r : g;
+                q[x] = r < n ? Qrm[(int64_t)rc * S1 + k] : 0.0;
+                y[x] = Yi[rc];
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                a0 = fma(q[x], y[x].x, a0);
+                a1 = fma(q[x], y[x].y, a1);
+            }
         }
     red[0][threadIdx.x] = a0;
     red[1][threadIdx.x] = a1;
@@ -1181,6 +1191,202 @@ bool launch_basis_image_fix_pair(hipStream_t s, int64_t n, int64_t d, int64_t S1
     else if (W == 2) class_sums2_kernel<2><<<g, 128, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
     else class_sums2_kernel<1><<<g, 64, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
     bi_contract_pair_kernel<<<(unsigned)d, 256, 0, s>>>((int)n, (int)S1, Qrm, Y, k1, k2, atol, out);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// basis_image through the block structure, blocks up to 3 x 3 (round 5; the 1 x 1 case above is its special case).
+//
+// Murota's columns of one block, Q_k = [q_k1 .. q_ks], span an INVARIANT subspace: the isotypic component is
+// C^s (x) C^m, the eigenspaces of the generic element are e_j (x) C^m, and irreducible_decomposition takes q_kj = e_j (x) u
+// with one and the same u for j = 1 .. s (src/eigen_decomposition.jl:326-344: q_k1 is an eigenvector, the others are its
+// images under the coupling blocks) -- so 1[P==i] Q_k = Q_k B for the s x s image B = blks[i][k], and the subspaces of
+// different blocks are orthogonal.  For x = sum_k Q_k g_k (one s_k-vector of weights per block):  Q_k'(1[P==i] x) = B g_k.
+// FOUR vectors -- two passes of the pair class-sum kernel, instead of the class sums of all S1 columns (the two-stage
+// kernels: 0.2 ms at ER(7) (x) K_72) -- give B G = Y with G = [g^(0) .. g^(s-1)] (identity + a generic perturbation:
+// well conditioned) and at least one more generic vector to CHECK: B g^(s) must reproduce Y's column s.  The identity is
+// only as good as the invariance, so a block whose check fails (close eigenvalues of the random generic element) gets its
+// image from the projection formula itself -- the same kernels with the weights e_1 .. e_s on that block alone.
+// ---------------------------------------------------------------------------
+constexpr int BIB_T = 4;  // vectors per run (two double2 passes)
+// weight of column j (of block k, size sz) in vector t
+__device__ __forceinline__ double bib_weight(uint64_t key, int k, int j, int t, int sz) {
+    const double u = (double)(sdpsr_fmix64(key + 0x9E3779B97F4A7C15ULL * (uint64_t)(1 + t + BIB_T * (j + 4 * k))) >> 11) * (1.0 / 9007199254740992.0);
+    if (t < sz) return (t == j ? 1.0 : 0.0) + 0.25 * (u - 0.5);
+    return 0.5 + u;  // check vectors: generic
+}
+// X0[r] = (x0, x1), X1[r] = (x2, x3);  only >= 0: weights e_t on block `only` alone (the projection formula for that block)
+__global__ void bib_vectors_kernel(int n, int S1, int nblocks, const int32_t* __restrict__ blk_col, const int32_t* __restrict__ blk_size, uint64_t key, int only,
+                                   const double* __restrict__ Qrm, double2* __restrict__ X0, double2* __restrict__ X1, uint32_t* flag,
+                                   double* __restrict__ ginv) {
+    extern __shared__ double bib_w[];  // weights of the S1 columns, BIB_T each (all blocks at once)
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (flag && blockIdx.x == 0)
+        for (int k = threadIdx.x; k <= nblocks; k += blockDim.x) flag[k] = 0u;
+    if (only < 0) {
+        for (int k = threadIdx.x; k < nblocks; k += blockDim.x) {
+            const int c0 = blk_col[k], sz = blk_size[k];
+            for (int j = 0; j < sz; ++j)
+                for (int t = 0; t < BIB_T; ++t) bib_w[(c0 + j) * BIB_T + t] = bib_weight(key, k, j, t, sz);
+            if (blockIdx.x == 0) {
+                // G^-1 of the block (G = weights of the first sz vectors: identity + a perturbation of at most 1/8 per entry,
+                // strictly diagonally dominant), once per block instead of once per (class, block) in the contraction; closed
+                // forms (adjugate / determinant): no indexed local array
+                double g00 = 1, g01 = 0, g02 = 0, g10 = 0, g11 = 1, g12 = 0, g20 = 0, g21 = 0, g22 = 1;
+                g00 = bib_weight(key, k, 0, 0, sz);
+                if (sz >= 2) {
+                    g01 = bib_weight(key, k, 0, 1, sz);
+                    g10 = bib_weight(key, k, 1, 0, sz);
+                    g11 = bib_weight(key, k, 1, 1, sz);
+                }
+                if (sz >= 3) {
+                    g02 = bib_weight(key, k, 0, 2, sz);
+                    g12 = bib_weight(key, k, 1, 2, sz);
+                    g20 = bib_weight(key, k, 2, 0, sz);
+                    g21 = bib_weight(key, k, 2, 1, sz);
+                    g22 = bib_weight(key, k, 2, 2, sz);
+                }
+                const double c00 = g11 * g22 - g12 * g21, c01 = g12 * g20 - g10 * g22, c02 = g10 * g21 - g11 * g20;
+                const double idet = 1.0 / (g00 * c00 + g01 * c01 + g02 * c02);
+                double* gi = ginv + (int64_t)k * 9;  // row-major 3 x 3; rows / columns >= sz belong to the identity padding, never read
+                gi[0] = c00 * idet;
+                gi[1] = (g02 * g21 - g01 * g22) * idet;
+                gi[2] = (g01 * g12 - g02 * g11) * idet;
+                gi[3] = c01 * idet;
+                gi[4] = (g00 * g22 - g02 * g20) * idet;
+                gi[5] = (g02 * g10 - g00 * g12) * idet;
+                gi[6] = c02 * idet;
+                gi[7] = (g01 * g20 - g00 * g21) * idet;
+                gi[8] = (g00 * g11 - g01 * g10) * idet;
+            }
+        }
+        __syncthreads();
+    }
+    if (r >= n) return;
+    double x[BIB_T] = {0, 0, 0, 0};
+    const double* q = Qrm + (int64_t)r * S1;
+    if (only >= 0) {
+        const int c0 = blk_col[only], sz = blk_size[only];
+        for (int j = 0; j < sz && j < BIB_T; ++j) x[j] = q[c0 + j];
+    } else {
+        for (int cc = 0; cc < S1; ++cc) {
+            const double v = q[cc];
+#pragma unroll
+            for (int t = 0; t < BIB_T; ++t) x[t] = fma(bib_w[cc * BIB_T + t], v, x[t]);
+        }
+    }
+    X0[r] = make_double2(x[0], x[1]);
+    X1[r] = make_double2(x[2], x[3]);
+}
+// grid (d, blocks to do); 256 threads = 4 columns x 64 row groups.  y[j][t] = q_kj' Y^(t)_i, B = Y G^-1, check, store.
+__global__ void __launch_bounds__(256)
+bib_contract_kernel(int n, int S1, int64_t S, const int32_t* __restrict__ blk_col, const int32_t* __restrict__ blk_size, const int64_t* __restrict__ blk_off,
+                    const double* __restrict__ Qrm, const double2* __restrict__ Y0, const double2* __restrict__ Y1, const double* __restrict__ ginv,
+                    uint64_t key, int only, double atol, double tol, double* __restrict__ out, uint32_t* __restrict__ flag) {
+    __shared__ double red[BIB_T][256];
+    __shared__ double ys[4][BIB_T];
+    const int i = blockIdx.x;
+    const int k = only >= 0 ? only : (int)blockIdx.y;
+    const int c0 = blk_col[k], sz = blk_size[k];
+    const int j = threadIdx.x & 3, g = threadIdx.x >> 2;
+    double a[BIB_T] = {0, 0, 0, 0};
+    if (j < sz) {
+        const double2* y0 = Y0 + (int64_t)i * n;
+        const double2* y1 = Y1 + (int64_t)i * n;
+        // eight rows per trip, their 24 loads in flight together (one row per trip was a dependent L2 round trip each: 50 us)
+        for (int r0 = g; r0 < n; r0 += 64 * 8) {
+            double q[8];
+            double2 u[8], w[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int r = r0 + 64 * x;
+                const int rc = r < n ? r : g;
+                q[x] = r < n ? Qrm[(int64_t)rc * S1 + c0 + j] : 0.0;
+                u[x] = y0[rc];
+                w[x] = y1[rc];
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                a[0] = fma(q[x], u[x].x, a[0]);
+                a[1] = fma(q[x], u[x].y, a[1]);
+                a[2] = fma(q[x], w[x].x, a[2]);
+                a[3] = fma(q[x], w[x].y, a[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < BIB_T; ++t) red[t][threadIdx.x] = a[t];
+    __syncthreads();
+    if (threadIdx.x < 16) {  // (column j, vector t): sum over the 64 row groups in a fixed order
+        const int jj = threadIdx.x & 3, t = threadIdx.x >> 2;
+        double v = 0;
+        for (int gg = 0; gg < 64; ++gg) v += red[t][gg * 4 + jj];
+        ys[jj][t] = v;
+    }
+    __syncthreads();
+    __shared__ double Bs[3][3];
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    if (threadIdx.x < 9) {
+        const int a2 = threadIdx.x / 3, b2 = threadIdx.x % 3;
+        double v = 0;
+        if (a2 < sz && b2 < sz) {
+            if (only >= 0) v = ys[a2][b2];  // Q_k'(1[P==i] q_kb): the projection formula
+            else
+                for (int t = 0; t < sz; ++t) v += ys[a2][t] * ginv[(int64_t)k * 9 + t * 3 + b2];  // B = Y G^-1
+        }
+        Bs[a2][b2] = v;
+    }
+    __syncthreads();
+    if (only < 0 && threadIdx.x < 12) {  // the check vectors t = sz .. 3: B g^(t) must reproduce column t of Y
+        const int a2 = threadIdx.x % 3, t = sz + threadIdx.x / 3;
+        if (a2 < sz && t < BIB_T) {
+            double v = 0;
+            for (int b2 = 0; b2 < sz; ++b2) v += Bs[a2][b2] * bib_weight(key, k, b2, t, sz);
+            if (!(fabs(v - ys[a2][t]) <= tol)) s_bad = 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_bad && atomicExch(&flag[1 + k], 1u) == 0u) atomicAdd(&flag[0], 1u);
+    if (threadIdx.x < 9) {
+        const int a2 = threadIdx.x / 3, b2 = threadIdx.x % 3;
+        if (a2 < sz && b2 < sz) {
+            const double v = 0.5 * (Bs[a2][b2] + Bs[b2][a2]);  // Q_k' 1[P==i] Q_k is symmetric
+            out[(int64_t)i * S + blk_off[k] + a2 + b2 * sz] = (fabs(v) < atol) ? 0.0 : v;
+        }
+    }
+}
+size_t basis_image_blocks_workspace_doubles(int64_t n, int64_t d) { return (size_t)4 * n * (d + 1) + 9 * 65536; }
+// Blocks up to 3 x 3.  ws: 4 n (d + 1) doubles.  only < 0: every block from four generic vectors, flag[0] = blocks whose
+// check failed, flag[1 + k] = 1 for those; only = k: block k alone by the projection formula (no check, flag untouched).
+// Returns false when the shape has no instance.
+bool launch_basis_image_blocks(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks, const int32_t* blk_col, const int32_t* blk_size,
+                               const int64_t* blk_off, const uint32_t* L, const double* Qrm, uint64_t key, int only, double atol, double tol, double* ws,
+                               double* out, uint32_t* flag) {
+    const int tstride = (int)((d + 1) | 1);
+    const size_t per_wave = (size_t)64 * tstride * sizeof(double2);
+    int W = 4;
+    while (W > 1 && per_wave * W > 150 * 1024) W >>= 1;
+    if (per_wave * W > 150 * 1024 || n < 1 || n > 0x7FFFFFFF / 2 || nblocks < 1 || nblocks > 65535) return false;
+    double2* X0 = reinterpret_cast<double2*>(ws);
+    double2* X1 = X0 + n;
+    double2* Y0 = X1 + n;
+    double2* Y1 = Y0 + (size_t)d * n;
+    double* ginv = reinterpret_cast<double*>(Y1 + (size_t)d * n);  // 9 doubles per block
+    if ((size_t)S1 * BIB_T * 8 > 48 * 1024) return false;
+    bib_vectors_kernel<<<(unsigned)((n + 255) / 256), 256, (size_t)S1 * BIB_T * 8, s>>>((int)n, (int)S1, nblocks, blk_col, blk_size, key, only, Qrm, X0, X1, only < 0 ? flag : nullptr, ginv);
+    int g = (int)((n + W - 1) / W);
+    if (g > 256) g = 256;
+    const size_t lds = per_wave * W;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double2* X = pass ? X1 : X0;
+        double2* Y = pass ? Y1 : Y0;
+        if (W == 4) class_sums2_kernel<4><<<g, 256, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+        else if (W == 2) class_sums2_kernel<2><<<g, 128, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+        else class_sums2_kernel<1><<<g, 64, lds, s>>>((int)n, (int)d, tstride, L, X, Y);
+    }
+    dim3 gc((unsigned)d, only >= 0 ? 1u : (unsigned)nblocks);
+    bib_contract_kernel<<<gc, 256, 0, s>>>((int)n, (int)S1, S, blk_col, blk_size, blk_off, Qrm, Y0, Y1, ginv, key, only, atol, tol, out, flag);
     return true;
 }
 

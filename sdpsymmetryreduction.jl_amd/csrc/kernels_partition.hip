@@ -1000,7 +1000,7 @@ size_t refine_block_entries() { return REFINE_BLOCK; }
 uint32_t refine_small_k() { return SMALL_K; }
 size_t refine_counters_bytes() { return (size_t)(LIST_OFF + SMALL_K) * sizeof(uint32_t); }
 
-__device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned long long* tab,
+__device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, RefSlot* tab,
                                                           uint32_t mask, uint32_t* counters) {
     // (the overflow flag is checked once per chunk by the caller: after an overflow the host
     // repeats the pass with a larger table, nobody should keep walking a full one)
@@ -1011,10 +1011,10 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, unsigned 
         // ~len/2 -- partitions without symmetry -- used to walk up to MAX_PROBES slots of the full table for every
         // remaining entry: 1.0 and 1.5 ms per failed attempt at len = 524 800, configs[1].)
         if ((probe & 7) == 7 && __builtin_nontemporal_load(&counters[1])) return NO_SLOT;
-        unsigned long long cur = tab[idx];  // slots are write-once: a stale read can only be 0
+        unsigned long long cur = tab[idx].sig;  // slots are write-once: a stale read can only be 0
         if (cur == sg) return idx;
         if (cur == 0ull) {
-            unsigned long long old = atomicCAS(&tab[idx], 0ull, (unsigned long long)sg);
+            unsigned long long old = atomicCAS(&tab[idx].sig, 0ull, (unsigned long long)sg);
             if (old == 0ull) {
                 uint32_t cnt = atomicAdd(&counters[0], 1u);
                 if (cnt < SMALL_K) counters[LIST_OFF + cnt] = idx;
@@ -1060,8 +1060,7 @@ constexpr int LDS_MAX_PROBES = 24;
 template <class SRC, int INSERT_PER_THREAD, int LDS_SLOTS, int THREADS = REFINE_THREADS>
 __global__ void __launch_bounds__(THREADS)
 refine_insert_kernel(int64_t len, const SRC src,
-                     uint32_t* __restrict__ slot_out, unsigned long long* __restrict__ tab_sig,
-                     uint32_t* __restrict__ tab_min, uint32_t mask, uint32_t* counters) {
+                     uint32_t* __restrict__ slot_out, RefSlot* __restrict__ tab, uint32_t mask, uint32_t* counters) {
     constexpr int INSERT_CHUNK = THREADS * INSERT_PER_THREAD;
     // The LDS table lives across the chunks of a workgroup: a signature is published to the
     // global table only the first time the workgroup meets it (its chunks come in increasing
@@ -1126,18 +1125,27 @@ refine_insert_kernel(int64_t len, const SRC src,
                     sb[q] = (e < len) ? src(e) : 0ull;
                 }
 #pragma unroll
-                for (int q = 0; q < BB; ++q) cur[q] = sb[q] ? tab_sig[(uint32_t)sb[q] & mask] : 0ull;
+                for (int q = 0; q < BB; ++q) {  // the home slot, signature and minimum in one 16-byte gather
+                    const uint4 rec = sb[q] ? *reinterpret_cast<const uint4*>(&tab[(uint32_t)sb[q] & mask]) : make_uint4(0u, 0u, 0u, 0u);
+                    cur[q] = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+                    mn[q] = rec.z;
+                }
 #pragma unroll
                 for (int q = 0; q < BB; ++q) {
                     outs[q] = NO_SLOT;
-                    if (sb[q]) outs[q] = (cur[q] == sb[q]) ? ((uint32_t)sb[q] & mask) : global_find_or_insert(sb[q], tab_sig, mask, counters);
+                    if (sb[q]) {
+                        if (cur[q] == sb[q]) {
+                            outs[q] = (uint32_t)sb[q] & mask;
+                        } else {
+                            outs[q] = global_find_or_insert(sb[q], tab, mask, counters);
+                            mn[q] = outs[q] != NO_SLOT ? tab[outs[q]].min : 0u;
+                        }
+                    }
                 }
-#pragma unroll
-                for (int q = 0; q < BB; ++q) mn[q] = outs[q] != NO_SLOT ? tab_min[outs[q]] : 0u;
 #pragma unroll
                 for (int q = 0; q < BB; ++q) {
                     const int64_t e = base + (q0 + q) * THREADS + threadIdx.x;
-                    if (outs[q] != NO_SLOT && mn[q] > (uint32_t)e) atomicMin(&tab_min[outs[q]], (uint32_t)e);
+                    if (outs[q] != NO_SLOT && mn[q] > (uint32_t)e) atomicMin(&tab[outs[q]].min, (uint32_t)e);
                     if (e < len) slot_out[e] = outs[q];
                 }
             }
@@ -1231,9 +1239,9 @@ refine_insert_kernel(int64_t len, const SRC src,
                     if (l_min[idx] > (uint32_t)e) atomicMin(&l_min[idx], (uint32_t)e);
                     myslot[q] = (int)idx;
                 } else {
-                    const uint32_t g = global_find_or_insert(sg, tab_sig, mask, counters);
+                    const uint32_t g = global_find_or_insert(sg, tab, mask, counters);
                     if (g != NO_SLOT) {
-                        if (tab_min[g] > (uint32_t)e) atomicMin(&tab_min[g], (uint32_t)e);
+                        if (tab[g].min > (uint32_t)e) atomicMin(&tab[g].min, (uint32_t)e);
                         myslot[q] = -2 - (int)g;
                     }
                 }
@@ -1247,12 +1255,12 @@ refine_insert_kernel(int64_t len, const SRC src,
         if (l_new) {
         for (int i = threadIdx.x; i < LDS_SLOTS; i += THREADS) {
             if (l_sig[i] != 0ull && l_gslot[i] == PENDING) {
-                const uint32_t g = global_find_or_insert(l_sig[i], tab_sig, mask, counters);
+                const uint32_t g = global_find_or_insert(l_sig[i], tab, mask, counters);
                 // tab_min only ever decreases, so a (possibly stale) plain read that is already
                 // <= our candidate proves the atomic cannot change anything: skip it.
                 if (g != NO_SLOT) {
                     const uint32_t mine = l_min[i];
-                    if (tab_min[g] > mine) atomicMin(&tab_min[g], mine);
+                    if (tab[g].min > mine) atomicMin(&tab[g].min, mine);
                 }
                 l_gslot[i] = g;
             }
@@ -1280,7 +1288,7 @@ refine_insert_kernel(int64_t len, const SRC src,
 // thread t of the block owns entries base + 4t .. 4t+3 (index order matters here)
 __device__ __forceinline__ int first_flags(int64_t len, int64_t base,
                                            const uint32_t* __restrict__ slot,
-                                           const uint32_t* __restrict__ tab_min, int* flags,
+                                           const RefSlot* __restrict__ tab, int* flags,
                                            uint32_t* slots) {
     int cnt = 0;
     const int64_t e0 = base + (int64_t)threadIdx.x * REFINE_PER_THREAD;
@@ -1290,7 +1298,7 @@ __device__ __forceinline__ int first_flags(int64_t len, int64_t base,
         uint32_t sl = (e < len) ? slot[e] : NO_SLOT;
         slots[q] = sl;
         int f = 0;
-        if (sl != NO_SLOT) f = (tab_min[sl] == (uint32_t)e);
+        if (sl != NO_SLOT) f = (tab[sl].min == (uint32_t)e);
         flags[q] = f;
         cnt += f;
     }
@@ -1299,7 +1307,7 @@ __device__ __forceinline__ int first_flags(int64_t len, int64_t base,
 
 __global__ void __launch_bounds__(REFINE_THREADS)
 refine_count_kernel(int64_t len, const uint32_t* __restrict__ slot,
-                    const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ blk_cnt,
+                    const RefSlot* __restrict__ tab, uint32_t* __restrict__ blk_cnt,
                     const uint32_t* __restrict__ counters) {
     __shared__ int sh[REFINE_THREADS / 64];
     if (counters[0] <= SMALL_K) return;  // ranked by refine_small_rank_kernel
@@ -1307,7 +1315,7 @@ refine_count_kernel(int64_t len, const uint32_t* __restrict__ slot,
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         int flags[REFINE_PER_THREAD];
         uint32_t slots[REFINE_PER_THREAD];
-        int cnt = first_flags(len, blk * REFINE_BLOCK, slot, tab_min, flags, slots);
+        int cnt = first_flags(len, blk * REFINE_BLOCK, slot, tab, flags, slots);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
@@ -1354,7 +1362,7 @@ refine_scan_kernel(int64_t nblk, uint32_t* __restrict__ blk_cnt, uint32_t* count
 
 __global__ void __launch_bounds__(REFINE_THREADS)
 refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
-                   const uint32_t* __restrict__ tab_min, const uint32_t* __restrict__ blk_off,
+                   const RefSlot* __restrict__ tab, const uint32_t* __restrict__ blk_off,
                    uint32_t* __restrict__ tab_lab, const uint32_t* __restrict__ counters, uint32_t* __restrict__ first_idx) {
     __shared__ int wsum[REFINE_THREADS / 64];
     if (counters[0] <= SMALL_K) return;
@@ -1363,7 +1371,7 @@ refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         int flags[REFINE_PER_THREAD];
         uint32_t slots[REFINE_PER_THREAD];
-        int cnt = first_flags(len, blk * REFINE_BLOCK, slot, tab_min, flags, slots);
+        int cnt = first_flags(len, blk * REFINE_BLOCK, slot, tab, flags, slots);
         int x = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -1389,7 +1397,7 @@ refine_rank_kernel(int64_t len, const uint32_t* __restrict__ slot,
 
 // <= SMALL_K classes: label of a class = 1 + number of classes with a smaller first index
 __global__ void __launch_bounds__(1024)
-refine_small_rank_kernel(const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ tab_lab,
+refine_small_rank_kernel(const RefSlot* __restrict__ tab, uint32_t* __restrict__ tab_lab,
                          uint32_t* __restrict__ counters, uint32_t* __restrict__ first_idx) {
     __shared__ uint32_t s_min[SMALL_K];
     const uint32_t K = counters[0];
@@ -1398,7 +1406,7 @@ refine_small_rank_kernel(const uint32_t* __restrict__ tab_min, uint32_t* __restr
     uint32_t slot = 0, mine = 0;
     if (i < K) {
         slot = counters[LIST_OFF + i];
-        mine = tab_min[slot];
+        mine = tab[slot].min;
         s_min[i] = mine;
     }
     __syncthreads();
@@ -1412,13 +1420,11 @@ refine_small_rank_kernel(const uint32_t* __restrict__ tab_min, uint32_t* __restr
 }
 
 // tab_sig = 0, tab_min = 0xFFFFFFFF, counters[0..16) = 0 in one launch
-__global__ void refine_clear_kernel(int64_t cap, unsigned long long* __restrict__ tab_sig,
-                                    uint32_t* __restrict__ tab_min, uint32_t* __restrict__ counters) {
+__global__ void refine_clear_kernel(int64_t cap, RefSlot* __restrict__ tab, uint32_t* __restrict__ counters) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = t0; i < cap; i += stride) {
-        tab_sig[i] = 0ull;
-        tab_min[i] = 0xFFFFFFFFu;
+        *reinterpret_cast<uint4*>(&tab[i]) = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
     }
     if (t0 < LIST_OFF) counters[t0] = 0u;
 }
@@ -1578,10 +1584,10 @@ static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SR
     // launch then finds those signatures by plain reads (slots are write-once) and minima it cannot lower.
     if (ws.log2cap <= 12 && nchunk > 4) {
         const int64_t first = (int64_t)REFINE_THREADS * PER;
-        refine_insert_kernel<SRC, PER, SLOTS><<<1, REFINE_THREADS, 0, s>>>(first < len ? first : len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
+        refine_insert_kernel<SRC, PER, SLOTS><<<1, REFINE_THREADS, 0, s>>>(first < len ? first : len, src, slot, ws.tab,
                                                                     (uint32_t)(cap - 1), ws.counters);
     }
-    refine_insert_kernel<SRC, PER, SLOTS><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, (unsigned long long*)ws.tab_sig, ws.tab_min,
+    refine_insert_kernel<SRC, PER, SLOTS><<<g, REFINE_THREADS, 0, s>>>(len, src, slot, ws.tab,
                                                                 (uint32_t)(cap - 1), ws.counters);
 #ifdef LK_TIMING
     if (dbg) {
@@ -1892,8 +1898,7 @@ void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint
 void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slot, uint32_t* labels_out,
                    const RefineWs& ws, int64_t sym_n) {
     const size_t cap = (size_t)1 << ws.log2cap;
-    refine_clear_kernel<<<grid_for((int64_t)cap, 256), 256, 0, s>>>((int64_t)cap, (unsigned long long*)ws.tab_sig,
-                                                                   ws.tab_min, ws.counters);
+    refine_clear_kernel<<<grid_for((int64_t)cap, 256), 256, 0, s>>>((int64_t)cap, ws.tab, ws.counters);
     const int64_t nblk = (len + REFINE_BLOCK - 1) / REFINE_BLOCK;
     // 116 VGPRs + 32 KiB of LDS: four workgroups are resident per CU; with few classes (LDS-level
     // work) launch exactly one round of resident workgroups -- a fifth per CU would run alone
@@ -1945,16 +1950,16 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
     // launches the one-workgroup ranking only; it checks counters[0] afterwards and repeats the
     // pass with expect_small = 0 on a misprediction (the three general kernels would exit at once
     // anyway, but three empty launches cost ~15 us of a ~150 us refinement)
-    refine_small_rank_kernel<<<1, 1024, 0, s>>>(ws.tab_min, ws.tab_lab, ws.counters, ws.first_idx);
+    refine_small_rank_kernel<<<1, 1024, 0, s>>>(ws.tab, ws.tab_lab, ws.counters, ws.first_idx);
     if (!ws.expect_small) {
         // more than SMALL_K classes: ranked from the table's side (kernels_refine_bucket.hip: one bit per first index, rank
         // records per 64 entries) -- work on the classes and on len / 64 words.  The entry-level count / scan / rank passes
         // stay for callers without that workspace.
-        if (!(ws.rank_ws && launch_rank_slots(s, len, (int64_t)cap, ws.tab_sig, ws.tab_min, ws.tab_lab, ws.counters, SMALL_K, ws.first_idx,
+        if (!(ws.rank_ws && launch_rank_slots(s, len, (int64_t)cap, ws.tab, ws.tab_lab, ws.counters, SMALL_K, ws.first_idx,
                                               REFINE_FIRST_CAP, ws.rank_ws, ws.rank_ws_bytes))) {
-            refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt, ws.counters);
+            refine_count_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab, ws.blk_cnt, ws.counters);
             refine_scan_kernel<<<1, 1024, 0, s>>>(nblk, ws.blk_cnt, ws.counters);
-            refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab_min, ws.blk_cnt,
+            refine_rank_kernel<<<g2, REFINE_THREADS, 0, s>>>(len, slot, ws.tab, ws.blk_cnt,
                                                              ws.tab_lab, ws.counters, ws.first_idx);
         }
     }

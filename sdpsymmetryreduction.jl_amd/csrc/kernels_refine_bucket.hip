@@ -1022,13 +1022,13 @@ bk_label_kernel(int64_t len, const uint32_t* __restrict__ first, uint32_t* __res
 // entry's slot and gathered its minimum twice (140 us at 16.7 M entries).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-rs_mark_kernel(int64_t cap, const unsigned long long* __restrict__ tab_sig, const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ bitmap,
+rs_mark_kernel(int64_t cap, const RefSlot* __restrict__ tab, uint32_t* __restrict__ bitmap,
                const uint32_t* __restrict__ counters, uint32_t small_k) {
     if (counters[0] <= small_k || counters[1]) return;  // ranked by the one-workgroup kernel / a pass the host repeats
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t sl = (int64_t)blockIdx.x * 256 + threadIdx.x; sl < cap; sl += stride)
-        if (tab_sig[sl]) {
-            const uint32_t m = tab_min[sl];
+        if (tab[sl].sig) {
+            const uint32_t m = tab[sl].min;
             atomicOr(&bitmap[m >> 5], 1u << (m & 31u));
         }
 }
@@ -1056,15 +1056,15 @@ rs_words_kernel(int64_t nwords, const unsigned long long* __restrict__ bitmap, B
     if (threadIdx.x == 63) blk_cnt[blockIdx.x] = incl;
 }
 __global__ void __launch_bounds__(256)
-rs_assign_kernel(int64_t cap, const unsigned long long* __restrict__ tab_sig, const uint32_t* __restrict__ tab_min, uint32_t* __restrict__ tab_lab,
+rs_assign_kernel(int64_t cap, const RefSlot* __restrict__ tab, uint32_t* __restrict__ tab_lab,
                  const BkRank* __restrict__ rk, const uint32_t* __restrict__ total, uint32_t* __restrict__ counters, uint32_t small_k,
                  uint32_t* __restrict__ first_idx, uint32_t first_cap) {
     if (counters[0] <= small_k || counters[1]) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[2] = total[0];
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t sl = (int64_t)blockIdx.x * 256 + threadIdx.x; sl < cap; sl += stride)
-        if (tab_sig[sl]) {
-            const uint32_t m = tab_min[sl];
+        if (tab[sl].sig) {
+            const uint32_t m = tab[sl].min;
             const uint32_t lab = bk_rank_of(m, rk) + 1u;
             tab_lab[sl] = lab;
             if (first_idx && lab <= first_cap) first_idx[lab - 1] = m;
@@ -1076,7 +1076,7 @@ size_t refine_rank_slots_workspace_bytes(int64_t len) {
 }
 // tab_lab[slot] = canonical label of the slot's class, counters[2] = number of classes, first_idx as in the other passes.
 // Every kernel returns at once when the one-workgroup ranking (<= small_k classes) has done the job or the table overflowed.
-bool launch_rank_slots(hipStream_t s, int64_t len, int64_t cap, const uint64_t* tab_sig, const uint32_t* tab_min, uint32_t* tab_lab,
+bool launch_rank_slots(hipStream_t s, int64_t len, int64_t cap, const RefSlot* tab, uint32_t* tab_lab,
                        uint32_t* counters, uint32_t small_k, uint32_t* first_idx, uint32_t first_cap, void* ws, size_t ws_bytes) {
     if (ws_bytes < refine_rank_slots_workspace_bytes(len) || len >= (int64_t(1) << 32)) return false;
     const int64_t nw = (len + 63) / 64, nb = (nw + 63) / 64;
@@ -1091,11 +1091,11 @@ bool launch_rank_slots(hipStream_t s, int64_t len, int64_t cap, const uint64_t* 
     uint32_t* total = (uint32_t*)p;
     if (hipMemsetAsync(bitmap, 0, (size_t)nw * 8, s) != hipSuccess) return false;
     const unsigned gs = (unsigned)std::min<int64_t>((cap + 255) / 256, 2048);
-    rs_mark_kernel<<<gs, 256, 0, s>>>(cap, (const unsigned long long*)tab_sig, tab_min, (uint32_t*)bitmap, counters, small_k);
+    rs_mark_kernel<<<gs, 256, 0, s>>>(cap, tab, (uint32_t*)bitmap, counters, small_k);
     rs_words_kernel<<<(unsigned)nb, 64, 0, s>>>(nw, bitmap, rk, blk_cnt, counters, small_k);
     bk_scan_kernel<<<1, 1024, 0, s>>>(nb, blk_cnt, total);
     bk_rank_finish_kernel<<<(unsigned)((nb * 64 + 255) / 256), 256, 0, s>>>(nw, blk_cnt, rk);
-    rs_assign_kernel<<<gs, 256, 0, s>>>(cap, (const unsigned long long*)tab_sig, tab_min, tab_lab, rk, total, counters, small_k, first_idx, first_cap);
+    rs_assign_kernel<<<gs, 256, 0, s>>>(cap, tab, tab_lab, rk, total, counters, small_k, first_idx, first_cap);
     return true;
 }
 

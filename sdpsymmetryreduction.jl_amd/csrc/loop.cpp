@@ -166,8 +166,8 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
             // refinement (entries of a class with different U_k get different projected values); it is CHECKED, once per
             // iteration until it holds, on the labels the last refinement made, and from then on the iteration is the
             // square alone: no dot-product pass over U, signatures from the channel values only.
-            if (!proj_dead && it >= 2 && r >= 1 && jl && c->first_idx_labels == Lp && current >= 1 && current <= (int64_t)refine_first_cap() &&
-                !(c->opts.flags & SDPSR_FLAG_ALWAYS_PROJECT)) {
+            if (!proj_dead && it >= 2 && it <= 4 && r >= 1 && jl && c->first_idx_labels == Lp && current >= 1 && current <= (int64_t)refine_first_cap() &&
+                !(c->opts.flags & SDPSR_FLAG_ALWAYS_PROJECT)) {  // (at most three attempts: a basis that is never class-constant must not pay the check in every iteration)
                 void* uref = ctx_buf(c, "adm_uref", uconst_ref_bytes(current, r));
                 const uint32_t* first = (const uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
                 uint32_t* hv = (uint32_t*)ctx_pinned(c, 1024);

@@ -100,13 +100,12 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         }
         const size_t cap = size_t(1) << log2cap;
         RefineWs ws;
-        ws.tab_sig = (uint64_t*)ctx_buf(c, "ref_tab_sig", cap * 8);
-        ws.tab_min = (uint32_t*)ctx_buf(c, "ref_tab_min", cap * 4);
+        ws.tab = (RefSlot*)ctx_buf(c, "ref_tab", cap * sizeof(RefSlot));
         ws.tab_lab = (uint32_t*)ctx_buf(c, "ref_tab_lab", cap * 4);
         ws.blk_cnt = (uint32_t*)ctx_buf(c, "ref_blk_cnt", (nblk + 1) * 4);
         ws.counters = (uint32_t*)ctx_buf(c, "ref_counters", refine_counters_bytes());
         ws.first_idx = (uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
-        if (!ws.tab_sig || !ws.tab_min || !ws.tab_lab || !ws.blk_cnt || !ws.counters || !ws.first_idx)
+        if (!ws.tab || !ws.tab_lab || !ws.blk_cnt || !ws.counters || !ws.first_idx)
             return SDPSR_OUT_OF_MEMORY;
         ws.log2cap = log2cap;
         if (log2cap > 12 || mispredicted || sampled) {  // (a table of 2^12 slots holds at most 3072 classes: mostly the one-workgroup ranking)

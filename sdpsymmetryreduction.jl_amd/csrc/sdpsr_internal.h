@@ -183,9 +183,15 @@ void launch_sig_f32(hipStream_t s, int64_t n, int64_t ld, int T, const uint32_t*
 
 // canonical relabel of signatures (hash table + first-occurrence ranking).
 // Workspace layout is owned by the caller (see refine_workspace_bytes).
+// slot of the refinement's global table: signature and first index side by side -- ONE 16-byte gather per look-up (a gather that
+// misses the L1 costs ~5 clocks per lane on this part: signature and minimum in separate arrays were two of them per entry)
+struct RefSlot {
+    unsigned long long sig;
+    uint32_t min;
+    uint32_t pad;
+};
 struct RefineWs {
-    uint64_t* tab_sig;   // cap
-    uint32_t* tab_min;   // cap
+    RefSlot* tab;        // cap
     uint32_t* tab_lab;   // cap
     uint32_t* blk_cnt;   // nblk + 1
     int insert_wgs_per_cu = 0;  // sdpsr_opts.insert_wgs_per_cu (0 = default)
@@ -240,7 +246,7 @@ bool refine_bucket_set_device_attributes();
 bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
                             uint32_t* counters, uint32_t* first_idx, uint32_t first_cap, uint32_t* host_counters = nullptr);
 size_t refine_rank_slots_workspace_bytes(int64_t len);
-bool launch_rank_slots(hipStream_t s, int64_t len, int64_t cap, const uint64_t* tab_sig, const uint32_t* tab_min, uint32_t* tab_lab,
+bool launch_rank_slots(hipStream_t s, int64_t len, int64_t cap, const RefSlot* tab, uint32_t* tab_lab,
                        uint32_t* counters, uint32_t small_k, uint32_t* first_idx, uint32_t first_cap, void* ws, size_t ws_bytes);
 // distinct-signature estimate of a signature array from <= 65536 sampled entries; host_out (pinned, 4 words): non-zero
 // entries sampled, distinct signatures among them, signatures seen once, seen twice.  Returns the sample size (0: failed)
@@ -411,6 +417,10 @@ void launch_basis_image_two_stage(hipStream_t s, int64_t n, int64_t d, int64_t S
                                   const uint32_t* L, const double* Qrm, double* T, const int32_t* colA,
                                   const int32_t* colB, double atol, double* out);
 size_t basis_image_commutative_workspace_doubles(int64_t n, int64_t d);
+size_t basis_image_blocks_workspace_doubles(int64_t n, int64_t d);
+bool launch_basis_image_blocks(hipStream_t s, int64_t n, int64_t d, int64_t S1, int64_t S, int nblocks, const int32_t* blk_col, const int32_t* blk_size,
+                               const int64_t* blk_off, const uint32_t* L, const double* Qrm, uint64_t key, int only, double atol, double tol, double* ws,
+                               double* out, uint32_t* flag);
 bool launch_basis_image_fix_pair(hipStream_t s, int64_t n, int64_t d, int64_t S1, const uint32_t* L, const double* Qrm, int k1, int k2,
                                  double atol, double* ws, double* out);
 bool launch_basis_image_commutative(hipStream_t s, int64_t n, int64_t d, int64_t S1, const uint32_t* L, const double* Qrm, uint64_t key,

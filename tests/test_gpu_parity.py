@@ -1003,6 +1003,18 @@ def test_bucketed_refine_small_and_ragged_sizes(pkg, oracle, n):
             assert P.nparts == R.nparts and np.array_equal(P.matrix, R.matrix), n
 
 
+def test_bucketed_refine_beyond_the_one_level_front_end(pkg, oracle):
+    """len > 22.7 M entries: the grouping keeps the two-level scatter + one-workgroup-per-bucket resolver of round 4 in front of the
+    round-5 back end (rank records, ballot label pass).  n = 4800 (23.04 M entries), ~len / 2 classes and a zero class."""
+    n = 4800
+    rng = np.random.default_rng(99)
+    M = rng.integers(0, n * n // 2, size=(n, n)).astype(np.float64)
+    with pkg.Context(seed=4, refine_path="bucket") as ctx:
+        P = pkg.Partition.from_matrix(M, ctx=ctx)
+    R = oracle.partition_from_values(M)
+    assert P.nparts == R.nparts and np.array_equal(P.matrix, R.matrix)
+
+
 def test_syev_alternating_orders_replay_their_graphs(pkg):
     """A caller that alternates between a few orders (the dense driver on problems of different size) must pay the
     construction of the tridiagonalisation's hipGraph once per order (twice where the ctx's grow-only buffers were still
