@@ -161,7 +161,9 @@ typedef struct sdpsr_opts {
     int32_t basis_image_kernel; /* 0 = by shape, 1 = two-stage (class sums per row), 2 = outer products per class,
                                    3 = sorted chunks with partial sums */
     int32_t refine_path;        /* 0 = by class count (hash tables; beyond 2^18 classes the bucketed grouping), 1 = hash tables
-                                   only, 2 = hipCUB radix-sort relabel forced (comparison), 3 = bucketed grouping forced */
+                                   only, 2 = hipCUB radix-sort relabel forced (comparison), 3 = bucketed grouping forced,
+                                   4 = as 0 without the one-workgroup-per-CU insert kernel of array sources (comparison), 6 = that kernel
+                                   without the workgroups that go first (comparison) */
     int32_t label_bits;         /* 0 = no emulation; 8 / 16 / 32: width of the reference's label type T in
                                    Partition{T} (admissible_subspace defaults to UInt16, src/partitions.jl:84):
                                    SDPSR_LABEL_OVERFLOW where the reference throws InexactError (see below) */

@@ -34,7 +34,7 @@ FLAG_SYTRD_PANELS = 1 << 12
 FLAG_COUPLING_ON_HOST = 1 << 13
 FLAG_SYTRD_ONE_LAUNCH = 1 << 14
 BASIS_IMAGE_KERNELS = {"auto": 0, "two_stage": 1, "outer": 2, "chunk": 3}
-REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2, "bucket": 3}
+REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2, "bucket": 3, "no_mid": 4, "mid_no_first": 6}
 
 STATUS = {
     0: "OK", 1: "INVALID_DECOMPOSITION_FIELD", 2: "NUMERICAL_INCONSISTENCY", 3: "DIMENSION_MISMATCH",
@@ -80,6 +80,15 @@ def load_library():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C sdpsymmetryreduction.jl_amd/csrc` "
             "(there is no CPU fallback for the HIP path)")
+    # One HIP runtime per process.  The library asks for `libamdhip64.so.7`; torch's wheels carry their own copy with that
+    # SONAME and load it under the file name `libamdhip64.so`.  torch first: the loader hands the library torch's copy (the
+    # SONAMEs match) and device pointers, streams and events are shared.  The library first: /opt/rocm's runtime is loaded,
+    # a later `import torch` loads its own copy beside it, and that second runtime finds no GPU ("No HIP GPUs are
+    # available", tools/gpu/torch_after_lib.py).  So torch, where installed, is imported before the library is opened.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     pi64, pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)

@@ -1016,7 +1016,13 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, RefSlot* 
         if (cur == 0ull) {
             unsigned long long old = atomicCAS(&tab[idx].sig, 0ull, (unsigned long long)sg);
             if (old == 0ull) {
-                uint32_t cnt = atomicAdd(&counters[0], 1u);
+                // one atomic per wave for the lanes that are here together (a workgroup that meets thousands of new signatures
+                // in one chunk: 3000 adds to one address are ~30 us at the L2)
+                const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+                const uint32_t lane = __lane_id();
+                uint32_t cnt = 0;
+                if (lane == (uint32_t)(__ffsll((long long)act) - 1)) cnt = atomicAdd(&counters[0], (uint32_t)__popcll(act));
+                cnt = __builtin_amdgcn_readfirstlane(cnt) + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
                 if (cnt < SMALL_K) counters[LIST_OFF + cnt] = idx;
                 if (cnt + 1 > (mask >> 1) + (mask >> 2)) counters[1] = 1u;  // > 75% full
                 return idx;
@@ -1282,6 +1288,204 @@ refine_insert_kernel(int64_t len, const SRC src,
         bypass = need_clear;
         __syncthreads();
         RI_STAMP(6);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The insert pass for the MID regime: ~500 .. 5000 classes.  There the 2048-slot LDS table of the kernel above
+// thrashes and every entry becomes a 16-byte gather from the L2-resident global table: one L1 miss per lane, ~5-9 clocks
+// per entry and CU, 270-300 us for 16.7 M entries (round 5, profiles/r05_refine_warm_3000_classes_kernel_stats.csv).
+// Here ONE workgroup per CU keeps every signature it has met in 128 KB of LDS (MID_SLOTS x {8-byte signature, 4-byte
+// word, 4-byte minimum}); a lookup is two LDS reads issued together, eight entries at a time, and the waves run FREE:
+// no barrier after the table is cleared.
+// The lane whose compare-and-swap puts a signature into the LDS table publishes it: global find-or-insert, minimum, then
+// the slot's word = (ordinal of the workgroup's chunk << 20) | global slot.  An entry that finds the word still
+// pending goes to the global table itself; nobody waits for anybody.  The minimum: the workgroup's chunks come in
+// increasing index order, so an entry of chunk j cannot lower the minimum of a class published in an OLDER chunk (word
+// ordinal < j) and takes its slot at once -- the steady state.  Otherwise (same or newer chunk: the waves drift apart)
+// it lowers the slot's LDS minimum first and goes to the global minimum only if it did -- the LDS minimum only ever holds
+// indices whose owners do go there.  A table that fills up (probe sequences beyond MID_MAX_PROBES) sends the extra
+// signatures to the global table entry by entry.
+// Measured and not kept (3000 classes, N = 4096, stamps below): a barrier per chunk with the new signatures published from a
+// list (143 us against 133: every wave sits through every other wave's latencies); the work of a chunk ordered by kind --
+// all home slots, then each lane walking only ITS entries that need probing, then the global home slots of all entries
+// that need them in one batch -- with the entry picked by select chains (180 us: one lane in five is not in its home
+// slot and the probing step, 6-12 us of a chunk, is where the time goes either way).
+// ---------------------------------------------------------------------------
+constexpr int MID_THREADS = 1024;
+constexpr int MID_SLOTS = 8192;
+constexpr int MID_PER = 8;
+constexpr int MID_MAX_PROBES = 16;
+constexpr int MID_FIRST_WGS = 16;  // workgroups that go first, 1024 entries each
+constexpr uint32_t MID_PENDING = 0xFFFFFFFFu;
+constexpr size_t MID_LDS_BYTES = (size_t)MID_SLOTS * 16;
+constexpr int MID_MAX_LOG2CAP = 20;  // the word's low 20 bits; ordinals < 2^11 (len < 2^31, >= 1024-entry chunks, 256 workgroups)
+
+__device__ __forceinline__ uint32_t mid_direct(uint64_t sg, uint32_t e, RefSlot* tab, uint32_t mask, uint32_t* counters) {
+    const uint32_t g = global_find_or_insert(sg, tab, mask, counters);
+    if (g != NO_SLOT && tab[g].min > e) atomicMin(&tab[g].min, e);
+    return g;
+}
+
+#ifdef LK_TIMING
+#define MID_STAMP(i)                                                                                                        \
+    do {                                                                                                                     \
+        if (ri_dbg && (threadIdx.x == 0 || threadIdx.x == 512) && ord < 10 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) \
+            ri_dbg[(((blockIdx.x ? 1 : 0) * 2 + (threadIdx.x ? 1 : 0)) * 10 + ord) * 8 + (i)] = wall_clock64();                \
+    } while (0)
+#else
+#define MID_STAMP(i)
+#endif
+
+// PER: entries per thread and chunk (8; 1 for the few workgroups that go first over the first 8192 entries)
+template <class SRC, int PER>
+__global__ void __launch_bounds__(MID_THREADS)
+refine_insert_mid_kernel(int64_t len, const SRC src, uint32_t* __restrict__ slot_out, RefSlot* __restrict__ tab, uint32_t mask,
+                         uint32_t* counters, int preload) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long mid_dyn[];
+    unsigned long long* l_sig = mid_dyn;
+    uint32_t* l_word = reinterpret_cast<uint32_t*>(mid_dyn + MID_SLOTS);
+    uint32_t* l_min = l_word + MID_SLOTS;
+    __shared__ uint32_t l_full, l_stop;
+    constexpr int CHUNK = MID_THREADS * PER;
+    const int64_t nchunk = (len + CHUNK - 1) / CHUNK;
+    for (int i = threadIdx.x; i < MID_SLOTS; i += MID_THREADS) {
+        l_sig[i] = 0ull;
+        l_word[i] = MID_PENDING;
+        l_min[i] = 0xFFFFFFFFu;
+    }
+    if (threadIdx.x == 0) {
+        l_full = 0;
+        l_stop = 0;
+    }
+    __syncthreads();
+    uint32_t ord = 0;  // ordinal of this workgroup's chunk
+    if (preload) {
+        // The workgroups that went first (launch below) have published the classes of the first entries of the array, with
+        // their final minima: no later index can lower them.  Every workgroup of the full launch starts with those in its LDS
+        // table, as if met in a chunk before its first -- instead of meeting them one by one in its first chunk, eight steps of
+        // two or three dependent L2 round trips each (48 us of the 122 us this kernel took at 3000 classes).
+        for (uint32_t g = threadIdx.x; g <= mask; g += MID_THREADS) {
+            const uint4 rec = *reinterpret_cast<const uint4*>(&tab[g]);
+            const unsigned long long sg = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+            if (!sg) continue;
+            uint32_t idx = __umulhi((uint32_t)(sg >> 32), (uint32_t)MID_SLOTS);
+            for (int probes = 0; probes < MID_MAX_PROBES; ++probes) {
+                if (atomicCAS(&l_sig[idx], 0ull, sg) == 0ull) {  // (the global table holds a signature once)
+                    l_word[idx] = g;  // ordinal 0
+                    break;
+                }
+                idx = (idx + 1) & (MID_SLOTS - 1);
+            }
+        }
+        if (threadIdx.x == 0 && counters[1]) l_stop = 1u;  // the table was too small already for the first entries: the host repeats the pass
+        __syncthreads();
+        if (l_stop) return;
+        ord = 1;
+    }
+    // The signatures of the NEXT chunk are in flight while this one is looked up.  The loads are unconditional (index
+    // clamped): a load under a branch makes the number of outstanding loads unknown to the compiler, and every wait
+    // becomes a wait for all of them -- the prefetch included.
+    uint64_t nxt[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int64_t e = (int64_t)blockIdx.x * CHUNK + q * MID_THREADS + threadIdx.x;
+        nxt[q] = src(e < len ? e : len - 1);
+    }
+    for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x, ++ord) {
+        const int64_t base = blk * CHUNK;
+        uint64_t sgs[PER];
+        uint32_t home[PER];  // LDS slot: the home slot first, the slot found or taken after the probing step
+        unsigned long long cur[PER];
+        uint32_t word[PER];
+        MID_STAMP(0);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) sgs[q] = (base + q * MID_THREADS + threadIdx.x < len) ? nxt[q] : 0ull;
+        {
+            const int64_t nbase = (blk + gridDim.x) * CHUNK;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int64_t e = nbase + q * MID_THREADS + threadIdx.x;
+                nxt[q] = src(e < len ? e : len - 1);
+            }
+        }
+        // (the overflow flag: thread 0 reads it for the workgroup -- 4096 waves asking one address every chunk queue up there)
+        if (threadIdx.x == 0 && counters[1]) l_stop = 1u;
+        // the home slots of all entries, both words, before anything depends on them
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            home[q] = __umulhi((uint32_t)(sgs[q] >> 32), (uint32_t)MID_SLOTS);
+            cur[q] = l_sig[home[q]];
+            word[q] = l_word[home[q]];
+        }
+        const bool full = l_full != 0;
+        const bool overflow = l_stop != 0;
+#ifdef LK_TIMING
+        if (cur[0] == 1ull) continue;  // (never: the stamp below waits for the LDS reads)
+#endif
+        MID_STAMP(1);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int64_t e = base + q * MID_THREADS + threadIdx.x;
+            const uint64_t sg = sgs[q];
+            uint32_t out = NO_SLOT;
+            if (sg) {
+                if (cur[q] == sg && (word[q] >> 20) < ord) {  // published in an older chunk: the steady state (a pending word is all ones)
+                    out = word[q] & 0xFFFFFu;
+                } else {
+                    // probe (the table is insert-only, signatures are write-once)
+                    uint32_t idx = home[q];
+                    int placed = cur[q] == sg ? 1 : 0;  // 1: found, 2: inserted here
+                    if (!placed) {
+                        for (int probes = 0; probes < MID_MAX_PROBES; ++probes) {
+                            const unsigned long long c = l_sig[idx];
+                            if (c == sg) {
+                                placed = 1;
+                                break;
+                            }
+                            if (c == 0ull) {
+                                if (full) break;  // (no new signatures into a table whose probe sequences have got long)
+                                const unsigned long long old = atomicCAS(&l_sig[idx], 0ull, (unsigned long long)sg);
+                                if (old == 0ull) {
+                                    placed = 2;
+                                    break;
+                                }
+                                if (old == sg) {
+                                    placed = 1;
+                                    break;
+                                }
+                            }
+                            idx = (idx + 1) & (MID_SLOTS - 1);
+                        }
+                    }
+                    if (!placed) {
+                        if (!full) l_full = 1u;
+                        out = mid_direct(sg, (uint32_t)e, tab, mask, counters);
+                    } else {
+                        const uint32_t w = placed == 2 ? MID_PENDING : l_word[idx];
+                        if (w != MID_PENDING && (w >> 20) < ord) {
+                            out = w & 0xFFFFFu;
+                        } else {
+                            // same or newer chunk, or not published yet: this entry may hold the class's smallest index
+                            const bool lowers = l_min[idx] > (uint32_t)e && atomicMin(&l_min[idx], (uint32_t)e) > (uint32_t)e;
+                            if (w != MID_PENDING) {
+                                out = w & 0xFFFFFu;
+                                if (lowers && tab[out].min > (uint32_t)e) atomicMin(&tab[out].min, (uint32_t)e);
+                            } else {
+                                out = global_find_or_insert(sg, tab, mask, counters);
+                                if (out != NO_SLOT) {
+                                    if (lowers && tab[out].min > (uint32_t)e) atomicMin(&tab[out].min, (uint32_t)e);
+                                    if (placed == 2) l_word[idx] = (ord << 20) | out;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (e < len) slot_out[e] = out;
+        }
+        MID_STAMP(2);
+        if (overflow) return;  // the host repeats the pass with a larger table (each wave leaves on its own: no barriers in this loop)
     }
 }
 
@@ -1943,7 +2147,50 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
         }
         case SIG_CHAN_I32: launch_insert_chan<int32_t>(s, gcap, len, q, slot, ws, cap); break;
         case SIG_CHAN_F32: launch_insert_chan<float>(s, gcap, len, q, slot, ws, cap); break;
-        default: launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap); break;
+        default:
+            if (ws.mid) {
+                const int64_t nchunk = (len + MID_THREADS * MID_PER - 1) / (MID_THREADS * MID_PER);
+                // A few workgroups first, over the first 8192 entries (as in launch_insert, and for the same reason: 256 workgroups
+                // publishing the same few thousand signatures at the same moment are compare-and-swaps and minimum atomics on one
+                // address each; the first 16 384 entries hold all but a dozen of 3000 classes, with their smallest indices).  Sixteen
+                // workgroups with one entry per thread: one round of probing and publishing each.  The full launch preloads its LDS
+                // tables with what they published.
+                const bool first = nchunk > 4 && !(ws.mid & 2);
+                if (first)
+                    refine_insert_mid_kernel<SrcArray, 1><<<MID_FIRST_WGS, MID_THREADS, MID_LDS_BYTES, s>>>((int64_t)MID_THREADS * MID_FIRST_WGS, SrcArray{q.sig},
+                                                                                                        slot, ws.tab, (uint32_t)(cap - 1), ws.counters, 0);
+#ifdef LK_TIMING
+                long long* dbg = nullptr;
+                if (dbg_on()) {
+                    hipMalloc(&dbg, 4 * 10 * 8 * 8);
+                    hipMemset(dbg, 0, 4 * 10 * 8 * 8);
+                    hipStreamSynchronize(s);
+                    hipMemcpyToSymbol(HIP_SYMBOL(ri_dbg), &dbg, sizeof(dbg));
+                }
+#endif
+                refine_insert_mid_kernel<SrcArray, MID_PER><<<(unsigned)(nchunk < 256 ? nchunk : 256), MID_THREADS, MID_LDS_BYTES, s>>>(
+                    len, SrcArray{q.sig}, slot, ws.tab, (uint32_t)(cap - 1), ws.counters, first ? 1 : 0);
+#ifdef LK_TIMING
+                if (dbg) {
+                    hipStreamSynchronize(s);
+                    long long h[4 * 10 * 8];
+                    hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+                    for (int w = 0; w < 4; ++w)
+                        for (int o = 0; o < 10; ++o) {
+                            const long long* t = &h[(w * 10 + o) * 8];
+                            if (!t[0]) continue;
+                            fprintf(stderr, "[mid timing] wg=%d wave=%d chunk=%d: start %8.2f us, home slots read +%6.2f, chunk done +%6.2f\n", w / 2, (w % 2) * 8, o,
+                                    (t[0] - h[0]) * 0.01, (t[1] - t[0]) * 0.01, (t[2] - t[0]) * 0.01);
+                        }
+                    long long* z = nullptr;
+                    hipMemcpyToSymbol(HIP_SYMBOL(ri_dbg), &z, sizeof(z));
+                    hipFree(dbg);
+                }
+#endif
+            } else {
+                launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap);
+            }
+            break;
     }
     const int g2 = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
     // ws.expect_small: the host predicts <= SMALL_K classes (from the previous refinement) and
@@ -2193,6 +2440,10 @@ bool partition_set_device_attributes() {
     bool ok = true;
     ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SrcArray, MID_PER>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SrcArray, 1>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
     return ok;
 }
 

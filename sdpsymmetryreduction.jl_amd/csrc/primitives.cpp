@@ -98,7 +98,14 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
             if (!cub && h[2] <= refine_first_cap()) c->first_idx_labels = labels;  // "ref_first" describes these labels
             return SDPSR_OK;
         }
-        const size_t cap = size_t(1) << log2cap;
+        // Up to ~5000 classes from an array: one workgroup per CU with every signature in LDS (refine_insert_mid_kernel; built for
+        // the regime of 500 .. 5000 classes, it also beats the 2048-slot workgroup tables below that: 0.096 against 0.135 ms at 34
+        // classes, N = 4096).  The global table then sees each signature once per workgroup, not once per entry: a quarter of
+        // the slots do (half full at most), and the label pass gathers from 32 KB of labels instead of 128 KB.
+        // (refine_path 4 / 6: never / without the workgroups that go first)
+        const bool mid = src.kind == SIG_ARRAY && log2cap <= 16 && len >= (int64_t(1) << 20) && c->opts.refine_path != 4;
+        const int tab_log2 = (mid && !mispredicted && !sampled && log2cap >= 14) ? log2cap - 2 : log2cap;
+        const size_t cap = size_t(1) << tab_log2;
         RefineWs ws;
         ws.tab = (RefSlot*)ctx_buf(c, "ref_tab", cap * sizeof(RefSlot));
         ws.tab_lab = (uint32_t*)ctx_buf(c, "ref_tab_lab", cap * 4);
@@ -107,12 +114,13 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         ws.first_idx = (uint32_t*)ctx_buf(c, "ref_first", (size_t)refine_first_cap() * 4);
         if (!ws.tab || !ws.tab_lab || !ws.blk_cnt || !ws.counters || !ws.first_idx)
             return SDPSR_OUT_OF_MEMORY;
-        ws.log2cap = log2cap;
+        ws.log2cap = tab_log2;
         if (log2cap > 12 || mispredicted || sampled) {  // (a table of 2^12 slots holds at most 3072 classes: mostly the one-workgroup ranking)
             ws.rank_ws_bytes = refine_rank_slots_workspace_bytes(len);
             ws.rank_ws = ctx_buf(c, "ref_rank_ws", ws.rank_ws_bytes);
             if (!ws.rank_ws) return SDPSR_OUT_OF_MEMORY;
         }
+        ws.mid = mid ? (c->opts.refine_path == 6 ? 3 : 1) : 0;
         ws.insert_wgs_per_cu = c->opts.insert_wgs_per_cu;
         ws.nblk = (int)nblk;
         // hint 12 <=> last dim <= 512; a table grown after an overflow in this call holds more than 0.75 * 2^12 classes
@@ -133,6 +141,8 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         HIP_TRY(c, hipGetLastError());
         if (!h[1] && ws.expect_small && h[0] > refine_small_k()) {  // more classes than predicted: general ranking
             mispredicted = true;
+            // the count is exact now: the size the hint would have asked for (a 2^12 table three quarters full probes long chains)
+            log2cap = std::min(full, std::max(log2cap, ceil_log2((uint64_t)h[0] * 8 + 1)));
             continue;
         }
         if (h[1]) {  // table too small for this many classes

@@ -196,6 +196,7 @@ struct RefineWs {
     uint32_t* blk_cnt;   // nblk + 1
     int insert_wgs_per_cu = 0;  // sdpsr_opts.insert_wgs_per_cu (0 = default)
     uint32_t* host_counters = nullptr;  // pinned host memory: counters[0..2] are also stored there by the label pass (plain label pass only)
+    int mid = 0;           // array source, ~1000 .. 6000 classes predicted: the one-workgroup-per-CU LDS table (refine_insert_mid_kernel)
     int expect_small = 0;  // host prediction: <= refine_small_k() classes (see launch_refine)
     uint32_t* first_idx = nullptr;  // optional: first-occurrence index of class l at [l - 1], l <= refine_first_cap()
     void* rank_ws = nullptr;        // refine_rank_slots_workspace_bytes(len): the ranking of more than refine_small_k() classes

@@ -1,5 +1,6 @@
 """Wall times of the BASELINE.json configs on the GPU (device-resident labels where possible)."""
 import sys, os, time, numpy as np
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 pkg = load_package(); pr = pkg.problems
@@ -25,7 +26,7 @@ with pkg.Context(seed=1, flags=int(os.environ.get("SDPSR_TOOL_FLAGS", "0"))) as 
     timeit(lambda: pkg.eigen_decomposition(P, atol=1.5e-8, ctx=ctx), reps=1)
     del os.environ["SDPSR_DEBUG"]
     # G(2048, 1/2) and G(4096, 1/2): the sizes where the relabel path of a fresh call matters (device-resident inputs and labels)
-    import torch, ctypes as C
+    import ctypes as C
     for ng in (2048, 4096):
         Cg, Ag, bg = pr.theta_prime_problem(pr.gnp_adjacency(ng, 0.5, seed=7))
         sg = pkg.admissible_setup(Cg, Ag, bg)
