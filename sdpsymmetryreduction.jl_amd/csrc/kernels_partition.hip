@@ -1016,13 +1016,10 @@ __device__ __forceinline__ uint32_t global_find_or_insert(uint64_t sg, RefSlot* 
         if (cur == 0ull) {
             unsigned long long old = atomicCAS(&tab[idx].sig, 0ull, (unsigned long long)sg);
             if (old == 0ull) {
-                // one atomic per wave for the lanes that are here together (a workgroup that meets thousands of new signatures
-                // in one chunk: 3000 adds to one address are ~30 us at the L2)
-                const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-                const uint32_t lane = __lane_id();
-                uint32_t cnt = 0;
-                if (lane == (uint32_t)(__ffsll((long long)act) - 1)) cnt = atomicAdd(&counters[0], (uint32_t)__popcll(act));
-                cnt = __builtin_amdgcn_readfirstlane(cnt) + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+                // (one atomic per wave for the lanes that are here together -- ballot, leader, prefix count -- measured: no gain where it
+                // could matter, the first workgroups of the one-workgroup-per-CU kernel, and four more registers in every insert kernel:
+                // SrcChan<int, 2> went from 5 to 4 resident workgroups per CU, 65 -> 81 us per refinement)
+                const uint32_t cnt = atomicAdd(&counters[0], 1u);
                 if (cnt < SMALL_K) counters[LIST_OFF + cnt] = idx;
                 if (cnt + 1 > (mask >> 1) + (mask >> 2)) counters[1] = 1u;  // > 75% full
                 return idx;
@@ -1327,6 +1324,50 @@ __device__ __forceinline__ uint32_t mid_direct(uint64_t sg, uint32_t e, RefSlot*
     return g;
 }
 
+// What a thread holds of an entry between its loads and its signature: the signature itself (array source) or the raw
+// operands of a computed source (SRC::Raw -- the loads of the next chunk stay in flight as raw words, the hash runs when
+// the chunk's turn comes).
+template <class SRC> struct MidTraits {
+    using Raw = typename SRC::Raw;
+    static __device__ __forceinline__ uint64_t sig(const SRC& s, const Raw& r) { return s.sig(r); }
+};
+template <> struct MidTraits<SrcArray> {
+    using Raw = uint64_t;
+    static __device__ __forceinline__ uint64_t sig(const SrcArray&, const uint64_t& r) { return r; }
+};
+// the loads of the chunk at `base`, all unconditional (an entry beyond the end reads entry 0 and is masked later)
+template <class SRC, int PER>
+__device__ __forceinline__ void mid_fetch(const SRC& src, int64_t len, int64_t base, typename MidTraits<SRC>::Raw (&r)[PER]) {
+    if constexpr (!SRC::kIJ) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int64_t e = base + q * MID_THREADS + threadIdx.x;
+            r[q] = src(e < len ? e : len - 1);
+        }
+    } else {
+        const bool walk = src.walks();  // uniform
+        const int nn = src.order();
+        const bool low = src.lower();
+        uint32_t wi = 0, wj = 0;
+        if (walk) {
+            const int64_t e0 = base + threadIdx.x;
+            IjWalk::locate(nn, low, e0 < len ? e0 : len - 1, wi, wj);
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int64_t e = base + q * MID_THREADS + threadIdx.x;
+            const bool valid = e < len;
+            if (walk) {
+                r[q] = src.fetch(valid ? wi : 0u, valid ? wj : 0u, valid ? e : 0);
+                IjWalk::step(nn, low, wi, wj, MID_THREADS);
+            } else {
+                const int64_t ec = valid ? e : 0;
+                r[q] = src.fetch((uint32_t)ec, 0u, ec);  // (flat: entry e of every operand)
+            }
+        }
+    }
+}
+
 #ifdef LK_TIMING
 #define MID_STAMP(i)                                                                                                        \
     do {                                                                                                                     \
@@ -1386,12 +1427,11 @@ refine_insert_mid_kernel(int64_t len, const SRC src, uint32_t* __restrict__ slot
     // The signatures of the NEXT chunk are in flight while this one is looked up.  The loads are unconditional (index
     // clamped): a load under a branch makes the number of outstanding loads unknown to the compiler, and every wait
     // becomes a wait for all of them -- the prefetch included.
-    uint64_t nxt[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int64_t e = (int64_t)blockIdx.x * CHUNK + q * MID_THREADS + threadIdx.x;
-        nxt[q] = src(e < len ? e : len - 1);
-    }
+    // (A source whose raw entries of a chunk do not fit 64 registers loads them when the chunk's turn comes.)
+    using RawT = typename MidTraits<SRC>::Raw;
+    constexpr bool PF = sizeof(RawT) * PER <= 256;
+    RawT nxt[PER];
+    if constexpr (PF) mid_fetch<SRC, PER>(src, len, (int64_t)blockIdx.x * CHUNK, nxt);
     for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x, ++ord) {
         const int64_t base = blk * CHUNK;
         uint64_t sgs[PER];
@@ -1399,16 +1439,10 @@ refine_insert_mid_kernel(int64_t len, const SRC src, uint32_t* __restrict__ slot
         unsigned long long cur[PER];
         uint32_t word[PER];
         MID_STAMP(0);
+        if constexpr (!PF) mid_fetch<SRC, PER>(src, len, base, nxt);
 #pragma unroll
-        for (int q = 0; q < PER; ++q) sgs[q] = (base + q * MID_THREADS + threadIdx.x < len) ? nxt[q] : 0ull;
-        {
-            const int64_t nbase = (blk + gridDim.x) * CHUNK;
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                const int64_t e = nbase + q * MID_THREADS + threadIdx.x;
-                nxt[q] = src(e < len ? e : len - 1);
-            }
-        }
+        for (int q = 0; q < PER; ++q) sgs[q] = (base + q * MID_THREADS + threadIdx.x < len) ? MidTraits<SRC>::sig(src, nxt[q]) : 0ull;
+        if constexpr (PF) mid_fetch<SRC, PER>(src, len, (blk + gridDim.x) * CHUNK, nxt);
         // (the overflow flag: thread 0 reads it for the workgroup -- 4096 waves asking one address every chunk queue up there)
         if (threadIdx.x == 0 && counters[1]) l_stop = 1u;
         // the home slots of all entries, both words, before anything depends on them
@@ -1424,6 +1458,61 @@ refine_insert_mid_kernel(int64_t len, const SRC src, uint32_t* __restrict__ slot
         if (cur[0] == 1ull) continue;  // (never: the stamp below waits for the LDS reads)
 #endif
         MID_STAMP(1);
+        if constexpr (PER == 1) {
+            // The workgroups that go first: one chunk each (gridDim.x = nchunk), every signature new to the workgroup, and with
+            // few classes a thousand lanes meet the same one at the same moment.  Barrier-free, every lane that finds the word
+            // pending asks the global table itself: 16 384 lanes on a handful of addresses (99 us at 3 classes).  Here the lanes
+            // only leave their index in the slot's LDS minimum; after a barrier the lane that inserted the signature publishes
+            // it with that minimum; after another everybody reads the word.
+            const int64_t e = base + threadIdx.x;
+            const uint64_t sg = sgs[0];
+            uint32_t idx = home[0];
+            int placed = (sg && cur[0] == sg) ? 1 : 0;
+            if (sg && !placed) {
+                for (int probes = 0; probes < MID_MAX_PROBES; ++probes) {
+                    const unsigned long long c = l_sig[idx];
+                    if (c == sg) {
+                        placed = 1;
+                        break;
+                    }
+                    if (c == 0ull) {
+                        const unsigned long long old = atomicCAS(&l_sig[idx], 0ull, (unsigned long long)sg);
+                        if (old == 0ull) {
+                            placed = 2;
+                            break;
+                        }
+                        if (old == sg) {
+                            placed = 1;
+                            break;
+                        }
+                    }
+                    idx = (idx + 1) & (MID_SLOTS - 1);
+                }
+            }
+            if (placed && l_min[idx] > (uint32_t)e) atomicMin(&l_min[idx], (uint32_t)e);
+            __syncthreads();
+            uint32_t out = NO_SLOT;
+            if (placed == 2) {
+                out = global_find_or_insert(sg, tab, mask, counters);
+                if (out != NO_SLOT) {
+                    const uint32_t mine = l_min[idx];
+                    if (tab[out].min > mine) atomicMin(&tab[out].min, mine);
+                    l_word[idx] = (ord << 20) | out;
+                }
+            } else if (sg && !placed) {
+                out = mid_direct(sg, (uint32_t)e, tab, mask, counters);  // (a probe sequence beyond MID_MAX_PROBES)
+            }
+            __syncthreads();
+            if (placed == 1) {
+                const uint32_t w = l_word[idx];
+                out = w != MID_PENDING ? (w & 0xFFFFFu) : NO_SLOT;  // (pending still: the global table has overflowed)
+            }
+            if (e < len) slot_out[e] = out;
+            (void)full;
+            (void)word;
+            (void)overflow;
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int64_t e = base + q * MID_THREADS + threadIdx.x;
@@ -1762,12 +1851,75 @@ refine_label_sym_kernel(int64_t n, const uint32_t* slot, uint32_t* labels_out,
     if (sym_tile_pass<VEC4>(n, slot, labels_out, MapSlotLabel{tab_lab}, tile)) counters[3] = 1u;
 }
 
+// Which sources have the one-workgroup-per-CU kernel (each costs two more instantiations of a large kernel; the ones the
+// loop of admissible_subspace runs on the benchmark shapes and the array source)
+template <class SRC> struct MidSource { static constexpr bool value = false; };
+template <> struct MidSource<SrcArray> { static constexpr bool value = true; };
+template <> struct MidSource<SrcPair> { static constexpr bool value = true; };
+// (Measured and not kept: SrcChan<int32_t, 2> and SrcJoint<2, 2> -- 83 against 54 us and 102 against 71 us for the full launch
+// at N = 4104, theta_er7xk72.)
+
+template <class SRC>
+static bool mid_set_attributes() {
+    return hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SRC, MID_PER>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES) &&
+           hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SRC, 1>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
+}
+
+template <class SRC>
+static void launch_insert_mid(hipStream_t s, int64_t len, const SRC& src, uint32_t* slot, const RefineWs& ws, size_t cap) {
+    const int64_t nchunk = (len + MID_THREADS * MID_PER - 1) / (MID_THREADS * MID_PER);
+    // A few workgroups first, over the first entries (as in launch_insert, and for the same reason: 256 workgroups publishing
+    // the same signatures at the same moment are compare-and-swaps and minimum atomics on one address each; the first 16 384
+    // entries hold all but a dozen of 3000 classes, with their smallest indices).  Sixteen workgroups with one entry per
+    // thread: one round of probing and publishing each.  The full launch preloads its LDS tables with what they published.
+    const bool first = nchunk > 4 && !(ws.mid & 2);
+    if (first)
+        refine_insert_mid_kernel<SRC, 1><<<MID_FIRST_WGS, MID_THREADS, MID_LDS_BYTES, s>>>((int64_t)MID_THREADS * MID_FIRST_WGS, src, slot, ws.tab,
+                                                                                       (uint32_t)(cap - 1), ws.counters, 0);
+#ifdef LK_TIMING
+    long long* dbg = nullptr;
+    if (dbg_on()) {
+        hipMalloc(&dbg, 4 * 10 * 8 * 8);
+        hipMemset(dbg, 0, 4 * 10 * 8 * 8);
+        hipStreamSynchronize(s);
+        hipMemcpyToSymbol(HIP_SYMBOL(ri_dbg), &dbg, sizeof(dbg));
+    }
+#endif
+    refine_insert_mid_kernel<SRC, MID_PER><<<(unsigned)(nchunk < 256 ? nchunk : 256), MID_THREADS, MID_LDS_BYTES, s>>>(
+        len, src, slot, ws.tab, (uint32_t)(cap - 1), ws.counters, first ? 1 : 0);
+#ifdef LK_TIMING
+    if (dbg) {
+        hipStreamSynchronize(s);
+        long long h[4 * 10 * 8];
+        hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 4; ++w)
+            for (int o = 0; o < 10; ++o) {
+                const long long* t = &h[(w * 10 + o) * 8];
+                if (!t[0]) continue;
+                fprintf(stderr, "[mid timing] wg=%d wave=%d chunk=%d: start %8.2f us, home slots read +%6.2f, chunk done +%6.2f\n", w / 2, (w % 2) * 8, o,
+                        (t[0] - h[0]) * 0.01, (t[1] - t[0]) * 0.01, (t[2] - t[0]) * 0.01);
+            }
+        long long* z = nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(ri_dbg), &z, sizeof(z));
+        hipFree(dbg);
+    }
+#endif
+}
+
 // SLOTS: entries of the workgroup's LDS table (16 bytes each): 2048 -> four workgroups per CU,
 // 1024 -> up to eight (the computed sources are bound by their hash arithmetic and by the
 // barriers between the phases of a chunk: more resident workgroups overlap those phases)
 template <class SRC, int PER, int SLOTS = 1024>
 static void launch_insert(hipStream_t s, int g_chunks_cap, int64_t len, const SRC& src, uint32_t* slot, const RefineWs& ws,
                           size_t cap) {
+    if constexpr (MidSource<SRC>::value) {
+        if (ws.mid) {
+            launch_insert_mid<SRC>(s, len, src, slot, ws, cap);
+            return;
+        }
+    }
     const int64_t nchunk = (len + REFINE_THREADS * PER - 1) / (REFINE_THREADS * PER);
     // resident workgroups per CU, measured 2..8: 5 is the minimum of a flat curve (sdpsr_opts.insert_wgs_per_cu overrides)
     // (a fetch-first source holds its raw entries in registers: 126 of them, four workgroups per CU are resident)
@@ -2099,6 +2251,15 @@ void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint
     }
 }
 
+// does launch_refine run the one-workgroup-per-CU insert kernel for this source (RefineWs::mid)?
+bool refine_mid_supports(const SigSource& q) {
+    switch (q.kind) {
+        case SIG_ARRAY:
+        case SIG_PAIR: return true;
+        default: return false;
+    }
+}
+
 void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slot, uint32_t* labels_out,
                    const RefineWs& ws, int64_t sym_n) {
     const size_t cap = (size_t)1 << ws.log2cap;
@@ -2149,44 +2310,7 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
         case SIG_CHAN_F32: launch_insert_chan<float>(s, gcap, len, q, slot, ws, cap); break;
         default:
             if (ws.mid) {
-                const int64_t nchunk = (len + MID_THREADS * MID_PER - 1) / (MID_THREADS * MID_PER);
-                // A few workgroups first, over the first 8192 entries (as in launch_insert, and for the same reason: 256 workgroups
-                // publishing the same few thousand signatures at the same moment are compare-and-swaps and minimum atomics on one
-                // address each; the first 16 384 entries hold all but a dozen of 3000 classes, with their smallest indices).  Sixteen
-                // workgroups with one entry per thread: one round of probing and publishing each.  The full launch preloads its LDS
-                // tables with what they published.
-                const bool first = nchunk > 4 && !(ws.mid & 2);
-                if (first)
-                    refine_insert_mid_kernel<SrcArray, 1><<<MID_FIRST_WGS, MID_THREADS, MID_LDS_BYTES, s>>>((int64_t)MID_THREADS * MID_FIRST_WGS, SrcArray{q.sig},
-                                                                                                        slot, ws.tab, (uint32_t)(cap - 1), ws.counters, 0);
-#ifdef LK_TIMING
-                long long* dbg = nullptr;
-                if (dbg_on()) {
-                    hipMalloc(&dbg, 4 * 10 * 8 * 8);
-                    hipMemset(dbg, 0, 4 * 10 * 8 * 8);
-                    hipStreamSynchronize(s);
-                    hipMemcpyToSymbol(HIP_SYMBOL(ri_dbg), &dbg, sizeof(dbg));
-                }
-#endif
-                refine_insert_mid_kernel<SrcArray, MID_PER><<<(unsigned)(nchunk < 256 ? nchunk : 256), MID_THREADS, MID_LDS_BYTES, s>>>(
-                    len, SrcArray{q.sig}, slot, ws.tab, (uint32_t)(cap - 1), ws.counters, first ? 1 : 0);
-#ifdef LK_TIMING
-                if (dbg) {
-                    hipStreamSynchronize(s);
-                    long long h[4 * 10 * 8];
-                    hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-                    for (int w = 0; w < 4; ++w)
-                        for (int o = 0; o < 10; ++o) {
-                            const long long* t = &h[(w * 10 + o) * 8];
-                            if (!t[0]) continue;
-                            fprintf(stderr, "[mid timing] wg=%d wave=%d chunk=%d: start %8.2f us, home slots read +%6.2f, chunk done +%6.2f\n", w / 2, (w % 2) * 8, o,
-                                    (t[0] - h[0]) * 0.01, (t[1] - t[0]) * 0.01, (t[2] - t[0]) * 0.01);
-                        }
-                    long long* z = nullptr;
-                    hipMemcpyToSymbol(HIP_SYMBOL(ri_dbg), &z, sizeof(z));
-                    hipFree(dbg);
-                }
-#endif
+                launch_insert_mid<SrcArray>(s, len, SrcArray{q.sig}, slot, ws, cap);
             } else {
                 launch_insert<SrcArray, 16, 2048>(s, gcap, len, SrcArray{q.sig}, slot, ws, cap);
             }
@@ -2440,10 +2564,8 @@ bool partition_set_device_attributes() {
     bool ok = true;
     ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SrcArray, MID_PER>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
-    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SrcArray, 1>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
+    ok &= mid_set_attributes<SrcArray>();
+    ok &= mid_set_attributes<SrcPair>();
     return ok;
 }
 

@@ -98,12 +98,12 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
             if (!cub && h[2] <= refine_first_cap()) c->first_idx_labels = labels;  // "ref_first" describes these labels
             return SDPSR_OK;
         }
-        // Up to ~5000 classes from an array: one workgroup per CU with every signature in LDS (refine_insert_mid_kernel; built for
+        // Up to ~5000 classes (array source and the loop's computed sources): one workgroup per CU with every signature in LDS (refine_insert_mid_kernel; built for
         // the regime of 500 .. 5000 classes, it also beats the 2048-slot workgroup tables below that: 0.096 against 0.135 ms at 34
         // classes, N = 4096).  The global table then sees each signature once per workgroup, not once per entry: a quarter of
         // the slots do (half full at most), and the label pass gathers from 32 KB of labels instead of 128 KB.
         // (refine_path 4 / 6: never / without the workgroups that go first)
-        const bool mid = src.kind == SIG_ARRAY && log2cap <= 16 && len >= (int64_t(1) << 20) && c->opts.refine_path != 4;
+        const bool mid = refine_mid_supports(src) && log2cap <= 16 && len >= (int64_t(1) << 20) && c->opts.refine_path != 4;
         const int tab_log2 = (mid && !mispredicted && !sampled && log2cap >= 14) ? log2cap - 2 : log2cap;
         const size_t cap = size_t(1) << tab_log2;
         RefineWs ws;

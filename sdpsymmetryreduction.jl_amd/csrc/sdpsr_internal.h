@@ -238,6 +238,7 @@ bool launch_verify_no_split(hipStream_t s, const SigSource& q, int64_t d, const 
 void launch_sig_materialize(hipStream_t s, int64_t len, const SigSource& q, uint64_t* sig);
 // slot: len entries of scratch; labels_out may alias q.L (it is written only by a pass that succeeded)
 // sym_n > 0 (and len == sym_n^2): the label pass also checks the new labels for symmetry, counters[3] = 1 if NOT symmetric
+bool refine_mid_supports(const SigSource& q);  // RefineWs::mid is honoured for this source
 void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slot, uint32_t* labels_out,
                    const RefineWs& ws, int64_t sym_n = 0);
 
