@@ -94,11 +94,12 @@ PROFILE_ROUND = "r05"
 BENCH_N = 4096  # set from --n: the committed rocprofv3 summary looked up is the one of the order being run
 
 
-def rocprof_average_us(pattern):
+def rocprof_average_us(pattern, summary=None):
     """Average duration (us) of a kernel in this round's committed rocprofv3 --kernel-trace --stats
-    summary of the bench command AT THE ORDER BEING RUN (profiles/r05_bench_n<N>_kernel_stats.csv), or None."""
+    summary of the bench command AT THE ORDER BEING RUN (profiles/r05_bench_n<N>_kernel_stats.csv), or of another
+    committed summary of this round (`summary`: the part of the file name after the round), or None."""
     try:
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_bench_n{BENCH_N}_kernel_stats*.csv")))[-1]
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{summary}" if summary else f"{PROFILE_ROUND}_bench_n{BENCH_N}_kernel_stats*.csv")))[-1]
         for row in csv.DictReader(open(path)):
             if pattern in row["Name"]:
                 return round(float(row["AverageNs"]) / 1e3, 2)
@@ -765,7 +766,13 @@ def main():
             gbs = 16.0 * n * n / (ms * 1e-3) / 1e9
             kernels[f"refine_{cls}_classes"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                                 "bound": "hbm", "algorithmic_bytes": 16 * n * n,
-                                                "rocprof_avg_us": {"refine_insert_kernel": rocprof_average_us("refine_insert_kernel")} if cls == int(d) else None}
+                                                # the probe's own summary (tools/refine_probe.py warm under rocprofv3, N = 4096; the first / full launches of
+                                                # the one-workgroup-per-CU insert kernel share a row there)
+                                                "rocprof_avg_us": ({k: rocprof_average_us(k, f"refine_warm_{cls}_classes_kernel_stats.csv")
+                                                                    for k in (("b2_count_kernel", "b2_scatter_kernel", "b2_resolve_kernel", "bk_bits_kernel", "bk_label_kernel")
+                                                                              if cls == n * n // 2 else
+                                                                              ("refine_insert_mid_kernel<sdpsr::SrcArray, 1>", "refine_insert_mid_kernel<sdpsr::SrcArray, 8>", "refine_label_kernel"))}
+                                                                   if n == 4096 else None)}
         ms = prof(4, n, aux=max(r, 1), reps=5)  # gather+project+signature: (4 + 8r)*2 read + 8 write per entry
         gbs = ((4.0 + 8.0 * max(r, 1)) * 2 + 8.0) * n * n / (ms * 1e-3) / 1e9
         kernels["project_sig"] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "bound": "hbm"}

@@ -1860,11 +1860,13 @@ template <> struct MidSource<SrcPair> { static constexpr bool value = true; };
 // at N = 4104, theta_er7xk72.)
 
 template <class SRC>
-static bool mid_set_attributes() {
-    return hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SRC, MID_PER>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES) &&
-           hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SRC, 1>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
+bool mid_set_attributes_kind() {
+    bool ok = true;
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SRC, MID_PER>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
+    ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_insert_mid_kernel<SRC, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
+    return ok;
 }
 
 template <class SRC>
@@ -2564,8 +2566,8 @@ bool partition_set_device_attributes() {
     bool ok = true;
     ok &= hipSuccess == hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_columns_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    ok &= mid_set_attributes<SrcArray>();
-    ok &= mid_set_attributes<SrcPair>();
+    ok &= mid_set_attributes_kind<SrcArray>();
+    ok &= mid_set_attributes_kind<SrcPair>();
     return ok;
 }
 

@@ -990,6 +990,34 @@ def test_sort_based_refine_matches_oracle(pkg, oracle):
             assert P3.nparts == R.nparts and np.array_equal(P3.matrix, R.matrix), path
 
 
+def test_lds_table_insert_kernel_matches_oracle(pkg, oracle):
+    """refine_insert_mid_kernel (array sources of >= 2^20 entries, tables of <= 2^16 slots): one workgroup per CU with every
+    signature in LDS, preloaded from the workgroups that go first.  Canonical labels against the oracle at 3 ... 7000 classes
+    (7000: more than the 8192-slot LDS table takes -- the overflow goes to the global table entry by entry), with a zero class,
+    a class that first appears in the very last entry, classes absent from the first 16 384 entries (not preloaded) and a
+    ragged length; every input twice in one ctx (first call: the table size is a guess; second: predicted) and through the
+    comparison paths (no such kernel / no first workgroups)."""
+    rng = np.random.default_rng(55)
+    n = 1100  # 1.21 M entries, not a multiple of the 8192-entry chunk
+    cases = {}
+    for d in (3, 40, 600, 3000, 7000):
+        M = rng.integers(1, d + 1, size=(n, n)).astype(np.float64)
+        M[rng.random((n, n)) < 0.05] = 0.0
+        cases["d%d" % d] = M
+    late = rng.integers(1, 200, size=(n, n)).astype(np.float64)
+    late[:, :20] = rng.integers(1, 20, size=(n, 20))  # the first 22 000 entries (column-major) hold 19 of the classes
+    late[n - 1, n - 1] = 1e6                        # a class of one entry, the last
+    cases["late"] = late
+    refs = {k: oracle.partition_from_values(M) for k, M in cases.items()}
+    for path in ("auto", "no_mid", "mid_no_first"):
+        with pkg.Context(seed=6, refine_path=path) as ctx:
+            for name in ("d3000", "d3", "d7000", "d40", "late", "d600"):  # class counts up and down: the prediction is wrong every time ...
+                for rep in range(2):                                      # ... and right the second time
+                    P = pkg.Partition.from_matrix(cases[name], ctx=ctx)
+                    assert P.nparts == refs[name].nparts, (name, path, rep)
+                    assert np.array_equal(P.matrix, refs[name].matrix), (name, path, rep)
+
+
 @pytest.mark.parametrize("n", [37, 300, 1500])
 def test_bucketed_refine_small_and_ragged_sizes(pkg, oracle, n):
     """The bucketed grouping forced at sizes below its regime (one chunk, 16 buckets) and at a ragged size whose last

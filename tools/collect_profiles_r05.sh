@@ -23,7 +23,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = stats ]; then
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = refine ]; then
   python3 tools/refine_probe.py both 4096 34 3000 30000 262144 1000000 8388608 > $O/refine_probes.txt 2>&1
-  for T in "cold 8388608" "warm 8388608" "warm 3000" "warm 262144"; do
+  for T in "cold 8388608" "warm 8388608" "warm 3000" "warm 262144" "warm 34"; do
     set -- $T
     rm -rf /tmp/rp_$1_$2
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$1_$2 -o out -- python3 tools/refine_probe.py $1 4096 $2 > $O/refine_$1_$2.log 2>&1

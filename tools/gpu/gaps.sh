@@ -12,8 +12,8 @@ for f in mc:
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "memcpy " + r.get("Direction", "")))
 rows.sort()
-# the last complete reduction: from the last but one 'refine_insert_kernel<sdpsr::SrcPair' to the last one
-starts = [i for i, r in enumerate(rows) if "SrcPair" in r[2]]
+# the last complete reduction: from one first launch of the pair-source insert to the next
+starts = [i for i, r in enumerate(rows) if "SrcPair, 1>" in r[2]]  # the first launch of a reduction's first refinement
 a, b = starts[-3], starts[-2]
 seg = rows[a:b]
 t0 = seg[0][0]
