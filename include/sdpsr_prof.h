@@ -44,6 +44,10 @@ int sdpsr_profile_host_waits(sdpsr_ctx* ctx, uint64_t* out);
    hand-offs through progress words), built to be measured: A_host n x n dense symmetric with bandwidth b (16, 32 or 64),
    d_host (n), e_host (n - 1) the tridiagonal result, out[0] = kernel milliseconds, out[1] = 1 if the chase gave up. */
 int sdpsr_profile_band_chase(sdpsr_ctx* ctx, int64_t n, int b, const double* A_host, double* d_host, double* e_host, double* out);
+/* Stage 1 of the two-stage form, measured with library kernels (rocSOLVER panel QR + rocBLAS level-3 updates): dense
+   symmetric A (n x n, column-major, host, n a multiple of b) -> band of width b, in place (lower triangle);
+   out[0] = ms of the stage (second of two runs), out[1] = ms of its panel factorisations. */
+int sdpsr_profile_band_reduce(sdpsr_ctx* ctx, int64_t n, int b, double* A_host, double* out);
 /* What the hipGraph cache of the tridiagonalisation (one graph per problem shape and buffer set, kept in ctx) has done
    so far: out[0] = replays of a cached graph, out[1] = misses (a graph of ~2 n nodes built and instantiated on the
    host), out[2] = milliseconds spent building.  A caller that alternates between a few orders pays the build once per

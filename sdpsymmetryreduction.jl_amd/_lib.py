@@ -173,6 +173,8 @@ def load_prof_library():
         fn.argtypes = [vp, C.c_int, i64, i64, C.c_int, C.POINTER(C.c_double)]
     lib.sdpsr_profile_band_chase.restype = C.c_int
     lib.sdpsr_profile_band_chase.argtypes = [vp, i64, C.c_int, vp, vp, vp, C.POINTER(C.c_double)]
+    lib.sdpsr_profile_band_reduce.restype = C.c_int
+    lib.sdpsr_profile_band_reduce.argtypes = [vp, i64, C.c_int, vp, C.POINTER(C.c_double)]
     lib.sdpsr_profile_host_waits.restype = C.c_int
     lib.sdpsr_profile_host_waits.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.sdpsr_profile_sytrd_graphs.restype = C.c_int

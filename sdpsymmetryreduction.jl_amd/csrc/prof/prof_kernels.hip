@@ -53,6 +53,20 @@ void launch_fill_test_sig(hipStream_t s, int64_t len, int64_t nclasses, uint64_t
 
 
 
+// Stage 1 of the two-stage form (prof.cpp: sdpsr_profile_band_reduce): after the panel's QR, V = the reflectors with their
+// unit diagonal and zeros above written out (what the level-3 updates take), and the panel keeps only R.
+__global__ void band_panel_split_kernel(int64_t m, int b, double* __restrict__ P, int64_t ldp, double* __restrict__ V, int64_t ldv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= m || j >= b) return;
+    const double v = P[i + (int64_t)j * ldp];
+    V[i + (int64_t)j * ldv] = i > j ? v : (i == j ? 1.0 : 0.0);
+    if (i > j) P[i + (int64_t)j * ldp] = 0.0;
+}
+void launch_band_panel_split(hipStream_t s, int64_t m, int b, double* P, int64_t ldp, double* V, int64_t ldv) {
+    band_panel_split_kernel<<<dim3((unsigned)((m + 255) / 256), (unsigned)b), 256, 0, s>>>(m, b, P, ldp, V, ldv);
+}
+
 // ---------------------------------------------------------------------------
 // Stage 2 of a two-stage tridiagonalisation, built to be MEASURED ("costed, not built"): symmetric band
 // (bandwidth b) -> tridiagonal by Householder bulge chasing (Bischof / Lang / Sun's SBR scheme; LAPACK's dsytrd_sb2st runs

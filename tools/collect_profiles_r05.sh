@@ -40,5 +40,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = configs ]; then
   python3 tools/config_times.py > $O/config_times.txt 2>&1
   python3 tools/host_waits.py > $O/host_waits.txt 2>&1
   python3 tools/band_chase.py 1024 2048 4096 > $O/band_chase.txt 2>&1
+  python3 tools/band_reduce.py 1024 2048 4096 > $O/band_reduce.txt 2>&1
+  bash tools/gpu/pmc_round.sh > $O/pmc_round.txt 2>&1
 fi
 ls -la $O
