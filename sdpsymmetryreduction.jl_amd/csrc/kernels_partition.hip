@@ -1427,9 +1427,10 @@ refine_insert_mid_kernel(int64_t len, const SRC src, uint32_t* __restrict__ slot
     // The signatures of the NEXT chunk are in flight while this one is looked up.  The loads are unconditional (index
     // clamped): a load under a branch makes the number of outstanding loads unknown to the compiler, and every wait
     // becomes a wait for all of them -- the prefetch included.
-    // (A source whose raw entries of a chunk do not fit 64 registers loads them when the chunk's turn comes.)
+    // (A source whose raw entries of a chunk do not fit 32 registers loads them when the chunk's turn comes: the joint source's
+    // 56 prefetched registers made SrcJoint<2, 2> spill, 107 us per launch.)
     using RawT = typename MidTraits<SRC>::Raw;
-    constexpr bool PF = sizeof(RawT) * PER <= 256;
+    constexpr bool PF = sizeof(RawT) * PER <= 128;
     RawT nxt[PER];
     if constexpr (PF) mid_fetch<SRC, PER>(src, len, (int64_t)blockIdx.x * CHUNK, nxt);
     for (int64_t blk = blockIdx.x; blk < nchunk; blk += gridDim.x, ++ord) {
@@ -1458,6 +1459,7 @@ refine_insert_mid_kernel(int64_t len, const SRC src, uint32_t* __restrict__ slot
         if (cur[0] == 1ull) continue;  // (never: the stamp below waits for the LDS reads)
 #endif
         MID_STAMP(1);
+        uint32_t deferred = 0, lowered = 0;  // bit q: entry q waits for another lane to publish its signature / has lowered the slot's LDS minimum
         if constexpr (PER == 1) {
             // The workgroups that go first: one chunk each (gridDim.x = nchunk), every signature new to the workgroup, and with
             // few classes a thousand lanes meet the same one at the same moment.  Barrier-free, every lane that finds the word
@@ -1560,18 +1562,52 @@ refine_insert_mid_kernel(int64_t len, const SRC src, uint32_t* __restrict__ slot
                             if (w != MID_PENDING) {
                                 out = w & 0xFFFFFu;
                                 if (lowers && tab[out].min > (uint32_t)e) atomicMin(&tab[out].min, (uint32_t)e);
-                            } else {
+                            } else if (placed == 2) {
                                 out = global_find_or_insert(sg, tab, mask, counters);
                                 if (out != NO_SLOT) {
                                     if (lowers && tab[out].min > (uint32_t)e) atomicMin(&tab[out].min, (uint32_t)e);
-                                    if (placed == 2) l_word[idx] = (ord << 20) | out;
+                                    l_word[idx] = (ord << 20) | out;
                                 }
+                            } else {
+                                // Somebody else is publishing this signature right now.  Asking the global table too is what
+                                // every lane of a LARGE new class would do at the same moment (a class that is absent from the
+                                // entries the first workgroups saw -- ER(7) x K_72 is not vertex-transitive -- met by thousands of
+                                // lanes of every workgroup in its first chunk: 90 us instead of 45).  The entry waits its turn
+                                // after the chunk's other entries; the word is there by then.
+                                home[q] = idx;
+                                deferred |= 1u << q;
+                                if (lowers) lowered |= 1u << q;
+                                continue;
                             }
                         }
                     }
                 }
             }
             if (e < len) slot_out[e] = out;
+        }
+        for (int tries = 0; deferred && tries < 64; ++tries) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                if (!((deferred >> q) & 1u)) continue;
+                const uint32_t w = l_word[home[q]];
+                if (w == MID_PENDING) continue;
+                const uint32_t e = (uint32_t)(base + q * MID_THREADS + threadIdx.x);
+                const uint32_t out = w & 0xFFFFFu;
+                if (((lowered >> q) & 1u) && tab[out].min > e) atomicMin(&tab[out].min, e);
+                slot_out[e] = out;
+                deferred &= ~(1u << q);
+            }
+            if (deferred) __builtin_amdgcn_s_sleep(16);
+        }
+        if (deferred) {  // (the publisher got no slot: the global table has overflowed, the host repeats the pass)
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                if (!((deferred >> q) & 1u)) continue;
+                const uint32_t e = (uint32_t)(base + q * MID_THREADS + threadIdx.x);
+                const uint32_t out = global_find_or_insert(sgs[q], tab, mask, counters);
+                if (out != NO_SLOT && ((lowered >> q) & 1u) && tab[out].min > e) atomicMin(&tab[out].min, e);
+                slot_out[e] = out;
+            }
         }
         MID_STAMP(2);
         if (overflow) return;  // the host repeats the pass with a larger table (each wave leaves on its own: no barriers in this loop)
@@ -1856,8 +1892,11 @@ refine_label_sym_kernel(int64_t n, const uint32_t* slot, uint32_t* labels_out,
 template <class SRC> struct MidSource { static constexpr bool value = false; };
 template <> struct MidSource<SrcArray> { static constexpr bool value = true; };
 template <> struct MidSource<SrcPair> { static constexpr bool value = true; };
-// (Measured and not kept: SrcChan<int32_t, 2> and SrcJoint<2, 2> -- 83 against 54 us and 102 against 71 us for the full launch
-// at N = 4104, theta_er7xk72.)
+template <> struct MidSource<SrcChan<int32_t, 2>> { static constexpr bool value = true; };
+// (Measured and not kept: the joint source.  SrcJoint<2, 2> with its raw entries prefetched spills (107 us per launch at
+// N = 4104), without the prefetch it takes 78 - 88 + 8 us against 71 + 18 for the 256-thread kernel.  The channel source gains
+// only with the deferral in the kernel: ER(7) x K_72 is not vertex-transitive, and its large classes that the first
+// workgroups never saw took the full launch from 47 to 90 us.)
 
 template <class SRC>
 bool mid_set_attributes_kind() {
@@ -2258,6 +2297,7 @@ bool refine_mid_supports(const SigSource& q) {
     switch (q.kind) {
         case SIG_ARRAY:
         case SIG_PAIR: return true;
+        case SIG_CHAN_I32: return q.T == 2;
         default: return false;
     }
 }
@@ -2568,6 +2608,7 @@ bool partition_set_device_attributes() {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     ok &= mid_set_attributes_kind<SrcArray>();
     ok &= mid_set_attributes_kind<SrcPair>();
+    ok &= mid_set_attributes_kind<SrcChan<int32_t, 2>>();
     return ok;
 }
 
