@@ -485,9 +485,10 @@ b2_scatter_kernel(int64_t len, const uint64_t* __restrict__ sig, uint32_t NB, in
     }
     uint64_t nxt[PER];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
+    for (int q = 0; q < PER; ++q) {  // (unconditional loads, index clamped: see refine_insert_mid_kernel)
         const int64_t e = wlo + q * B2_THREADS + threadIdx.x;
-        nxt[q] = (e < whi) ? __builtin_nontemporal_load(&sig[e]) : 0ull;
+        const uint64_t v = __builtin_nontemporal_load(&sig[e < whi ? e : whi - 1]);
+        nxt[q] = (e < whi) ? v : 0ull;
     }
     __syncthreads();
     for (int64_t lo = wlo; lo < whi; lo += B2_CH) {
@@ -546,7 +547,8 @@ b2_scatter_kernel(int64_t len, const uint64_t* __restrict__ sig, uint32_t NB, in
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int64_t e = lo + B2_CH + q * B2_THREADS + threadIdx.x;
-            nxt[q] = (e < whi) ? __builtin_nontemporal_load(&sig[e]) : 0ull;
+            const uint64_t v = __builtin_nontemporal_load(&sig[e < whi ? e : whi - 1]);
+            nxt[q] = (e < whi) ? v : 0ull;
         }
         __syncthreads();
         const uint32_t staged = s_lbase[NB - 1] + s_cnt[NB - 1];
