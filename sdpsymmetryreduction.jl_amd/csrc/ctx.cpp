@@ -59,7 +59,7 @@ void* ctx_pinned(sdpsr_ctx* c, size_t bytes) {  // shared with eigen.cpp
     c->pinned = nullptr;
     c->pinned_bytes = 0;
     size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
-    if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&c->pinned, want, hipHostMallocCoherent) != hipSuccess) {  // (coherent: kernels report into it while they run, ctx_wait_word)
         c->pinned = nullptr;
         return nullptr;
     }
@@ -245,7 +245,7 @@ int sdpsr_create(int device_id, uint64_t seed, const sdpsr_opts* opts, sdpsr_ctx
     }
     c->pinned_bytes = 1 << 16;
     if (hipHostMalloc((void**)&c->pinned_small, 256, hipHostMallocDefault) != hipSuccess) c->pinned_small = nullptr;
-    if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocCoherent) != hipSuccess) {
         hipStreamDestroy(c->stream);
         delete c;
         return SDPSR_OUT_OF_MEMORY;

@@ -181,10 +181,12 @@ struct TotalEvents {
 };
 
 // canonical refinement of a signature source / array (primitives.cpp)
+// early: return as soon as the label pass has REPORTED the class count (ctx_wait_word) -- the pass itself is still running; only
+// for a caller that goes on in stream order and waits for the stream before its own return
 int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32_t* labels, int64_t* nparts, int64_t sym_n = 0,
-                      uint32_t* symflag_dev = nullptr, int* sym_out = nullptr);
+                      uint32_t* symflag_dev = nullptr, int* sym_out = nullptr, bool early = false);
 int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* labels, int64_t* nparts, int64_t sym_n = 0,
-                      uint32_t* symflag_dev = nullptr, int* sym_out = nullptr);
+                      uint32_t* symflag_dev = nullptr, int* sym_out = nullptr, bool early = false);
 
 // loop.cpp / blockdiag.cpp: the bodies of the entry points, chainable without host synchronisation in between
 // (reduce.cpp: sdpsr_jordan_reduce)

@@ -1763,10 +1763,15 @@ __global__ void refine_clear_kernel(int64_t cap, RefSlot* __restrict__ tab, uint
 // old labels from that very array.  slot may be labels_out itself (array source: in place).
 __global__ void refine_label_kernel(int64_t len, const uint32_t* slot, uint32_t* labels_out,
                                     const uint32_t* __restrict__ tab_lab, const uint32_t* __restrict__ counters,
-                                    int expect_small, uint32_t* __restrict__ host_counters) {
+                                    int expect_small, uint32_t* __restrict__ host_counters, uint32_t host_seq) {
     // the last kernel of a refinement hands the counters (inserted, overflow flag, classes) to the host itself: a
     // store into pinned host memory instead of a separate 16-byte copy launch (~5 us + a launch gap per refinement)
-    if (host_counters && blockIdx.x == 0 && threadIdx.x < 4) host_counters[threadIdx.x] = threadIdx.x < 3 ? counters[threadIdx.x] : 0u;
+    // ... and then the stamp: the host may go on as soon as it sees it (ctx_wait_word), the rest of this pass is behind it in the stream
+    if (host_counters && blockIdx.x == 0 && threadIdx.x < 64) {
+        if (threadIdx.x < 3) host_counters[threadIdx.x] = counters[threadIdx.x];
+        __threadfence_system();
+        if (threadIdx.x == 0) host_counters[3] = host_seq;
+    }
     if (counters[1] || (expect_small && counters[0] > SMALL_K)) return;
     // four consecutive entries per thread and trip: one 16-byte load, four gathers in flight together, one 16-byte store (one
     // entry per trip was a load, a wait, a gather, a wait and a store, sixteen times per thread; round 4)
@@ -2381,7 +2386,7 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
         if (sym_n % 4 == 0) refine_label_sym_kernel<true><<<dim3(t, t), 256, 0, s>>>(sym_n, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small);
         else refine_label_sym_kernel<false><<<dim3(t, t), 256, 0, s>>>(sym_n, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small);
     } else {
-        refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small, ws.host_counters);
+        refine_label_kernel<<<grid_for(len, 256), 256, 0, s>>>(len, slot, labels_out, ws.tab_lab, ws.counters, ws.expect_small, ws.host_counters, ws.host_seq);
     }
 }
 

@@ -972,7 +972,7 @@ bk_rank_finish_kernel(int64_t nwords, const uint32_t* __restrict__ blk_off, BkRa
 __global__ void __launch_bounds__(256)
 bk_label_kernel(int64_t len, const uint32_t* __restrict__ first, uint32_t* __restrict__ labels, const BkRank* __restrict__ rk,
                 const uint32_t* __restrict__ total, uint32_t* __restrict__ counters, uint32_t* __restrict__ host_counters,
-                uint32_t* __restrict__ first_idx, uint32_t first_cap) {
+                uint32_t* __restrict__ first_idx, uint32_t first_cap, uint32_t host_seq) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t d = total[0];
         counters[0] = d;
@@ -982,7 +982,8 @@ bk_label_kernel(int64_t len, const uint32_t* __restrict__ first, uint32_t* __res
             host_counters[0] = d;
             host_counters[1] = total[1];
             host_counters[2] = d;
-            host_counters[3] = 0u;
+            __threadfence_system();
+            host_counters[3] = host_seq;  // (the stamp: see refine_label_kernel)
         }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1206,7 +1207,7 @@ size_t refine_bucketed_workspace_bytes(int64_t len) {
 // resolved -- labels_out is then not a partition of the input; the caller repeats the refinement through the radix sort);
 // first_idx (may be null): first-occurrence index of class l at [l - 1] for l <= first_cap
 bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
-                            uint32_t* counters, uint32_t* first_idx, uint32_t first_cap, uint32_t* host_counters) {
+                            uint32_t* counters, uint32_t* first_idx, uint32_t first_cap, uint32_t* host_counters, uint32_t host_seq) {
     if (len < 1 || len >= (int64_t(1) << 31) || ws_bytes < refine_bucketed_workspace_bytes(len)) return false;
     const bool one_level = len <= B2_MAXLEN;
     int lg1 = 0, lg2 = 0;
@@ -1300,7 +1301,7 @@ bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uin
     bk_scan_kernel<<<1, 1024, 0, s>>>(nrb, blk_cnt, total);
     bk_rank_finish_kernel<<<(unsigned)((nrb * 64 + 255) / 256), 256, 0, s>>>((len + 63) / 64, blk_cnt, rk);
     const int64_t g = std::min<int64_t>(nrb, 256 * 8);
-    bk_label_kernel<<<(unsigned)g, 256, 0, s>>>(len, first, labels_out, rk, total, counters, host_counters, first_idx, first_cap);
+    bk_label_kernel<<<(unsigned)g, 256, 0, s>>>(len, first, labels_out, rk, total, counters, host_counters, first_idx, first_cap, host_seq);
     return true;
 }
 

@@ -112,7 +112,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
             // src/partitions.jl:128-141): the initial partition from the lower triangle, mirrored
             q.n = n;
             q.packed = 1;
-            st = refine_signatures(c, lenp, q, Lp, &d);
+            st = refine_signatures(c, lenp, q, Lp, &d, 0, nullptr, nullptr, true);  // (early report: what follows is stream-ordered)
             labels_sym = 1;
             packed_valid = true;
             full_valid = false;
@@ -123,7 +123,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
     }
     tm.end();
     if (st) return st;
-    tm.collect();  // (the refinement has synchronised the stream)
+    tm.collect();  // (intervals whose end has not passed yet stay pending: the refinement may have returned on its label pass's report)
     c->adm_dims.assign(1, d);
     if (label_overflows(c, (uint64_t)d)) return label_overflow_fail(c, "admissible_subspace: dim(S)", (uint64_t)d);
     // Projection on the lower triangle (half the bytes and hashes of the step) needs symmetric
@@ -258,7 +258,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                     }
                 }
                 if (unchanged) dj = current;  // labels, class representatives and table hints stay as they are
-                else st = refine_signatures(c, lenp, qj, Lp, &dj);
+                else st = refine_signatures(c, lenp, qj, Lp, &dj, 0, nullptr, nullptr, true);
                 packed_valid = true;
                 full_valid = false;
                 tm.end();
@@ -324,7 +324,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
         int64_t d1 = 0;
         if (packed_proj) {
             // symmetric by construction: refine the packed lower triangle (in place when the labels were packed)
-            st = refine_signatures(c, lenp, qp, Lp, &d1);
+            st = refine_signatures(c, lenp, qp, Lp, &d1, 0, nullptr, nullptr, true);
             packed_valid = true;
             full_valid = false;
             if (!st && !keep_packed) need_full();
@@ -420,7 +420,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                 // symmetric labels: the signatures exist for the packed lower triangle only;
                 // refine n (n + 1) / 2 entries (same relative order, same canonical numbering);
                 // the full symmetric matrix is formed when somebody needs it
-                st = refine_signatures(c, lenp, qs, Lp, &d2);
+                st = refine_signatures(c, lenp, qs, Lp, &d2, 0, nullptr, nullptr, true);
                 packed_valid = true;
                 full_valid = false;
                 if (!st && !keep_packed) need_full();

@@ -24,7 +24,7 @@ namespace sdpsr {
 // evaluated inside the insert kernel; it is written out as an array (src.sig: len entries of
 // scratch) only for the sort path or when the insert kernel has no instance for it.
 int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32_t* labels,
-                      int64_t* nparts, int64_t sym_n, uint32_t* symflag_dev, int* sym_out) {
+                      int64_t* nparts, int64_t sym_n, uint32_t* symflag_dev, int* sym_out, bool early) {
     SigSource src = src_in;
     auto materialize = [&]() -> bool {
         if (src.kind == SIG_ARRAY) return true;
@@ -75,15 +75,18 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
             uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
             if (!wsp || !counters || !firsts || !h) return SDPSR_OUT_OF_MEMORY;
             if (!materialize()) return ctx_fail(c, SDPSR_BAD_ARGUMENT, "refine: signature source needs scratch");
+            const uint32_t seq = ++c->report_seq ? c->report_seq : ++c->report_seq;  // (never 0: the pinned words start as zeros)
             if (cub ? !launch_refine_sorted(c->stream, len, src.sig, labels, wsp, wsb, counters)
-                    : !launch_refine_bucketed(c->stream, len, src.sig, labels, wsp, wsb, counters, firsts, refine_first_cap(), h))
+                    : !launch_refine_bucketed(c->stream, len, src.sig, labels, wsp, wsb, counters, firsts, refine_first_cap(), h, seq))
                 return ctx_fail(c, SDPSR_HIP_ERROR, "sorted / bucketed refinement failed");
             if (cub) HIP_TRY(c, hipMemcpyAsync(h, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));  // (the grouping's label pass stores them itself)
             if (sym_n > 0 && symflag_dev) {
                 launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);
                 HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             }
-            HIP_TRY(c, ctx_sync_stream(c, c->stream));
+            // (early: the caller only needs the label pass's report and waits for the stream itself before it returns)
+            if (early && !cub && !(sym_n > 0 && symflag_dev)) HIP_TRY(c, ctx_wait_word(c, c->stream, h + 3, seq));
+            else HIP_TRY(c, ctx_sync_stream(c, c->stream));
             HIP_TRY(c, hipGetLastError());
             if (h[1]) {
                 // a bucket the grouping could not resolve (signatures that do not spread over its sub-passes): the radix sort
@@ -129,13 +132,15 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
         uint32_t* h = (uint32_t*)ctx_pinned(c, 64);
         if (!h) return ctx_fail(c, SDPSR_OUT_OF_MEMORY, "pinned staging");
         ws.host_counters = sym_fused ? nullptr : h;  // the plain label pass stores the counters into the pinned buffer itself
+        ws.host_seq = ++c->report_seq ? c->report_seq : ++c->report_seq;
         launch_refine(c->stream, len, src, slot, labels, ws, sym_fused ? sym_n : 0);
         if (!ws.host_counters) HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         if (sym_n > 0 && symflag_dev && !sym_fused) {
             launch_check_symmetric(c->stream, sym_n, labels, symflag_dev);  // flag = 1 if NOT symmetric
             HIP_TRY(c, hipMemcpyAsync(h + 8, symflag_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         }
-        HIP_TRY(c, ctx_sync_stream(c, c->stream));
+        if (early && ws.host_counters && !(sym_n > 0 && symflag_dev)) HIP_TRY(c, ctx_wait_word(c, c->stream, h + 3, ws.host_seq));
+        else HIP_TRY(c, ctx_sync_stream(c, c->stream));
         if (sym_fused) h[8] = h[3];
         if (sym_n > 0 && (symflag_dev || sym_fused) && sym_out) *sym_out = h[8] ? 0 : 1;
         HIP_TRY(c, hipGetLastError());
@@ -196,11 +201,11 @@ int refine_signatures(sdpsr_ctx* c, int64_t len, const SigSource& src_in, uint32
 }
 
 int refine_signatures(sdpsr_ctx* c, int64_t len, const uint64_t* sig, uint32_t* labels,
-                      int64_t* nparts, int64_t sym_n, uint32_t* symflag_dev, int* sym_out) {
+                      int64_t* nparts, int64_t sym_n, uint32_t* symflag_dev, int* sym_out, bool early) {
     SigSource src;
     src.kind = SIG_ARRAY;
     src.sig = const_cast<uint64_t*>(sig);
-    return refine_signatures(c, len, src, labels, nparts, sym_n, symflag_dev, sym_out);
+    return refine_signatures(c, len, src, labels, nparts, sym_n, symflag_dev, sym_out, early);
 }
 
 }  // namespace sdpsr

@@ -81,6 +81,7 @@ struct sdpsr_ctx {
     bool predict_closed = false;
     int64_t predict_n = 0;
     uint64_t host_waits = 0;                 // host waits for one of this ctx's streams (ctx_sync_stream); sdpsr_profile_host_waits
+    uint32_t report_seq = 0;                 // stamps of the label passes' reports to pinned memory (ctx_wait_word)
 };
 
 // sdpsr_problem_create: the loop's inputs, device-resident, shared (read-only) by every reduction / restart that names them
@@ -109,6 +110,37 @@ inline hipError_t ctx_sync_stream(sdpsr_ctx* c, hipStream_t s) {
         }
         c->yield_fn(c->yield_arg);
     }
+}
+
+// Wait for a REPORT instead of for the stream: a kernel has been told to store its result words into pinned host memory and
+// then the stamp `seq` into *w (system-scope fence in between).  The label pass of a refinement knows its counters when it
+// STARTS -- the ranking kernels before it produced them -- so the host has them ~15 us before the pass ends and enqueues the
+// next kernels meanwhile (they follow in stream order).  Only for callers whose own return is covered by a later wait for
+// the stream (the loop of admissible_subspace): the stream is NOT idle when this returns.  The stream is still asked now
+// and then: a failed launch or a kernel that never reports must not hang the host.
+inline hipError_t ctx_wait_word(sdpsr_ctx* c, hipStream_t s, const volatile uint32_t* w, uint32_t seq) {
+    ++c->host_waits;
+    const hipError_t before = hipPeekAtLastError();
+    bool queried = false;
+    hipError_t res = hipSuccess;
+    for (unsigned spins = 1;; ++spins) {
+        if (*w == seq) break;
+        if (c->yield_fn || (spins & 2047u) == 0) {
+            queried = true;
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) {  // drained (or failed): the report is there, or will never be
+                res = e != hipSuccess ? e : (*w == seq ? hipSuccess : hipErrorUnknown);
+                break;
+            }
+            if (c->yield_fn) c->yield_fn(c->yield_arg);
+        } else {
+            __builtin_ia32_pause();
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (queried && hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
+    if (res == hipSuccess && before != hipSuccess && before != hipErrorNotReady) return before;
+    return res;
 }
 
 void* ctx_buf(sdpsr_ctx* c, const char* name, size_t bytes);  // throws std::bad_alloc-like via status
@@ -196,6 +228,7 @@ struct RefineWs {
     uint32_t* blk_cnt;   // nblk + 1
     int insert_wgs_per_cu = 0;  // sdpsr_opts.insert_wgs_per_cu (0 = default)
     uint32_t* host_counters = nullptr;  // pinned host memory: counters[0..2] are also stored there by the label pass (plain label pass only)
+    uint32_t host_seq = 0;              // ... and then this stamp into word 3: the host may read the three words once it sees the stamp
     int mid = 0;           // array source, ~1000 .. 6000 classes predicted: the one-workgroup-per-CU LDS table (refine_insert_mid_kernel)
     int expect_small = 0;  // host prediction: <= refine_small_k() classes (see launch_refine)
     uint32_t* first_idx = nullptr;  // optional: first-occurrence index of class l at [l - 1], l <= refine_first_cap()
@@ -246,7 +279,7 @@ void launch_refine(hipStream_t s, int64_t len, const SigSource& q, uint32_t* slo
 size_t refine_bucketed_workspace_bytes(int64_t len);
 bool refine_bucket_set_device_attributes();
 bool launch_refine_bucketed(hipStream_t s, int64_t len, const uint64_t* sig, uint32_t* labels_out, void* ws, size_t ws_bytes,
-                            uint32_t* counters, uint32_t* first_idx, uint32_t first_cap, uint32_t* host_counters = nullptr);
+                            uint32_t* counters, uint32_t* first_idx, uint32_t first_cap, uint32_t* host_counters = nullptr, uint32_t host_seq = 0);
 size_t refine_rank_slots_workspace_bytes(int64_t len);
 bool launch_rank_slots(hipStream_t s, int64_t len, int64_t cap, const RefSlot* tab, uint32_t* tab_lab,
                        uint32_t* counters, uint32_t small_k, uint32_t* first_idx, uint32_t first_cap, void* ws, size_t ws_bytes);
