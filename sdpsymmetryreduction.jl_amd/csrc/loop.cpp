@@ -229,6 +229,11 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                     uint32_t* hv = (uint32_t*)ctx_pinned(c, 1024);
                     if (!vref || !first || !hv) return SDPSR_OUT_OF_MEMORY;
                     hv += 128;
+                    // (inside sdpsr_jordan_reduce, on a guess that the input is closed: both verdicts go to words nobody else writes
+                    // and are read by the reduction behind its next host waits, not here)
+                    const bool guess = it == 1 && !confirming && confirm_left > 0 && c->predict_closed && c->predict_n == n;
+                    const bool defer = guess && c->allow_deferred_verdict && c->pinned_small != nullptr;
+                    if (defer) hv = c->pinned_small + 8;
                     if (launch_verify_no_split(s, qv, current, first, vref, hv)) {  // the verdict is stored straight into pinned host memory
                         // An input that was closed the last time (the restarts of ONE problem, the use this library is
                         // built for) will be closed again: the confirm round -- a fresh square into its own buffers and its
@@ -237,7 +242,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                         // either way (the first verdict decides first, exactly as without the guess).
                         bool spec = false;
                         uint32_t* hv2 = hv + 16;
-                        if (it == 1 && !confirming && confirm_left > 0 && c->predict_closed && c->predict_n == n) {
+                        if (guess) {
                             void* Xs = ctx_buf(c, "adm_xi8_spec", (size_t)T * ld * ld);
                             void* Cs = ctx_buf(c, "adm_ci32_spec", (size_t)T * ld * ld * 4);
                             void* vref2 = ctx_buf(c, "adm_vref2", verify_ref_bytes(current));
@@ -251,10 +256,17 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                                 spec = launch_verify_no_split(s, q2, current, first, vref2, hv2);
                             }
                         }
-                        HIP_TRY(c, ctx_sync_stream(c, s));
-                        HIP_TRY(c, hipGetLastError());
-                        unchanged = hv[0] == 0;
-                        spec_confirmed = spec && unchanged && hv2[0] == 0;
+                        if (defer && spec) {
+                            c->deferred_verdict = hv;  // hv[0], hv[16]: read in reduce.cpp
+                            HIP_TRY(c, hipGetLastError());
+                            unchanged = true;
+                            spec_confirmed = true;
+                        } else {
+                            HIP_TRY(c, ctx_sync_stream(c, s));
+                            HIP_TRY(c, hipGetLastError());
+                            unchanged = hv[0] == 0;
+                            spec_confirmed = spec && unchanged && hv2[0] == 0;
+                        }
                     }
                 }
                 if (unchanged) dj = current;  // labels, class representatives and table hints stay as they are

@@ -35,8 +35,11 @@ int jordan_reduce_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* 
     c->bd_labels_ext = nullptr;
     double pm_a[SDPSR_T_COUNT] = {}, pm_b[SDPSR_T_COUNT] = {}, pm_i[SDPSR_T_COUNT] = {};
     int labels_sym = 0;
+    c->deferred_verdict = nullptr;
+    c->allow_deferred_verdict = true;  // (the loop's last verdicts may ride on this reduction's later host waits, see sdpsr_internal.h)
     st = admissible_subspace_impl(c, n, CL, X0L, U, r, atol, L, dim_out, iters_out, phase_ms ? pm_a : nullptr, mem_in, SDPSR_MEM_DEVICE,
                                   /*final_sync=*/false, &labels_sym);
+    c->allow_deferred_verdict = false;
     const int st_loop = st;
     if (st && st != SDPSR_NOT_CONVERGED) return st;
     if (P_out && !in_place) {  // stream-ordered; complete when the call returns (it ends with a synchronisation on every path)
@@ -81,6 +84,19 @@ int jordan_reduce_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* 
     if (!images_done) {  // (sdpsr_block_images ends synchronised, and nothing has been enqueued since)
         const hipError_t e = ctx_sync_stream(c, s);
         if (e != hipSuccess && st == SDPSR_OK) st = ctx_fail(c, SDPSR_HIP_ERROR, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+    if (c->deferred_verdict) {
+        // The stream has been waited for: the verdicts the loop left unread are in.  A violated one means the loop stopped on a
+        // partition that one more step would have refined -- whatever blockDiagonalize made of it (a failure included) is void;
+        // the reduction is done again, this time reading the verdicts where they arise.
+        const volatile uint32_t* dv = c->deferred_verdict;
+        c->deferred_verdict = nullptr;
+        if (dv[0] != 0 || dv[16] != 0) {
+            c->predict_closed = false;
+            if (dbg_on()) fprintf(stderr, "[sdpsr] jordan_reduce: the input was not closed after all (deferred verdicts %u %u): reduction repeated\n", dv[0], dv[16]);
+            return jordan_reduce_impl(c, n, CL, X0L, U, r, atol, epsilon, P_out, dim_out, iters_out, nblocks, sum_sq, sum_s, blks, blks_capacity, Q_hat,
+                                      qhat_capacity, phase_ms, mem_in, mem_out);
+        }
     }
     if (phase_ms) {
         for (int i = 0; i < SDPSR_T_COUNT; ++i) phase_ms[i] = pm_a[i] + pm_b[i] + pm_i[i];

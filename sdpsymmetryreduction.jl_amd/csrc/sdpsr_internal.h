@@ -82,6 +82,12 @@ struct sdpsr_ctx {
     int64_t predict_n = 0;
     uint64_t host_waits = 0;                 // host waits for one of this ctx's streams (ctx_sync_stream); sdpsr_profile_host_waits
     uint32_t report_seq = 0;                 // stamps of the label passes' reports to pinned memory (ctx_wait_word)
+    // sdpsr_jordan_reduce: the loop may leave the verdicts of its LAST verify passes (first iteration of an input predicted
+    // closed: the verify pass and the speculative confirm round) unread and return "converged"; the reduction goes on in stream
+    // order and reads them behind its next host waits (reduce.cpp) -- one host wait less per reduction.  Violated verdicts
+    // discard everything and the reduction is repeated without the guess.
+    bool allow_deferred_verdict = false;
+    const volatile uint32_t* deferred_verdict = nullptr;  // words [0] and [16] must be 0
 };
 
 // sdpsr_problem_create: the loop's inputs, device-resident, shared (read-only) by every reduction / restart that names them

@@ -1677,6 +1677,58 @@ def test_complex_path_largest_orders(pkg, problems):
             assert np.allclose(bd.blks[c][k], q.conj().T @ (M @ q), atol=1e-7), (k, c)
 
 
+def test_deferred_verdicts_of_a_wrong_guess_repeat_the_reduction(pkg, problems, golden, capfd, monkeypatch):
+    """sdpsr_jordan_reduce on a ctx whose previous input of this order was closed leaves the verdicts of the first verify pass
+    and of the speculative confirm round unread, goes on into blockDiagonalize in stream order and reads them behind its later
+    host waits (one host wait less per reduction).  (a) closed input again: same partition, same block sizes, fewer host
+    waits than the ctx's first reduction; (b) an input of the SAME order that is not closed (theta' of C_16 [] K_16, N = 256, after
+    circ256: the loop starts from {diagonal, edges, non-edges} on the packed lower triangle, the shape the guess applies to): the
+    guess is wrong, the verdicts say so, everything is discarded and the reduction repeated -- the generator's closure, block
+    sizes and iteration count as on a fresh ctx."""
+    L = pkg._lib
+    prof = L.load_prof_library()
+    Lc = golden["circ256_P"].astype(np.int64)
+    closed = pkg.admissible_setup(*problems.partition_as_sdp(Lc, seed=1))
+    Cv, A, b, Le, dopen = problems.theta_prime_product_problem(problems.cycle_adjacency(16), problems.symmetric_circulant_labels(16), 16, seed=1)
+    open_ = pkg.admissible_setup(Cv, A, b)
+    assert closed[0] == open_[0] == 256
+
+    def reduce(ctx, setup):
+        n, CL, X0L, U = setup
+        Uf = np.asfortranarray(U)
+        P = np.zeros(n * n, dtype=np.uint32)
+        dd, it, nb, ssq, ss = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        w0, w1 = C.c_uint64(0), C.c_uint64(0)
+        if setup.hint:
+            ctx._lib.sdpsr_hint_symmetric_basis(ctx._h, setup.hint)
+        ctx.check(prof.sdpsr_profile_host_waits(ctx._h, C.byref(w0)))
+        ctx.check(ctx._lib.sdpsr_jordan_reduce(ctx._h, n, C.c_void_p(CL.ctypes.data), C.c_void_p(X0L.ctypes.data), C.c_void_p(Uf.ctypes.data), U.shape[1],
+                                               pkg.api.RTOL_DEFAULT, pkg.api.RTOL_DEFAULT, C.c_void_p(P.ctypes.data), C.byref(dd), C.byref(it), C.byref(nb),
+                                               C.byref(ssq), C.byref(ss), None, 0, None, 0, None, L.MEM_HOST))
+        ctx.check(prof.sdpsr_profile_host_waits(ctx._h, C.byref(w1)))
+        sizes = np.zeros(nb.value, dtype=np.int32)
+        ctx.check(ctx._lib.sdpsr_block_sizes(ctx._h, sizes.ctypes.data_as(C.c_void_p)))
+        return P.reshape(n, n, order="F"), dd.value, it.value, sorted(int(x) for x in sizes), w1.value - w0.value
+
+    with pkg.Context(seed=11) as fresh:
+        Pe, de, ite, blke, _ = reduce(fresh, open_)
+    assert np.array_equal(Pe, Le) and de == dopen and ite > 1
+    with pkg.Context(seed=12) as ctx:
+        P1, d1, it1, blk1, waits1 = reduce(ctx, closed)   # no guess yet
+        P2, d2, it2, blk2, waits2 = reduce(ctx, closed)   # guessed closed, verdicts deferred
+        assert np.array_equal(P1, Lc) and np.array_equal(P2, Lc) and d1 == d2 and it1 == it2 == 1
+        assert blk1 == blk2 == sorted(int(x) for x in golden["circ256_blk"])
+        assert waits2 < waits1, (waits1, waits2)
+        monkeypatch.setenv("SDPSR_DEBUG", "1")             # (read by the library at every trace point)
+        capfd.readouterr()
+        P3, d3, it3, blk3, _ = reduce(ctx, open_)          # same order, NOT closed: the guess is wrong
+        monkeypatch.delenv("SDPSR_DEBUG")
+        assert "not closed after all" in capfd.readouterr().err  # the repeated reduction is what ran
+        assert np.array_equal(P3, Le) and d3 == de and it3 == ite and blk3 == blke
+        P4, d4, it4, blk4, _ = reduce(ctx, closed)          # and the ctx has unlearnt the guess
+        assert np.array_equal(P4, Lc) and blk4 == blk1
+
+
 def test_problem_handle_uploads_once(pkg, problems, golden):
     """Upload once, restart many: the PCIe bytes of a 4-restart batch from HOST arrays are those of
     one call -- through the problem handle (sdpsr_problem_create + sdpsr_problem_reduce_batch: nothing but small words
