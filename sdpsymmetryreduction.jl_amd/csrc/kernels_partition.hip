@@ -1297,12 +1297,15 @@ refine_insert_kernel(int64_t len, const SRC src,
 // no barrier after the table is cleared.
 // The lane whose compare-and-swap puts a signature into the LDS table publishes it: global find-or-insert, minimum, then
 // the slot's word = (ordinal of the workgroup's chunk << 20) | global slot.  An entry that finds the word still
-// pending goes to the global table itself; nobody waits for anybody.  The minimum: the workgroup's chunks come in
+// pending is set aside and looked at again behind the chunk's other entries (a bounded number of times; asking the global
+// table itself is what thousands of lanes of one large new class would do at the same moment).  The minimum: the workgroup's chunks come in
 // increasing index order, so an entry of chunk j cannot lower the minimum of a class published in an OLDER chunk (word
 // ordinal < j) and takes its slot at once -- the steady state.  Otherwise (same or newer chunk: the waves drift apart)
 // it lowers the slot's LDS minimum first and goes to the global minimum only if it did -- the LDS minimum only ever holds
 // indices whose owners do go there.  A table that fills up (probe sequences beyond MID_MAX_PROBES) sends the extra
 // signatures to the global table entry by entry.
+// A short first launch (PER = 1: sixteen workgroups, one entry per thread, publishing behind a barrier) goes over the first
+// 16 384 entries; the full launch preloads its LDS tables with what that published (launch_insert_mid).
 // Measured and not kept (3000 classes, N = 4096, stamps below): a barrier per chunk with the new signatures published from a
 // list (143 us against 133: every wave sits through every other wave's latencies); the work of a chunk ordered by kind --
 // all home slots, then each lane walking only ITS entries that need probing, then the global home slots of all entries
