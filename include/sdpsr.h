@@ -138,7 +138,11 @@ enum {
        product is taken with the unnormalised column, the reflector is finished by the next launch, redundantly in every
        tile (csrc/kernels_sytrd_look.hip).  Same results to rounding; measured slower than the two-launch form on MI355X
        (DESIGN.md 4.1), kept for comparison */
-    SDPSR_FLAG_SYTRD_ONE_LAUNCH = 1u << 14
+    SDPSR_FLAG_SYTRD_ONE_LAUNCH = 1u << 14,
+    /* A/B: every host wait of the loop is a wait for the stream and every verdict is read where it arises (rounds 1-4) --
+       no return on the label pass's report, no verdicts deferred to the reduction's later waits (round 5).  Same
+       partition, iterations and dimension trajectory either way. */
+    SDPSR_FLAG_WAIT_FOR_EVERY_VERDICT = 1u << 15
 };
 
 typedef struct sdpsr_opts {

@@ -33,6 +33,7 @@ FLAG_ALWAYS_PROJECT = 1 << 11
 FLAG_SYTRD_PANELS = 1 << 12
 FLAG_COUPLING_ON_HOST = 1 << 13
 FLAG_SYTRD_ONE_LAUNCH = 1 << 14
+FLAG_WAIT_FOR_EVERY_VERDICT = 1 << 15
 BASIS_IMAGE_KERNELS = {"auto": 0, "two_stage": 1, "outer": 2, "chunk": 3}
 REFINE_PATHS = {"auto": 0, "hash": 1, "sort": 2, "bucket": 3, "no_mid": 4, "mid_no_first": 6}
 

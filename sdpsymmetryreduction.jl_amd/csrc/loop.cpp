@@ -34,6 +34,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
     int st = check_len(c, len);
     if (st) return st;
     hipStream_t s = c->stream;
+    const bool early_ok = !(c->opts.flags & SDPSR_FLAG_WAIT_FOR_EVERY_VERDICT);  // refinements return on their label pass's report (ctx_wait_word)
     PhaseTimer tm(c, phase_ms != nullptr);
     TotalEvents ev_total(phase_ms != nullptr, s);
 
@@ -112,7 +113,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
             // src/partitions.jl:128-141): the initial partition from the lower triangle, mirrored
             q.n = n;
             q.packed = 1;
-            st = refine_signatures(c, lenp, q, Lp, &d, 0, nullptr, nullptr, true);  // (early report: what follows is stream-ordered)
+            st = refine_signatures(c, lenp, q, Lp, &d, 0, nullptr, nullptr, early_ok);  // (early report: what follows is stream-ordered)
             labels_sym = 1;
             packed_valid = true;
             full_valid = false;
@@ -270,7 +271,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                     }
                 }
                 if (unchanged) dj = current;  // labels, class representatives and table hints stay as they are
-                else st = refine_signatures(c, lenp, qj, Lp, &dj, 0, nullptr, nullptr, true);
+                else st = refine_signatures(c, lenp, qj, Lp, &dj, 0, nullptr, nullptr, early_ok);
                 packed_valid = true;
                 full_valid = false;
                 tm.end();
@@ -336,7 +337,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
         int64_t d1 = 0;
         if (packed_proj) {
             // symmetric by construction: refine the packed lower triangle (in place when the labels were packed)
-            st = refine_signatures(c, lenp, qp, Lp, &d1, 0, nullptr, nullptr, true);
+            st = refine_signatures(c, lenp, qp, Lp, &d1, 0, nullptr, nullptr, early_ok);
             packed_valid = true;
             full_valid = false;
             if (!st && !keep_packed) need_full();
@@ -432,7 +433,7 @@ int admissible_subspace_impl(sdpsr_ctx* c, int64_t n, const double* CL, const do
                 // symmetric labels: the signatures exist for the packed lower triangle only;
                 // refine n (n + 1) / 2 entries (same relative order, same canonical numbering);
                 // the full symmetric matrix is formed when somebody needs it
-                st = refine_signatures(c, lenp, qs, Lp, &d2, 0, nullptr, nullptr, true);
+                st = refine_signatures(c, lenp, qs, Lp, &d2, 0, nullptr, nullptr, early_ok);
                 packed_valid = true;
                 full_valid = false;
                 if (!st && !keep_packed) need_full();

@@ -36,7 +36,7 @@ int jordan_reduce_impl(sdpsr_ctx* c, int64_t n, const double* CL, const double* 
     double pm_a[SDPSR_T_COUNT] = {}, pm_b[SDPSR_T_COUNT] = {}, pm_i[SDPSR_T_COUNT] = {};
     int labels_sym = 0;
     c->deferred_verdict = nullptr;
-    c->allow_deferred_verdict = true;  // (the loop's last verdicts may ride on this reduction's later host waits, see sdpsr_internal.h)
+    c->allow_deferred_verdict = !(c->opts.flags & SDPSR_FLAG_WAIT_FOR_EVERY_VERDICT);  // (the loop's last verdicts may ride on this reduction's later host waits, see sdpsr_internal.h)
     st = admissible_subspace_impl(c, n, CL, X0L, U, r, atol, L, dim_out, iters_out, phase_ms ? pm_a : nullptr, mem_in, SDPSR_MEM_DEVICE,
                                   /*final_sync=*/false, &labels_sym);
     c->allow_deferred_verdict = false;

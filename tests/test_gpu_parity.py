@@ -1727,6 +1727,13 @@ def test_deferred_verdicts_of_a_wrong_guess_repeat_the_reduction(pkg, problems, 
         assert np.array_equal(P3, Le) and d3 == de and it3 == ite and blk3 == blke
         P4, d4, it4, blk4, _ = reduce(ctx, closed)          # and the ctx has unlearnt the guess
         assert np.array_equal(P4, Lc) and blk4 == blk1
+    # A/B (SDPSR_FLAG_WAIT_FOR_EVERY_VERDICT: the control flow of rounds 1-4): same matrices, iterations, dimensions; more host waits
+    with pkg.Context(seed=12, flags=L.FLAG_WAIT_FOR_EVERY_VERDICT) as ctx:
+        Q1, e1, jt1, bl1, _ = reduce(ctx, closed)
+        Q2, e2, jt2, bl2, waits_ab = reduce(ctx, closed)
+        assert np.array_equal(Q2, Lc) and e2 == d2 and jt2 == it2 and bl2 == blk2 and waits_ab > waits2, (waits_ab, waits2)
+        Q3, e3, jt3, bl3, _ = reduce(ctx, open_)
+        assert np.array_equal(Q3, Le) and e3 == de and jt3 == ite and bl3 == blke
 
 
 def test_problem_handle_uploads_once(pkg, problems, golden):
